@@ -1,0 +1,170 @@
+/*
+ * stringwars_amd.h -- C ABI of the MI355X-native batched edit-distance backend.
+ *
+ * This is the drop-in boundary for the similarity hot path of ashvardanian/StringWars
+ * (`similarities/bench.rs`, `similarities/bench.py`). Every entry point below replaces one call
+ * the reference makes into `stringzilla::szs` (whose own C ABI, `stringzillas.h`, is not vendored
+ * under /root/reference) or into the per-pair CPU baselines. The `file:line` in each comment is
+ * the reference call site that the symbol serves. Plain pointers and sizes only; no C++ or torch
+ * types cross this boundary. All functions are `extern "C"`, return a status code and, when
+ * `error` is non-NULL, leave a pointer to a static NUL-terminated message in `*error`.
+ *
+ * Memory: every pointer inside a tape and every `out` pointer may be DEVICE memory (hipMalloc,
+ * torch CUDA tensors) -- used in place, the steady state the benchmark times -- or HOST memory
+ * (pageable, pinned, managed), in which case the call stages it through PCIe itself. Calls are
+ * synchronous (results are visible on return, like `compute_into`, bench.rs:478-486) unless the
+ * scope was switched to asynchronous mode with `swh_scope_set_async`.
+ */
+#ifndef STRINGWARS_AMD_H_
+#define STRINGWARS_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWH_VERSION_MAJOR 0
+#define SWH_VERSION_MINOR 1
+#define SWH_VERSION_PATCH 0
+
+/* Status codes. 0 is success; the rest map onto the `Result<_, E: Display>` errors of the szs
+ * wrappers (bench.rs:390-399 `.ok()`, :480-485 `panic!("{}", error)`, :632-635 SKIPPED). */
+typedef enum swh_status_t {
+    swh_success_k = 0,
+    swh_bad_alloc_k = 1,
+    swh_invalid_argument_k = 2,
+    swh_invalid_utf8_k = 3,        /* C callers can pass bytes that Rust `&str` never could */
+    swh_unsupported_length_k = 4,  /* "the engine may decline inputs beyond its supported length" bench.rs:394 */
+    swh_no_device_k = 5,           /* no gfx950 device / HIP runtime unavailable */
+    swh_device_error_k = 6,        /* a HIP call failed; message carries hipGetErrorString */
+    swh_not_implemented_k = 7
+} swh_status_t;
+
+#define SWH_UNBOUNDED UINT32_MAX
+
+/* Which DP algorithm a Levenshtein engine runs for unit costs (0,1,1,1). */
+typedef enum swh_algorithm_t {
+    swh_algorithm_auto_k = 0,        /* fastest measured path per length class */
+    swh_algorithm_wavefront_k = 1,   /* anti-diagonal wavefront, register-tiled, DPP hand-off */
+    swh_algorithm_bitparallel_k = 2  /* Myers/Hyyro bit-vectors, systolic over 32-row blocks */
+} swh_algorithm_t;
+
+/* ---- Device scope: replaces `DeviceScope::gpu_device(0)` (bench.rs:379, :652, :978). ------- */
+typedef struct swh_scope_s *swh_scope_t;
+
+/* Creates a scope on HIP device `device` with its own stream and scratch arena. */
+swh_status_t swh_scope_init_gpu(int device, swh_scope_t *scope, const char **error);
+/* Same, but work is enqueued on a caller-owned `hipStream_t` (e.g. torch's current stream). */
+swh_status_t swh_scope_init_gpu_stream(int device, void *hip_stream, swh_scope_t *scope, const char **error);
+/* `DeviceScope::cpu_cores(n)` (bench.rs:376-378). This backend has no CPU path: always returns
+ * swh_not_implemented_k so a harness prints SKIPPED instead of silently running a fallback. */
+swh_status_t swh_scope_init_cpu(size_t cores, swh_scope_t *scope, const char **error);
+swh_status_t swh_scope_free(swh_scope_t scope);
+/* Compute-unit count for `auto_batch_size` (utils.rs:815-819, :826-836: one SM == one core). */
+swh_status_t swh_scope_compute_units(swh_scope_t scope, size_t *compute_units);
+/* async != 0: engine calls only enqueue; `swh_scope_synchronize` makes results visible. */
+swh_status_t swh_scope_set_async(swh_scope_t scope, int async);
+swh_status_t swh_scope_synchronize(swh_scope_t scope, const char **error);
+
+/* Kernel timing (hipEvents on the scope's stream around every kernel of the last engine call).
+ * Used by bench.py's roofline object; off by default. */
+typedef struct swh_timing_t {
+    double total_ms;          /* all kernels of the last call, first-start to last-stop */
+    double dominant_ms;       /* longest single kernel */
+    char dominant_name[64];   /* its name */
+    uint64_t cells;           /* nominal DP cells of the call (sum len_s(a)*len_s(b)) */
+    uint64_t bytes;           /* algorithmic HBM bytes: symbols + offsets + results */
+    uint32_t kernels;         /* number of kernel launches */
+} swh_timing_t;
+swh_status_t swh_scope_set_profiling(swh_scope_t scope, int enabled);
+swh_status_t swh_scope_last_timing(swh_scope_t scope, swh_timing_t *timing);
+
+/* ---- Memory: `UnifiedAlloc` / `UnifiedMat` parity (bench.rs:292-295, :466-468). ------------ */
+/* Host-visible, device-readable allocation (pinned + mapped). */
+swh_status_t swh_unified_alloc(swh_scope_t scope, size_t bytes, void **pointer, const char **error);
+swh_status_t swh_unified_free(swh_scope_t scope, void *pointer);
+/* Explicit device allocation / copies for device-resident tapes (the timed steady state). */
+swh_status_t swh_device_alloc(swh_scope_t scope, size_t bytes, void **pointer, const char **error);
+swh_status_t swh_device_free(swh_scope_t scope, void *pointer);
+swh_status_t swh_copy_to_device(swh_scope_t scope, void *device_dst, const void *host_src, size_t bytes,
+                                const char **error);
+swh_status_t swh_copy_to_host(swh_scope_t scope, void *host_dst, const void *device_src, size_t bytes,
+                              const char **error);
+
+/* ---- Tapes: `BytesTapeView<u64>` / `AnyBytesTape::View64` (bench.rs:62, :134-143, :292-306). */
+/* Arrow-style: `offsets` has `count + 1` entries, string i is data[offsets[i] .. offsets[i+1]). */
+typedef struct swh_tape_u32_t { const uint8_t *data; const uint32_t *offsets; size_t count; } swh_tape_u32_t;
+typedef struct swh_tape_u64_t { const uint8_t *data; const uint64_t *offsets; size_t count; } swh_tape_u64_t;
+
+/* ---- Levenshtein: `LevenshteinDistances::new(&scope, 0, 1, 1, 1)` (bench.rs:382-393). ------ */
+typedef struct swh_levenshtein_s *swh_levenshtein_t;
+/* Costs are non-negative; gap of length k costs open + (k-1)*extend. */
+swh_status_t swh_levenshtein_init(swh_scope_t scope, int match, int mismatch, int open, int extend,
+                                  swh_levenshtein_t *engine, const char **error);
+swh_status_t swh_levenshtein_free(swh_levenshtein_t engine);
+swh_status_t swh_levenshtein_set_algorithm(swh_levenshtein_t engine, swh_algorithm_t algorithm);
+
+/* Pairwise batch, bytes as symbols: out[i] = min(d(a_i, b_i), bound + 1); bound == SWH_UNBOUNDED
+ * disables the cutoff. Replaces the per-pair loops `rapidfuzz::levenshtein::distance`
+ * (bench.rs:404-423) / `bio::levenshtein` (bench.rs:443-459) and the batched pairwise
+ * `cudf ... str.edit_distance` (similarities/bench.py:596-604). `a.count == b.count`.
+ * `out_stride_bytes` is the distance between consecutive results (>= 4; 0 means 4). */
+swh_status_t swh_levenshtein_pairs_u32tape(swh_levenshtein_t engine, swh_scope_t scope, const swh_tape_u32_t *a,
+                                           const swh_tape_u32_t *b, uint32_t bound, uint32_t *out,
+                                           size_t out_stride_bytes, const char **error);
+swh_status_t swh_levenshtein_pairs_u64tape(swh_levenshtein_t engine, swh_scope_t scope, const swh_tape_u64_t *a,
+                                           const swh_tape_u64_t *b, uint32_t bound, uint32_t *out,
+                                           size_t out_stride_bytes, const char **error);
+/* Same with Unicode scalar values as symbols: `LevenshteinDistancesUtf8` (bench.rs:386-399),
+ * `rapidfuzz::levenshtein<Chars>` (bench.rs:425-441). Invalid UTF-8 -> swh_invalid_utf8_k. */
+swh_status_t swh_levenshtein_utf8_pairs_u32tape(swh_levenshtein_t engine, swh_scope_t scope,
+                                                const swh_tape_u32_t *a, const swh_tape_u32_t *b, uint32_t bound,
+                                                uint32_t *out, size_t out_stride_bytes, const char **error);
+swh_status_t swh_levenshtein_utf8_pairs_u64tape(swh_levenshtein_t engine, swh_scope_t scope,
+                                                const swh_tape_u64_t *a, const swh_tape_u64_t *b, uint32_t bound,
+                                                uint32_t *out, size_t out_stride_bytes, const char **error);
+/* Dense cross-product `a.count x b.count`, row-major `size_t`, the literal shape of
+ * `engine.compute_into(&scope, AnyBytesTape::View64(q), Some(AnyBytesTape::View64(c)), &mut matrix)`
+ * (bench.rs:478-486, :599-603). `b == NULL` means the symmetric self-product. */
+swh_status_t swh_levenshtein_cross_u64tape(swh_levenshtein_t engine, swh_scope_t scope, const swh_tape_u64_t *a,
+                                           const swh_tape_u64_t *b, size_t *out, size_t row_stride_bytes,
+                                           const char **error);
+swh_status_t swh_levenshtein_utf8_cross_u64tape(swh_levenshtein_t engine, swh_scope_t scope,
+                                                const swh_tape_u64_t *a, const swh_tape_u64_t *b, size_t *out,
+                                                size_t row_stride_bytes, const char **error);
+
+/* ---- Needleman-Wunsch: `NeedlemanWunschScores::new(&scope, &byte_to_class, &class_costs,
+ *      open, extend)` (bench.rs:658-670, :985-997); scores are max-plus, gaps usually negative. */
+typedef struct swh_nw_s *swh_nw_t;
+/* Full 256x256 `i8` substitution matrix, row = symbol of a, column = symbol of b (config C4). */
+swh_status_t swh_nw_init(swh_scope_t scope, const int8_t *substitution_256x256, int open, int extend,
+                         swh_nw_t *engine, const char **error);
+/* The reference's 32-class form (`unary_class_costs`, bench.rs:95-108): expands to 256x256. */
+swh_status_t swh_nw_init_classes(swh_scope_t scope, const uint8_t *byte_to_class_256,
+                                 const int8_t *class_costs_32x32, int open, int extend, swh_nw_t *engine,
+                                 const char **error);
+swh_status_t swh_nw_free(swh_nw_t engine);
+/* Pairwise batch of global alignment scores (`bio ... Aligner::global(a, b).score`,
+ * bench.rs:746-765, batched). */
+swh_status_t swh_nw_pairs_u32tape(swh_nw_t engine, swh_scope_t scope, const swh_tape_u32_t *a,
+                                  const swh_tape_u32_t *b, int32_t *out, size_t out_stride_bytes,
+                                  const char **error);
+swh_status_t swh_nw_pairs_u64tape(swh_nw_t engine, swh_scope_t scope, const swh_tape_u64_t *a,
+                                  const swh_tape_u64_t *b, int32_t *out, size_t out_stride_bytes,
+                                  const char **error);
+/* Cross-product into `isize` (`UnifiedMat<isize>`, bench.rs:814-821, :872-876). */
+swh_status_t swh_nw_cross_u64tape(swh_nw_t engine, swh_scope_t scope, const swh_tape_u64_t *a,
+                                  const swh_tape_u64_t *b, ptrdiff_t *out, size_t row_stride_bytes,
+                                  const char **error);
+
+/* ---- Introspection: `log_stringzilla_metadata` (utils.rs:78-92). --------------------------- */
+const char *swh_version(void);
+/* Comma-separated capability string, e.g. "gfx950,hip,wavefront,bitparallel,utf8,nw". */
+const char *swh_capabilities(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRINGWARS_AMD_H_ */

@@ -1,0 +1,604 @@
+// api.hip -- the extern "C" boundary declared in include/stringwars_amd.h.
+//
+// Host-side plumbing only: scope/engine lifetime, residency detection and staging of host tapes,
+// scratch carving, the device pre-pass, kernel dispatch and optional hipEvent timing. There is no
+// CPU compute path in this library: without a HIP device every entry point fails with
+// swh_no_device_k.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+namespace swh {
+
+// ---- error text (static storage, one slot per thread) ----------------------------------------
+static thread_local char g_error_text[512];
+static swh_status_t fail(const char **error, swh_status_t status, const char *fmt, const char *a = "",
+                         const char *b = "") {
+    snprintf(g_error_text, sizeof g_error_text, fmt, a, b);
+    if (error) *error = g_error_text;
+    return status;
+}
+static swh_status_t fail_hip(const char **error, const HipFailure &f) {
+    snprintf(g_error_text, sizeof g_error_text, "HIP error '%s' in %s", hipGetErrorString(f.code), f.what);
+    if (error) *error = g_error_text;
+    (void)hipGetLastError();
+    return f.code == hipErrorOutOfMemory ? swh_bad_alloc_k : swh_device_error_k;
+}
+
+// ---- kernel stamps -------------------------------------------------------------------------------
+StampGuard::StampGuard(Scope *s, const char *name) : scope(s), idx(0), on(s->profiling) {
+    if (!on) return;
+    if (scope->stamps_used == scope->stamps.size()) {
+        KernelStamp st{};
+        if (hipEventCreate(&st.start) != hipSuccess || hipEventCreate(&st.stop) != hipSuccess) { on = false; return; }
+        scope->stamps.push_back(st);
+    }
+    idx = scope->stamps_used++;
+    scope->stamps[idx].name = name;
+    (void)hipEventRecord(scope->stamps[idx].start, scope->stream);
+}
+StampGuard::~StampGuard() {
+    if (on) (void)hipEventRecord(scope->stamps[idx].stop, scope->stream);
+}
+
+static void collect_timing(Scope *scope) {
+    swh_timing_t &t = scope->last_timing;
+    t.total_ms = 0; t.dominant_ms = 0; t.dominant_name[0] = 0; t.kernels = (uint32_t)scope->stamps_used;
+    if (!scope->stamps_used) return;
+    float span = 0;
+    (void)hipEventElapsedTime(&span, scope->stamps[0].start, scope->stamps[scope->stamps_used - 1].stop);
+    t.total_ms = span;
+    for (size_t i = 0; i < scope->stamps_used; ++i) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, scope->stamps[i].start, scope->stamps[i].stop);
+        if (ms > t.dominant_ms) {
+            t.dominant_ms = ms;
+            snprintf(t.dominant_name, sizeof t.dominant_name, "%s", scope->stamps[i].name);
+        }
+    }
+}
+
+// ---- scratch -------------------------------------------------------------------------------------
+struct Carver {
+    char *base; size_t used, cap;
+    template <typename T> T *take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        char *p = base ? base + used : nullptr;
+        used += bytes;
+        return (T *)p;
+    }
+};
+
+static void ensure(char *&buf, size_t &cap, size_t need) {
+    if (need <= cap) return;
+    if (buf) SWH_HIP_CHECK(hipFree(buf));
+    buf = nullptr; cap = 0;
+    size_t want = need + need / 4 + (1 << 20);
+    SWH_HIP_CHECK(hipMalloc((void **)&buf, want));
+    cap = want;
+}
+
+static bool is_device_pointer(const void *p) {
+    if (!p) return true;
+    hipPointerAttribute_t attr;
+    hipError_t err = hipPointerGetAttributes(&attr, p);
+    if (err != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// ---- one engine call ---------------------------------------------------------------------------
+struct HostTape { const uint8_t *data; const void *offsets; size_t count; int off64; };
+
+struct CallSpec {
+    HostTape a, b;
+    bool cross, utf8;
+    uint32_t bound;
+    void *out; size_t out_stride, row_stride; bool out64;
+};
+
+static uint64_t read_offset(const void *offs, int off64, size_t i, bool device, hipStream_t stream) {
+    uint64_t v = 0;
+    size_t w = off64 ? 8 : 4;
+    if (device) {
+        SWH_HIP_CHECK(hipMemcpyAsync(&v, (const char *)offs + i * w, w, hipMemcpyDeviceToHost, stream));
+        SWH_HIP_CHECK(hipStreamSynchronize(stream));
+    } else {
+        memcpy(&v, (const char *)offs + i * w, w);
+    }
+    return v;
+}
+
+static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec &spec, const char **error) {
+    if (!scope || !engine) return fail(error, swh_invalid_argument_k, "null scope or engine");
+    if (!spec.out && spec.a.count) return fail(error, swh_invalid_argument_k, "null output pointer");
+    if (!spec.cross && spec.a.count != spec.b.count)
+        return fail(error, swh_invalid_argument_k, "pairwise call needs tapes of equal count");
+    const uint64_t pairs = spec.cross ? (uint64_t)spec.a.count * spec.b.count : spec.a.count;
+    if (pairs >= 0xFFFFFFF0ull) return fail(error, swh_unsupported_length_k, "more than 2^32 pairs in one call");
+    scope->stamps_used = 0;
+    scope->last_timing = swh_timing_t{};
+    if (pairs == 0) return swh_success_k;
+    if (spec.utf8 && engine->scoring.matrix)
+        return fail(error, swh_not_implemented_k, "affine or matrix scoring over UTF-8 code points");
+    try {
+        SWH_HIP_CHECK(hipSetDevice(scope->device));
+        hipStream_t stream = scope->stream;
+        const size_t ow = spec.a.off64 ? 8 : 4;
+        const size_t elem = spec.out64 ? 8 : 4;
+
+        // -- residency --------------------------------------------------------------------------
+        bool dev_a_data = is_device_pointer(spec.a.data), dev_a_off = is_device_pointer(spec.a.offsets);
+        bool dev_b_data = is_device_pointer(spec.b.data), dev_b_off = is_device_pointer(spec.b.offsets);
+        bool dev_out = is_device_pointer(spec.out);
+        bool same_tape = spec.b.data == spec.a.data && spec.b.offsets == spec.a.offsets && spec.b.count == spec.a.count;
+        uint64_t a_bytes = 0, b_bytes = 0;
+        bool need_sizes = !dev_a_data || !dev_b_data || spec.utf8;
+        if (need_sizes) {
+            a_bytes = read_offset(spec.a.offsets, spec.a.off64, spec.a.count, dev_a_off, stream);
+            b_bytes = same_tape ? a_bytes : read_offset(spec.b.offsets, spec.b.off64, spec.b.count, dev_b_off, stream);
+        }
+        size_t out_bytes = spec.cross ? (spec.a.count ? (spec.a.count - 1) * spec.row_stride + spec.b.count * elem : 0)
+                                      : (size_t)(pairs - 1) * spec.out_stride + elem;
+
+        // -- staging of host-resident buffers -----------------------------------------------------
+        size_t stage_need = 0;
+        auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
+        if (!dev_a_data) stage_need += pad(a_bytes + 8);
+        if (!dev_a_off) stage_need += pad((spec.a.count + 1) * ow + 8);
+        if (!same_tape) {
+            if (!dev_b_data) stage_need += pad(b_bytes + 8);
+            if (!dev_b_off) stage_need += pad((spec.b.count + 1) * ow + 8);
+        }
+        if (!dev_out) stage_need += pad(out_bytes);
+        ensure(scope->stage, scope->stage_bytes, stage_need);
+        Carver st{scope->stage, 0, scope->stage_bytes};
+        auto stage_in = [&](const void *src, size_t bytes, bool dev) -> const void * {
+            if (dev) return src;
+            char *dst = st.take<char>(bytes + 8);
+            if (bytes) SWH_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+            return dst;
+        };
+        TapeRef ta, tb;
+        ta.data = stage_in(spec.a.data, a_bytes, dev_a_data);
+        ta.offsets = stage_in(spec.a.offsets, (spec.a.count + 1) * ow, dev_a_off);
+        ta.count = spec.a.count;
+        if (same_tape) tb = ta;
+        else {
+            tb.data = stage_in(spec.b.data, b_bytes, dev_b_data);
+            tb.offsets = stage_in(spec.b.offsets, (spec.b.count + 1) * ow, dev_b_off);
+            tb.count = spec.b.count;
+        }
+        char *out_dev = dev_out ? (char *)spec.out : st.take<char>(out_bytes);
+
+        // -- scratch carving ------------------------------------------------------------------------
+        const bool bitpar_ok = engine->kind == 0 && engine->unit_costs && !spec.utf8 &&
+                               engine->algorithm != swh_algorithm_wavefront_k;
+        size_t need = 0;
+        {
+            Carver probe{nullptr, 0, 0};
+            probe.take<uint32_t>(pairs);            // perm
+            probe.take<uint32_t>(kKeys);            // hist
+            probe.take<uint32_t>(kKeys);            // cursor
+            probe.take<Plan>(1);
+            probe.take<uint32_t>(pairs + 8);        // bit-parallel control + overflow list
+            if (spec.utf8) {
+                probe.take<uint32_t>(a_bytes + 4); probe.take<uint64_t>(spec.a.count + 1);
+                probe.take<uint32_t>(spec.a.count + 2 + 2 * ((spec.a.count + 1023) / 1024 + 1));
+                probe.take<uint32_t>(b_bytes + 4); probe.take<uint64_t>(spec.b.count + 1);
+                probe.take<uint32_t>(spec.b.count + 2 + 2 * ((spec.b.count + 1023) / 1024 + 1));
+                probe.take<uint32_t>(4);
+            }
+            need = probe.used;
+        }
+        ensure(scope->scratch, scope->scratch_bytes, need);
+        Carver sc{scope->scratch, 0, scope->scratch_bytes};
+        uint32_t *perm = sc.take<uint32_t>(pairs);
+        uint32_t *hist = sc.take<uint32_t>(kKeys);
+        uint32_t *cursor = sc.take<uint32_t>(kKeys);
+        Plan *plan_dev = sc.take<Plan>(1);
+        uint32_t *bp_ctl = sc.take<uint32_t>(pairs + 8);
+
+        // -- UTF-8 staging ----------------------------------------------------------------------------
+        uint32_t sym_bytes = 1, off64 = (uint32_t)spec.a.off64;
+        uint32_t *invalid_dev = nullptr;
+        if (spec.utf8) {
+            auto decode = [&](const TapeRef &in, uint64_t bytes, TapeRef &out_tape) {
+                Utf8Args u{};
+                u.in = in; u.off64 = off64; u.total_bytes = bytes;
+                u.symbols = sc.take<uint32_t>(bytes + 4);
+                u.offsets = sc.take<uint64_t>(in.count + 1);
+                u.counts = sc.take<uint32_t>(in.count + 2 + 2 * ((in.count + 1023) / 1024 + 1));
+                u.invalid = invalid_dev;
+                launch_utf8_decode(scope, u);
+                out_tape.data = u.symbols; out_tape.offsets = u.offsets; out_tape.count = in.count;
+            };
+            // the flag is carved last in the probe; take it first here is fine (sizes are padded equally)
+            TapeRef da, db;
+            uint32_t *flag_slot = nullptr;
+            {
+                // reserve the flag before the decode buffers so both decodes can share it
+                flag_slot = sc.take<uint32_t>(4);
+                invalid_dev = flag_slot;
+                SWH_HIP_CHECK(hipMemsetAsync(invalid_dev, 0, 16, stream));
+            }
+            decode(ta, a_bytes, da);
+            if (same_tape) db = da; else decode(tb, b_bytes, db);
+            ta = da; tb = db;
+            sym_bytes = 4; off64 = 1;
+        }
+
+        // -- job + pre-pass -------------------------------------------------------------------------------
+        Job job{};
+        job.a = ta; job.b = tb; job.pairs = pairs; job.b_count = spec.b.count; job.cross = spec.cross ? 1 : 0;
+        job.bound = engine->kind == 0 ? spec.bound : SWH_UNBOUNDED;
+        job.out = out_dev; job.out_stride = spec.out_stride; job.row_stride = spec.row_stride;
+        job.out_elem64 = spec.out64 ? 1 : 0;
+        job.negate = engine->kind == 0 ? 1 : 0;
+
+        PrepassArgs pre{};
+        pre.job = job;
+        pre.mode = bitpar_ok ? kPlanBitParallel : kPlanWavefront;
+        pre.off64 = off64; pre.sym_bytes = sym_bytes;
+        pre.symmetric = engine->kind == 0 ? 1u : (engine->unit_costs ? 1u : 0u);  // nw: set at init when symmetric
+        pre.gap_open = engine->scoring.open; pre.gap_extend = engine->scoring.extend;
+        pre.unit_costs = engine->kind == 0 && engine->unit_costs ? 1 : 0;
+        pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.plan = plan_dev;
+        launch_prepass(scope, pre);
+
+        // The class histogram decides which kernels to launch: one small D2H copy.
+        Plan &plan = *scope->plan_host;
+        SWH_HIP_CHECK(hipMemcpyAsync(&plan, plan_dev, sizeof(Plan), hipMemcpyDeviceToHost, stream));
+        uint32_t invalid_host = 0;
+        if (spec.utf8) SWH_HIP_CHECK(hipMemcpyAsync(&invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));
+        SWH_HIP_CHECK(hipStreamSynchronize(stream));
+        if (invalid_host) {
+            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in string %u of a tape", invalid_host - 1);
+            if (error) *error = g_error_text;
+            return swh_invalid_utf8_k;
+        }
+
+        KernelArgs k{};
+        k.job = job; k.perm = perm; k.plan = plan_dev; k.scoring = engine->scoring;
+        k.off64 = off64; k.sym_bytes = sym_bytes; k.symmetric = pre.symmetric;
+        k.affine = engine->scoring.open != engine->scoring.extend ? 1 : 0;
+
+        if (bitpar_ok) {
+            KernelArgs kb = k;
+            kb.boundary = (int32_t *)bp_ctl;
+            launch_bitparallel(scope, kb, plan);
+        }
+        // wavefront classes (all of them when the plan is wavefront-only)
+        bool any_wf = false, multi = false;
+        for (int c = kClassWf16; c <= kClassWfMulti; ++c) {
+            if (!plan.class_count[c]) continue;
+            any_wf = true;
+            if (c == kClassWfMulti || (k.affine && c >= kClassWf64 + 8)) multi = true;
+        }
+        if (any_wf) {
+            if (multi) {
+                // one boundary column (H, E) per concurrently resident group
+                uint64_t stride = (uint64_t)(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb) + 64 + 16;
+                uint64_t groups = (uint64_t)scope->compute_units * 8 * 4;  // max blocks * waves (G = 64)
+                ensure(scope->boundary, scope->boundary_bytes, groups * stride * 2 * sizeof(int32_t));
+                k.boundary = (int32_t *)scope->boundary;
+                k.boundary_stride = stride;
+            }
+            launch_wavefront(scope, k, plan);
+        }
+
+        // -- results back ------------------------------------------------------------------------------------
+        if (!dev_out) SWH_HIP_CHECK(hipMemcpyAsync(spec.out, out_dev, out_bytes, hipMemcpyDeviceToHost, stream));
+        scope->last_timing.cells = plan.cells;
+        scope->last_timing.bytes = (need_sizes ? a_bytes + b_bytes : plan.symbols) + pairs * (2 * ow + elem);
+        if (!scope->async || !dev_out) {
+            SWH_HIP_CHECK(hipStreamSynchronize(stream));
+            if (scope->profiling) collect_timing(scope);
+        }
+        return swh_success_k;
+    } catch (const HipFailure &f) {
+        return fail_hip(error, f);
+    } catch (const std::bad_alloc &) {
+        return fail(error, swh_bad_alloc_k, "host allocation failed");
+    }
+}
+
+}  // namespace swh
+
+using namespace swh;
+
+// =====================================================================================================
+// extern "C"
+// =====================================================================================================
+extern "C" {
+
+const char *swh_version(void) { return "0.1.0"; }
+const char *swh_capabilities(void) { return "gfx950,hip,wavefront,bitparallel,utf8,bounded,nw-linear,nw-affine,cross"; }
+
+static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_t *out, const char **error) {
+    if (!out) return fail(error, swh_invalid_argument_k, "null scope pointer");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        return fail(error, swh_no_device_k, "no HIP device visible (this backend has no CPU path)");
+    }
+    if (device < 0 || device >= count) return fail(error, swh_no_device_k, "HIP device index out of range");
+    try {
+        SWH_HIP_CHECK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        SWH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(error, swh_no_device_k, "device is %s, this library carries gfx950 code only", prop.gcnArchName);
+        Scope *scope = new Scope();
+        scope->device = device;
+        scope->compute_units = prop.multiProcessorCount;
+        if (borrow) { scope->stream = (hipStream_t)stream; scope->owns_stream = false; }
+        else { SWH_HIP_CHECK(hipStreamCreateWithFlags(&scope->stream, hipStreamNonBlocking)); scope->owns_stream = true; }
+        SWH_HIP_CHECK(hipHostMalloc((void **)&scope->plan_host, sizeof(Plan), hipHostMallocDefault));
+        *out = (swh_scope_t)scope;
+        return swh_success_k;
+    } catch (const HipFailure &f) {
+        return fail_hip(error, f);
+    }
+}
+
+swh_status_t swh_scope_init_gpu(int device, swh_scope_t *scope, const char **error) {
+    return scope_init(device, nullptr, false, scope, error);
+}
+swh_status_t swh_scope_init_gpu_stream(int device, void *hip_stream, swh_scope_t *scope, const char **error) {
+    return scope_init(device, hip_stream, true, scope, error);
+}
+swh_status_t swh_scope_init_cpu(size_t, swh_scope_t *scope, const char **error) {
+    if (scope) *scope = nullptr;
+    return fail(error, swh_not_implemented_k, "stringwars_amd has no CPU backend; use a GPU scope");
+}
+swh_status_t swh_scope_free(swh_scope_t handle) {
+    Scope *scope = (Scope *)handle;
+    if (!scope) return swh_success_k;
+    (void)hipSetDevice(scope->device);
+    (void)hipStreamSynchronize(scope->stream);
+    for (auto &st : scope->stamps) { (void)hipEventDestroy(st.start); (void)hipEventDestroy(st.stop); }
+    if (scope->scratch) (void)hipFree(scope->scratch);
+    if (scope->stage) (void)hipFree(scope->stage);
+    if (scope->boundary) (void)hipFree(scope->boundary);
+    if (scope->plan_host) (void)hipHostFree(scope->plan_host);
+    if (scope->owns_stream) (void)hipStreamDestroy(scope->stream);
+    delete scope;
+    return swh_success_k;
+}
+swh_status_t swh_scope_compute_units(swh_scope_t handle, size_t *cus) {
+    if (!handle || !cus) return swh_invalid_argument_k;
+    *cus = (size_t)((Scope *)handle)->compute_units;
+    return swh_success_k;
+}
+swh_status_t swh_scope_set_async(swh_scope_t handle, int async) {
+    if (!handle) return swh_invalid_argument_k;
+    ((Scope *)handle)->async = async != 0;
+    return swh_success_k;
+}
+swh_status_t swh_scope_synchronize(swh_scope_t handle, const char **error) {
+    Scope *scope = (Scope *)handle;
+    if (!scope) return fail(error, swh_invalid_argument_k, "null scope");
+    hipError_t err = hipStreamSynchronize(scope->stream);
+    if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipStreamSynchronize"});
+    if (scope->profiling) collect_timing(scope);
+    return swh_success_k;
+}
+swh_status_t swh_scope_set_profiling(swh_scope_t handle, int enabled) {
+    if (!handle) return swh_invalid_argument_k;
+    ((Scope *)handle)->profiling = enabled != 0;
+    return swh_success_k;
+}
+swh_status_t swh_scope_last_timing(swh_scope_t handle, swh_timing_t *timing) {
+    if (!handle || !timing) return swh_invalid_argument_k;
+    *timing = ((Scope *)handle)->last_timing;
+    return swh_success_k;
+}
+
+// ---- memory --------------------------------------------------------------------------------------
+swh_status_t swh_unified_alloc(swh_scope_t handle, size_t bytes, void **pointer, const char **error) {
+    if (!handle || !pointer) return fail(error, swh_invalid_argument_k, "null argument");
+    (void)hipSetDevice(((Scope *)handle)->device);
+    hipError_t err = hipHostMalloc(pointer, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable);
+    if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipHostMalloc"});
+    return swh_success_k;
+}
+swh_status_t swh_unified_free(swh_scope_t, void *pointer) {
+    if (pointer) (void)hipHostFree(pointer);
+    return swh_success_k;
+}
+swh_status_t swh_device_alloc(swh_scope_t handle, size_t bytes, void **pointer, const char **error) {
+    if (!handle || !pointer) return fail(error, swh_invalid_argument_k, "null argument");
+    (void)hipSetDevice(((Scope *)handle)->device);
+    hipError_t err = hipMalloc(pointer, bytes ? bytes : 1);
+    if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipMalloc"});
+    return swh_success_k;
+}
+swh_status_t swh_device_free(swh_scope_t, void *pointer) {
+    if (pointer) (void)hipFree(pointer);
+    return swh_success_k;
+}
+swh_status_t swh_copy_to_device(swh_scope_t handle, void *dst, const void *src, size_t bytes, const char **error) {
+    Scope *scope = (Scope *)handle;
+    if (!scope) return fail(error, swh_invalid_argument_k, "null scope");
+    hipError_t err = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, scope->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(scope->stream);
+    if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipMemcpy H2D"});
+    return swh_success_k;
+}
+swh_status_t swh_copy_to_host(swh_scope_t handle, void *dst, const void *src, size_t bytes, const char **error) {
+    Scope *scope = (Scope *)handle;
+    if (!scope) return fail(error, swh_invalid_argument_k, "null scope");
+    hipError_t err = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, scope->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(scope->stream);
+    if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipMemcpy D2H"});
+    return swh_success_k;
+}
+
+// ---- engines --------------------------------------------------------------------------------------
+static swh_status_t upload_matrix(Engine *engine, const int8_t *matrix, const char **error) {
+    hipError_t err = hipMalloc((void **)&engine->matrix_dev, 65536);
+    if (err == hipSuccess) err = hipMemcpy(engine->matrix_dev, matrix, 65536, hipMemcpyHostToDevice);
+    if (err != hipSuccess) return fail_hip(error, HipFailure{err, "substitution matrix upload"});
+    engine->scoring.matrix = engine->matrix_dev;
+    return swh_success_k;
+}
+
+swh_status_t swh_levenshtein_init(swh_scope_t handle, int match, int mismatch, int open, int extend,
+                                  swh_levenshtein_t *out, const char **error) {
+    if (!handle || !out) return fail(error, swh_invalid_argument_k, "null argument");
+    if (match < 0 || mismatch < 0 || open < 0 || extend < 0 || match > 127 || mismatch > 127 || open > 4096 ||
+        extend > 4096)
+        return fail(error, swh_invalid_argument_k, "Levenshtein costs must be small non-negative integers");
+    Scope *scope = (Scope *)handle;
+    Engine *engine = new Engine{};
+    engine->kind = 0;
+    engine->device = scope->device;
+    engine->unit_costs = match == 0 && mismatch == 1 && open == 1 && extend == 1;
+    engine->algorithm = swh_algorithm_auto_k;
+    // max-plus core: distances are negated scores
+    engine->scoring = Scoring{-match, -mismatch, -open, -extend, nullptr};
+    if (open != extend) {
+        // affine gaps run on the matrix kernels: expand the uniform costs into a 256x256 table
+        static thread_local int8_t table[65536];
+        for (int i = 0; i < 256; ++i)
+            for (int j = 0; j < 256; ++j) table[i * 256 + j] = (int8_t)(i == j ? -match : -mismatch);
+        (void)hipSetDevice(scope->device);
+        swh_status_t st = upload_matrix(engine, table, error);
+        if (st != swh_success_k) { delete engine; return st; }
+    }
+    *out = (swh_levenshtein_t)engine;
+    return swh_success_k;
+}
+swh_status_t swh_levenshtein_free(swh_levenshtein_t handle) {
+    Engine *engine = (Engine *)handle;
+    if (!engine) return swh_success_k;
+    if (engine->matrix_dev) { (void)hipSetDevice(engine->device); (void)hipFree(engine->matrix_dev); }
+    delete engine;
+    return swh_success_k;
+}
+swh_status_t swh_levenshtein_set_algorithm(swh_levenshtein_t handle, swh_algorithm_t algorithm) {
+    if (!handle) return swh_invalid_argument_k;
+    ((Engine *)handle)->algorithm = algorithm;
+    return swh_success_k;
+}
+
+swh_status_t swh_nw_init(swh_scope_t handle, const int8_t *matrix, int open, int extend, swh_nw_t *out,
+                         const char **error) {
+    if (!handle || !out || !matrix) return fail(error, swh_invalid_argument_k, "null argument");
+    if (open > 0 || extend > 0 || open < -4096 || extend < -4096)
+        return fail(error, swh_invalid_argument_k, "gap costs must be in [-4096, 0]");
+    Scope *scope = (Scope *)handle;
+    Engine *engine = new Engine{};
+    engine->kind = 1;
+    engine->device = scope->device;
+    engine->algorithm = swh_algorithm_wavefront_k;
+    engine->scoring = Scoring{0, 0, open, extend, nullptr};
+    bool symmetric = true;
+    for (int i = 0; i < 256 && symmetric; ++i)
+        for (int j = 0; j < i; ++j)
+            if (matrix[i * 256 + j] != matrix[j * 256 + i]) { symmetric = false; break; }
+    engine->unit_costs = symmetric;  // reused as "columns may be swapped" for nw engines
+    (void)hipSetDevice(scope->device);
+    swh_status_t st = upload_matrix(engine, matrix, error);
+    if (st != swh_success_k) { delete engine; return st; }
+    *out = (swh_nw_t)engine;
+    return swh_success_k;
+}
+swh_status_t swh_nw_init_classes(swh_scope_t handle, const uint8_t *byte_to_class, const int8_t *class_costs, int open,
+                                 int extend, swh_nw_t *out, const char **error) {
+    if (!byte_to_class || !class_costs) return fail(error, swh_invalid_argument_k, "null argument");
+    static thread_local int8_t table[65536];
+    for (int i = 0; i < 256; ++i) {
+        if (byte_to_class[i] >= 32) return fail(error, swh_invalid_argument_k, "byte_to_class entries must be < 32");
+        for (int j = 0; j < 256; ++j) {
+            if (byte_to_class[j] >= 32) return fail(error, swh_invalid_argument_k, "byte_to_class entries must be < 32");
+            table[i * 256 + j] = class_costs[byte_to_class[i] * 32 + byte_to_class[j]];
+        }
+    }
+    return swh_nw_init(handle, table, open, extend, out, error);
+}
+swh_status_t swh_nw_free(swh_nw_t handle) { return swh_levenshtein_free((swh_levenshtein_t)handle); }
+
+// ---- calls -----------------------------------------------------------------------------------------
+#define SWH_TAPE(t, w) HostTape{(t)->data, (const void *)(t)->offsets, (t)->count, (w)}
+
+static swh_status_t lev_pairs(swh_levenshtein_t e, swh_scope_t s, HostTape a, HostTape b, bool utf8, uint32_t bound,
+                              uint32_t *out, size_t stride, const char **error) {
+    if (e && ((Engine *)e)->kind != 0) return fail(error, swh_invalid_argument_k, "not a Levenshtein engine");
+    CallSpec spec{a, b, false, utf8, bound, out, stride ? stride : 4, 0, false};
+    if (spec.out_stride < 4) return fail(error, swh_invalid_argument_k, "out_stride_bytes must be >= 4");
+    return run_call((Scope *)s, (Engine *)e, spec, error);
+}
+
+swh_status_t swh_levenshtein_pairs_u32tape(swh_levenshtein_t e, swh_scope_t s, const swh_tape_u32_t *a,
+                                           const swh_tape_u32_t *b, uint32_t bound, uint32_t *out, size_t stride,
+                                           const char **error) {
+    if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
+    return lev_pairs(e, s, SWH_TAPE(a, 0), SWH_TAPE(b, 0), false, bound, out, stride, error);
+}
+swh_status_t swh_levenshtein_pairs_u64tape(swh_levenshtein_t e, swh_scope_t s, const swh_tape_u64_t *a,
+                                           const swh_tape_u64_t *b, uint32_t bound, uint32_t *out, size_t stride,
+                                           const char **error) {
+    if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
+    return lev_pairs(e, s, SWH_TAPE(a, 1), SWH_TAPE(b, 1), false, bound, out, stride, error);
+}
+swh_status_t swh_levenshtein_utf8_pairs_u32tape(swh_levenshtein_t e, swh_scope_t s, const swh_tape_u32_t *a,
+                                                const swh_tape_u32_t *b, uint32_t bound, uint32_t *out, size_t stride,
+                                                const char **error) {
+    if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
+    return lev_pairs(e, s, SWH_TAPE(a, 0), SWH_TAPE(b, 0), true, bound, out, stride, error);
+}
+swh_status_t swh_levenshtein_utf8_pairs_u64tape(swh_levenshtein_t e, swh_scope_t s, const swh_tape_u64_t *a,
+                                                const swh_tape_u64_t *b, uint32_t bound, uint32_t *out, size_t stride,
+                                                const char **error) {
+    if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
+    return lev_pairs(e, s, SWH_TAPE(a, 1), SWH_TAPE(b, 1), true, bound, out, stride, error);
+}
+
+static swh_status_t cross_call(void *e, int kind, swh_scope_t s, const swh_tape_u64_t *a, const swh_tape_u64_t *b,
+                               bool utf8, void *out, size_t row_stride, const char **error) {
+    if (!a) return fail(error, swh_invalid_argument_k, "null tape");
+    if (e && ((Engine *)e)->kind != kind) return fail(error, swh_invalid_argument_k, "engine kind mismatch");
+    const swh_tape_u64_t *bb = b ? b : a;
+    CallSpec spec{SWH_TAPE(a, 1), SWH_TAPE(bb, 1), true, utf8, SWH_UNBOUNDED, out, 8,
+                  row_stride ? row_stride : bb->count * 8, true};
+    if (spec.row_stride < bb->count * 8) return fail(error, swh_invalid_argument_k, "row_stride_bytes too small");
+    return run_call((Scope *)s, (Engine *)e, spec, error);
+}
+swh_status_t swh_levenshtein_cross_u64tape(swh_levenshtein_t e, swh_scope_t s, const swh_tape_u64_t *a,
+                                           const swh_tape_u64_t *b, size_t *out, size_t row_stride, const char **error) {
+    return cross_call(e, 0, s, a, b, false, out, row_stride, error);
+}
+swh_status_t swh_levenshtein_utf8_cross_u64tape(swh_levenshtein_t e, swh_scope_t s, const swh_tape_u64_t *a,
+                                                const swh_tape_u64_t *b, size_t *out, size_t row_stride,
+                                                const char **error) {
+    return cross_call(e, 0, s, a, b, true, out, row_stride, error);
+}
+swh_status_t swh_nw_cross_u64tape(swh_nw_t e, swh_scope_t s, const swh_tape_u64_t *a, const swh_tape_u64_t *b,
+                                  ptrdiff_t *out, size_t row_stride, const char **error) {
+    return cross_call(e, 1, s, a, b, false, out, row_stride, error);
+}
+
+static swh_status_t nw_pairs(swh_nw_t e, swh_scope_t s, HostTape a, HostTape b, int32_t *out, size_t stride,
+                             const char **error) {
+    if (e && ((Engine *)e)->kind != 1) return fail(error, swh_invalid_argument_k, "not a Needleman-Wunsch engine");
+    CallSpec spec{a, b, false, false, SWH_UNBOUNDED, out, stride ? stride : 4, 0, false};
+    if (spec.out_stride < 4) return fail(error, swh_invalid_argument_k, "out_stride_bytes must be >= 4");
+    return run_call((Scope *)s, (Engine *)e, spec, error);
+}
+swh_status_t swh_nw_pairs_u32tape(swh_nw_t e, swh_scope_t s, const swh_tape_u32_t *a, const swh_tape_u32_t *b,
+                                  int32_t *out, size_t stride, const char **error) {
+    if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
+    return nw_pairs(e, s, SWH_TAPE(a, 0), SWH_TAPE(b, 0), out, stride, error);
+}
+swh_status_t swh_nw_pairs_u64tape(swh_nw_t e, swh_scope_t s, const swh_tape_u64_t *a, const swh_tape_u64_t *b,
+                                  int32_t *out, size_t stride, const char **error) {
+    if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
+    return nw_pairs(e, s, SWH_TAPE(a, 1), SWH_TAPE(b, 1), out, stride, error);
+}
+
+}  // extern "C"

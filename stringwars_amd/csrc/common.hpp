@@ -1,0 +1,206 @@
+// common.hpp -- shared host/device definitions of the stringwars_amd HIP backend (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/stringwars_amd.h"
+
+namespace swh {
+
+// ------------------------------------------------------------------------------------------------
+// Problem description handed to every kernel. One `Job` = one engine call.
+// ------------------------------------------------------------------------------------------------
+// Symbols are either raw tape bytes (Sym = uint8_t) or decoded Unicode scalar values
+// (Sym = uint32_t, produced by the UTF-8 staging kernel into scope scratch). Offsets are the
+// tape's own u32/u64 (bytes) or the scratch tape's u64 (code points).
+struct TapeRef {
+    const void *data;     // device pointer, Sym elements
+    const void *offsets;  // device pointer, count+1 entries
+    uint64_t count;
+};
+
+struct Job {
+    TapeRef a, b;
+    uint64_t pairs;       // number of (a_i, b_j) pairs to score
+    uint64_t b_count;     // for cross-product mode: j = p % b_count, i = p / b_count
+    uint32_t cross;       // 0 = pairwise (i == j == p), 1 = cross-product
+    uint32_t bound;       // SWH_UNBOUNDED or k: out = min(d, k+1)      (Levenshtein only)
+    char *out;            // device pointer
+    uint64_t out_stride;  // bytes between consecutive pair results (pairwise) / elements in a row
+    uint64_t row_stride;  // bytes between rows (cross)
+    uint32_t out_elem64;  // 0: 32-bit results, 1: 64-bit results (size_t / ptrdiff_t)
+    uint32_t negate;      // results are stored as -score (min-plus distances run on the max-plus core)
+};
+
+template <typename Off>
+__device__ __forceinline__ void pair_extent(const Job &job, uint64_t p, uint64_t &a0, uint32_t &la, uint64_t &b0,
+                                            uint32_t &lb) {
+    uint64_t ia = p, ib = p;
+    if (job.cross) { ia = p / job.b_count; ib = p - ia * job.b_count; }
+    const Off *oa = (const Off *)job.a.offsets, *ob = (const Off *)job.b.offsets;
+    Off x0 = oa[ia], x1 = oa[ia + 1], y0 = ob[ib], y1 = ob[ib + 1];
+    a0 = (uint64_t)x0; la = (uint32_t)(x1 - x0);
+    b0 = (uint64_t)y0; lb = (uint32_t)(y1 - y0);
+}
+
+__device__ __forceinline__ void store_result(const Job &job, uint64_t p, int64_t value) {
+    char *dst;
+    if (job.cross) {
+        uint64_t ia = p / job.b_count, ib = p - ia * job.b_count;
+        dst = job.out + ia * job.row_stride + ib * (job.out_elem64 ? 8 : 4);
+    } else {
+        dst = job.out + p * job.out_stride;
+    }
+    if (job.out_elem64) *(int64_t *)dst = value;
+    else *(int32_t *)dst = (int32_t)value;
+}
+
+// Levenshtein results honour the cutoff convention out = min(d, bound + 1).
+__device__ __forceinline__ uint32_t clamp_bound(uint32_t d, uint32_t bound) {
+    return (bound != 0xFFFFFFFFu && d > bound) ? bound + 1 : d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Work plan built on the device by the pre-pass (prepass.hip): pairs are counting-sorted by a
+// length-class key so that every wave gets pairs of one class and similar row counts.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxClasses = 96;   // kernel classes (a class = one kernel configuration)
+constexpr int kBuckets = 64;      // length buckets inside a class (sort granularity)
+constexpr int kKeys = kMaxClasses * kBuckets;
+
+struct Plan {
+    uint32_t class_start[kMaxClasses + 1];  // exclusive prefix of pairs per class into `perm`
+    uint32_t class_count[kMaxClasses];
+    uint64_t cells;                          // sum len_s(a)*len_s(b): the reference's CUPS numerator
+    uint64_t symbols;                        // sum len_s(a)+len_s(b)
+    uint32_t max_la, max_lb;
+    uint32_t invalid_utf8;                   // index+1 of the first pair with invalid UTF-8, else 0
+    uint32_t pad;
+};
+
+// Class numbering --------------------------------------------------------------------------------
+// 0                : trivial pairs (an empty side, or cutoff decided by lengths) -- finished in the pre-pass
+// 1..64            : bit-parallel, G = class = number of 32-row blocks of the shorter string
+// 65..72           : wavefront, 16 lanes per pair, W = class-64 columns per lane (cols <= 16*W)
+// 73..84           : wavefront, 64 lanes per pair, W = kWideW[class-73]
+// 85               : wavefront multi-pass (columns beyond 64*kWideW[last])
+constexpr int kClassTrivial = 0;
+constexpr int kClassBp0 = 1;
+constexpr int kClassWf16 = 65;
+constexpr int kClassWf64 = 73;
+constexpr int kNumWideW = 12;
+constexpr int kClassWfMulti = kClassWf64 + kNumWideW;
+__host__ __device__ constexpr int wide_w(int i) {
+    constexpr int w[kNumWideW] = {3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 80, 96};
+    return w[i];
+}
+
+enum PlanMode : uint32_t {
+    kPlanBitParallel = 0,  // unit-cost Levenshtein on bytes: bit-parallel where it fits, else wavefront
+    kPlanWavefront = 1,    // everything on the wavefront kernels
+};
+
+// ------------------------------------------------------------------------------------------------
+// Scoring model of the wavefront core (max-plus; distances are negated scores).
+// ------------------------------------------------------------------------------------------------
+struct Scoring {
+    int match, mismatch;   // uniform substitution (used when `matrix` is null)
+    int open, extend;      // gap(k) = open + (k-1)*extend
+    const int8_t *matrix;  // device pointer to 256x256 i8, row = a symbol, col = b symbol; or null
+};
+
+// ------------------------------------------------------------------------------------------------
+// Host-side scope.
+// ------------------------------------------------------------------------------------------------
+struct KernelStamp { hipEvent_t start, stop; const char *name; };
+
+struct Scope {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    bool async = false;
+    bool profiling = false;
+    int compute_units = 0;
+    // scratch arena (device), grown on demand, reused across calls
+    char *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // staging for host-resident inputs
+    char *stage = nullptr;
+    size_t stage_bytes = 0;
+    // right-edge columns of multi-pass wavefront groups
+    char *boundary = nullptr;
+    size_t boundary_bytes = 0;
+    Plan *plan_host = nullptr;  // pinned
+    std::vector<KernelStamp> stamps;
+    size_t stamps_used = 0;
+    swh_timing_t last_timing{};
+    std::string error;
+};
+
+struct Engine {
+    int kind;  // 0 = levenshtein, 1 = nw
+    Scoring scoring;
+    bool unit_costs;
+    swh_algorithm_t algorithm;
+    int8_t *matrix_dev;  // owned
+    int device;
+};
+
+// Kernel launch bookkeeping with optional hipEvent timing.
+struct StampGuard {
+    Scope *scope; size_t idx; bool on;
+    StampGuard(Scope *s, const char *name);
+    ~StampGuard();
+};
+
+// Launchers implemented in the kernel translation units ------------------------------------------
+struct PrepassArgs {
+    Job job;
+    uint32_t mode;          // PlanMode
+    uint32_t off64;         // offsets are u64 (else u32)
+    uint32_t sym_bytes;     // 1 or 4
+    uint32_t symmetric;     // scoring symmetric in (a,b): columns may be swapped to the shorter string
+    int gap_open, gap_extend;  // max-plus gap costs (negative for distances), for the trivial pairs
+    uint32_t unit_costs;    // Levenshtein (0,1,1,1): enables the |la-lb| > bound shortcut
+    uint32_t *perm;         // out: pair ids sorted by key
+    uint32_t *hist;         // scratch: kKeys counters
+    uint32_t *cursor;       // scratch: kKeys cursors
+    Plan *plan;             // out (device)
+};
+void launch_prepass(Scope *scope, const PrepassArgs &args);
+
+struct KernelArgs {
+    Job job;
+    const uint32_t *perm;
+    const Plan *plan;   // device
+    Scoring scoring;
+    uint32_t off64, sym_bytes, symmetric, affine;
+    int32_t *boundary;      // scratch for multi-pass wavefront
+    uint64_t boundary_stride;  // int32 elements per group slot
+};
+void launch_bitparallel(Scope *scope, const KernelArgs &args, const Plan &plan_host);
+void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan_host);
+
+// UTF-8 staging: decodes a byte tape into u32 code points + u64 code-point offsets.
+struct Utf8Args {
+    TapeRef in; uint32_t off64;
+    uint32_t *symbols;     // out, capacity = total bytes
+    uint64_t *offsets;     // out, count+1
+    uint32_t *counts;      // scratch, count entries
+    uint32_t *invalid;     // out flag: index+1 of an invalid string (0 = all valid)
+    uint64_t total_bytes;
+};
+void launch_utf8_decode(Scope *scope, const Utf8Args &args);
+
+#define SWH_HIP_CHECK(expr)                                                                          \
+    do {                                                                                              \
+        hipError_t err__ = (expr);                                                                    \
+        if (err__ != hipSuccess) throw ::swh::HipFailure{err__, #expr};                               \
+    } while (0)
+struct HipFailure { hipError_t code; const char *what; };
+
+}  // namespace swh

@@ -1,0 +1,369 @@
+// prepass.hip -- device-side planning for one engine call.
+//
+//   1. k_plan_hist    : per pair, derive its kernel class + length bucket (a "key"), finish the
+//                       trivial pairs (an empty side / cutoff decided by |la-lb|), histogram the keys,
+//                       accumulate the reference's work units (cells = len(a)*len(b), bench.rs:413).
+//   2. k_plan_scan    : exclusive scan of the key histogram -> write cursors + per-class ranges.
+//   3. k_plan_scatter : counting-sort pair ids by key into `perm` (block-local ranks in LDS, one
+//                       global atomic per (block, key)).
+//
+// Sorting by (class, length bucket) is what lets a wave64 hold pairs of one shape: equal block
+// count for the bit-parallel kernel, equal columns-per-lane for the wavefront kernel, and nearly
+// equal row counts so the lanes of a wave finish together ("load imbalance").
+//
+// Also here: UTF-8 -> code point staging (k_utf8_count / k_utf8_write) and a small device scan.
+#include "common.hpp"
+
+namespace swh {
+
+__device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t x) { return x <= 1 ? 0 : 32 - __clz(x - 1); }
+
+// Key = class * kBuckets + bucket. Must match the decode logic in the kernels (they re-derive
+// orientation from the lengths: columns = shorter string when `symmetric`).
+__device__ __forceinline__ uint32_t plan_key(uint32_t la, uint32_t lb, uint32_t mode, uint32_t symmetric,
+                                             uint32_t sym_bytes) {
+    uint32_t m = la < lb ? la : lb, n = la < lb ? lb : la;
+    if (mode == kPlanBitParallel && sym_bytes == 1) {
+        uint32_t g = (m + 31) >> 5;
+        if (g <= 64) {
+            uint32_t shift = 2 + ceil_log2_u32(g);
+            uint32_t bucket = n >> shift;
+            return (kClassBp0 + g - 1) * kBuckets + (bucket > 63 ? 63 : bucket);
+        }
+    }
+    uint32_t cols = symmetric ? m : lb, rows = symmetric ? n : la;
+    uint32_t cls, bucket;
+    if (cols <= 128) {
+        cls = kClassWf16 + ((cols + 15) >> 4) - 1;
+        bucket = rows >> 2;
+    } else {
+        cls = kClassWfMulti;
+        for (int i = 0; i < kNumWideW; ++i)
+            if (cols <= 64u * wide_w(i)) { cls = kClassWf64 + i; break; }
+        bucket = rows >> 7;
+    }
+    return cls * kBuckets + (bucket > 63 ? 63 : bucket);
+}
+
+struct PairInfo { uint32_t la, lb; bool trivial; int64_t trivial_value; };
+
+template <typename Off>
+__device__ __forceinline__ PairInfo pair_info(const PrepassArgs &args, uint64_t p, int gap_open, int gap_extend,
+                                              bool levenshtein_unit) {
+    uint64_t a0, b0;
+    PairInfo info;
+    pair_extent<Off>(args.job, p, a0, info.la, b0, info.lb);
+    info.trivial = false;
+    info.trivial_value = 0;
+    uint32_t la = info.la, lb = info.lb;
+    if (la == 0 || lb == 0) {
+        uint32_t len = la + lb;
+        info.trivial = true;
+        // gap(k) = open + (k-1)*extend; a pair of empty strings scores 0.
+        info.trivial_value = len ? (int64_t)gap_open + (int64_t)(len - 1) * gap_extend : 0;
+    } else if (levenshtein_unit && args.job.bound != 0xFFFFFFFFu) {
+        uint32_t diff = la > lb ? la - lb : lb - la;
+        if (diff > args.job.bound) { info.trivial = true; info.trivial_value = -(int64_t)(args.job.bound + 1); }
+    }
+    return info;
+}
+
+template <typename Off>
+__global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
+    __shared__ uint32_t lhist[kKeys];
+    __shared__ unsigned long long lcells, lsyms;
+    __shared__ uint32_t lmaxa, lmaxb;
+    for (int i = threadIdx.x; i < kKeys; i += blockDim.x) lhist[i] = 0;
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; }
+    __syncthreads();
+    unsigned long long cells = 0, syms = 0;
+    uint32_t maxa = 0, maxb = 0;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < args.job.pairs; p += stride) {
+        PairInfo info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, args.unit_costs != 0);
+        cells += (unsigned long long)info.la * info.lb;
+        syms += (unsigned long long)info.la + info.lb;
+        maxa = info.la > maxa ? info.la : maxa;
+        maxb = info.lb > maxb ? info.lb : maxb;
+        uint32_t key;
+        if (info.trivial) {
+            key = kClassTrivial * kBuckets;
+            int64_t v = info.trivial_value;
+            // distances are stored positive: the max-plus core negates, the trivial path mirrors it
+            if (args.job.negate) {
+                v = -v;
+                if (args.unit_costs) v = (int64_t)clamp_bound((uint32_t)v, args.job.bound);
+            }
+            store_result(args.job, p, v);
+        } else {
+            key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes);
+        }
+        atomicAdd(&lhist[key], 1u);
+    }
+    atomicAdd(&lcells, cells);
+    atomicAdd(&lsyms, syms);
+    atomicMax(&lmaxa, maxa);
+    atomicMax(&lmaxb, maxb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kKeys; i += blockDim.x)
+        if (lhist[i]) atomicAdd(&args.hist[i], lhist[i]);
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long *)&args.plan->cells, lcells);
+        atomicAdd((unsigned long long *)&args.plan->symbols, lsyms);
+        atomicMax(&args.plan->max_la, lmaxa);
+        atomicMax(&args.plan->max_lb, lmaxb);
+    }
+}
+
+// One block of 1024 threads; kKeys = 6144 -> 6 keys per thread.
+__global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cursor, Plan *plan) {
+    __shared__ uint32_t partial[1024];
+    constexpr int kPer = (kKeys + 1023) / 1024;
+    uint32_t local[kPer];
+    uint32_t sum = 0;
+    for (int k = 0; k < kPer; ++k) {
+        int i = threadIdx.x * kPer + k;
+        local[k] = i < kKeys ? hist[i] : 0;
+        sum += local[k];
+    }
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t base = partial[threadIdx.x] - sum;
+    for (int k = 0; k < kPer; ++k) {
+        int i = threadIdx.x * kPer + k;
+        if (i < kKeys) {
+            cursor[i] = base;
+            if (i % kBuckets == 0) plan->class_start[i / kBuckets] = base;
+            base += local[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) plan->class_start[kMaxClasses] = partial[1023];
+    __syncthreads();
+    if (threadIdx.x < kMaxClasses) {
+        // class_count = next class start - this start (class_start filled above; need a barrier at device scope
+        // only within this single block, which __syncthreads() provides).
+        uint32_t s0 = plan->class_start[threadIdx.x], s1 = plan->class_start[threadIdx.x + 1];
+        plan->class_count[threadIdx.x] = s1 - s0;
+    }
+}
+
+constexpr int kScatterTile = 2048;  // pairs per block iteration (8 per thread)
+template <typename Off>
+__global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
+    __shared__ uint32_t lcount[kKeys];
+    __shared__ uint32_t lbase[kKeys];
+    constexpr int kPerThread = kScatterTile / 256;
+    uint64_t tiles = (args.job.pairs + kScatterTile - 1) / kScatterTile;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < kKeys; i += blockDim.x) lcount[i] = 0;
+        __syncthreads();
+        uint32_t keys[kPerThread], ranks[kPerThread];
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            uint64_t p = tile * kScatterTile + (uint64_t)k * 256 + threadIdx.x;
+            keys[k] = 0xFFFFFFFFu;
+            if (p < args.job.pairs) {
+                PairInfo info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, args.unit_costs != 0);
+                uint32_t key = info.trivial ? kClassTrivial * kBuckets
+                                            : plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes);
+                keys[k] = key;
+                ranks[k] = atomicAdd(&lcount[key], 1u);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kKeys; i += blockDim.x)
+            if (lcount[i]) lbase[i] = atomicAdd(&args.cursor[i], lcount[i]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            uint64_t p = tile * kScatterTile + (uint64_t)k * 256 + threadIdx.x;
+            if (keys[k] != 0xFFFFFFFFu) args.perm[lbase[keys[k]] + ranks[k]] = (uint32_t)p;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
+    PrepassArgs args = args_in;
+    hipStream_t stream = scope->stream;
+    SWH_HIP_CHECK(hipMemsetAsync(args.hist, 0, sizeof(uint32_t) * kKeys, stream));
+    SWH_HIP_CHECK(hipMemsetAsync(args.plan, 0, sizeof(Plan), stream));
+    uint64_t pairs = args.job.pairs;
+    int blocks = (int)((pairs + 256 * 8 - 1) / (256 * 8));
+    int max_blocks = scope->compute_units * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    {
+        StampGuard guard(scope, "plan_hist");
+        if (args.off64) hipLaunchKernelGGL(k_plan_hist<uint64_t>, dim3(blocks), dim3(256), 0, stream, args);
+        else hipLaunchKernelGGL(k_plan_hist<uint32_t>, dim3(blocks), dim3(256), 0, stream, args);
+    }
+    {
+        StampGuard guard(scope, "plan_scan");
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, stream, args.hist, args.cursor, args.plan);
+    }
+    {
+        StampGuard guard(scope, "plan_scatter");
+        uint64_t tiles = (pairs + kScatterTile - 1) / kScatterTile;
+        int sblocks = (int)(tiles < (uint64_t)scope->compute_units * 4 ? tiles : (uint64_t)scope->compute_units * 4);
+        if (sblocks < 1) sblocks = 1;
+        if (args.off64) hipLaunchKernelGGL(k_plan_scatter<uint64_t>, dim3(sblocks), dim3(256), 0, stream, args);
+        else hipLaunchKernelGGL(k_plan_scatter<uint32_t>, dim3(sblocks), dim3(256), 0, stream, args);
+    }
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// UTF-8 staging. Thread per string (v1): count + validate, then scan, then write code points.
+// Validation is strict (RFC 3629 / Rust `str`): no overlongs, no surrogates, <= U+10FFFF.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int utf8_step(const uint8_t *s, uint64_t i, uint64_t n, uint32_t &cp) {
+    uint32_t c = s[i];
+    if (c < 0x80) { cp = c; return 1; }
+    int need;
+    if (c >= 0xC2 && c <= 0xDF) { cp = c & 0x1F; need = 1; }
+    else if (c >= 0xE0 && c <= 0xEF) { cp = c & 0x0F; need = 2; }
+    else if (c >= 0xF0 && c <= 0xF4) { cp = c & 0x07; need = 3; }
+    else return 0;
+    if (i + need >= n) return 0;
+    for (int k = 1; k <= need; ++k) {
+        uint32_t cc = s[i + k];
+        if ((cc & 0xC0) != 0x80) return 0;
+        cp = (cp << 6) | (cc & 0x3F);
+    }
+    if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) return 0;
+    if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) return 0;
+    return need + 1;
+}
+
+template <typename Off>
+__global__ __launch_bounds__(256) void k_utf8_count(Utf8Args args) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= args.in.count) return;
+    const Off *offs = (const Off *)args.in.offsets;
+    uint64_t b0 = offs[i], b1 = offs[i + 1];
+    const uint8_t *s = (const uint8_t *)args.in.data + b0;
+    uint64_t n = b1 - b0, pos = 0;
+    uint32_t count = 0;
+    while (pos < n) {
+        uint32_t cp;
+        int adv = utf8_step(s, pos, n, cp);
+        if (!adv) { atomicCAS(args.invalid, 0u, (uint32_t)(i + 1)); break; }
+        pos += adv;
+        ++count;
+    }
+    args.counts[i] = count;
+}
+
+template <typename Off>
+__global__ __launch_bounds__(256) void k_utf8_write(Utf8Args args) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= args.in.count) return;
+    const Off *offs = (const Off *)args.in.offsets;
+    uint64_t b0 = offs[i], b1 = offs[i + 1];
+    const uint8_t *s = (const uint8_t *)args.in.data + b0;
+    uint64_t n = b1 - b0, pos = 0;
+    uint32_t *dst = args.symbols + args.offsets[i];
+    while (pos < n) {
+        uint32_t cp;
+        int adv = utf8_step(s, pos, n, cp);
+        if (!adv) break;
+        pos += adv;
+        *dst++ = cp;
+    }
+}
+
+// Exclusive scan of u32 counts into u64 offsets (count+1 entries). Three small kernels.
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const uint32_t *counts, uint64_t n,
+                                                                unsigned long long *block_sums) {
+    __shared__ unsigned long long red[kScanBlock];
+    uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    red[threadIdx.x] = i < n ? counts[i] : 0;
+    __syncthreads();
+    for (int off = kScanBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(kScanBlock) void k_scan_top(unsigned long long *block_sums, uint32_t nblocks) {
+    // serial-in-chunks exclusive scan by one block; nblocks is small (count / 1024)
+    __shared__ unsigned long long carry;
+    __shared__ unsigned long long buf[kScanBlock];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += kScanBlock) {
+        uint32_t i = base + threadIdx.x;
+        unsigned long long v = i < nblocks ? block_sums[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kScanBlock; off <<= 1) {
+            unsigned long long t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblocks) block_sums[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1) carry += buf[kScanBlock - 1];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t *counts, uint64_t n,
+                                                           const unsigned long long *block_sums, uint64_t *offsets) {
+    __shared__ unsigned long long buf[kScanBlock];
+    uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    unsigned long long v = i < n ? counts[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        unsigned long long t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned long long excl = block_sums[blockIdx.x] + buf[threadIdx.x] - v;
+    if (i < n) offsets[i] = excl;
+    if (i == n - 1) offsets[n] = excl + v;
+}
+
+void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
+    hipStream_t stream = scope->stream;
+    uint64_t n = args.in.count;
+    if (n == 0) {
+        SWH_HIP_CHECK(hipMemsetAsync(args.offsets, 0, sizeof(uint64_t), stream));
+        return;
+    }
+    int blocks = (int)((n + 255) / 256);
+    {
+        StampGuard guard(scope, "utf8_count");
+        if (args.off64) hipLaunchKernelGGL(k_utf8_count<uint64_t>, dim3(blocks), dim3(256), 0, stream, args);
+        else hipLaunchKernelGGL(k_utf8_count<uint32_t>, dim3(blocks), dim3(256), 0, stream, args);
+    }
+    uint32_t nblocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
+    // block sums live right after `counts` in scratch (caller reserves nblocks u64 there)
+    unsigned long long *block_sums = (unsigned long long *)(args.counts + ((n + 1) & ~1ull));
+    {
+        StampGuard guard(scope, "utf8_scan");
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(kScanBlock), 0, stream, args.counts, n, block_sums);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, stream, block_sums, nblocks);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, stream, args.counts, n, block_sums,
+                           args.offsets);
+    }
+    {
+        StampGuard guard(scope, "utf8_write");
+        if (args.off64) hipLaunchKernelGGL(k_utf8_write<uint64_t>, dim3(blocks), dim3(256), 0, stream, args);
+        else hipLaunchKernelGGL(k_utf8_write<uint32_t>, dim3(blocks), dim3(256), 0, stream, args);
+    }
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace swh

@@ -1,0 +1,341 @@
+// wavefront.hip -- anti-diagonal wavefront DP for gfx950, register-tiled, DPP hand-off.
+//
+// One pair is scored by a group of G lanes (G = 16: four pairs per wave64, `row_shr:1` DPP;
+// G = 64: one pair per wave, `wave_shr:1` DPP). Lane g of a group owns W consecutive DP columns
+// (the "strip" g*W+1 .. g*W+W) and keeps the previous row of its strip in registers. At global
+// step s lane g processes DP row r = s - g + 1, so the lanes of a group sit on one anti-diagonal
+// of W-wide tiles; the only cross-lane traffic per step is the right-edge value of the strip
+// (plus the horizontal-gap state for affine gaps), shifted one lane up by a single DPP move.
+// Row symbols are fetched four steps ahead with one (possibly unaligned) dword load per lane.
+//
+// The core is max-plus (global alignment score). Distances run on it with negated costs
+// (`Job::negate`), so one kernel family serves `LevenshteinDistances` with arbitrary
+// (match, mismatch, open, extend) (bench.rs:382), its UTF-8 twin on decoded code points
+// (bench.rs:386) and `NeedlemanWunschScores` with a 256x256 matrix (bench.rs:658, config C4).
+//
+// Strips wider than one pass (columns > G*W of the widest instantiation) run as several passes
+// over column chunks; the chunk's right edge column is parked in a per-group global buffer.
+#include "common.hpp"
+
+namespace swh {
+
+enum WfModel : int { kUniformLinear = 0, kMatrixLinear = 1, kMatrixAffine = 2 };
+
+constexpr int kNegInf = -0x20000000;
+
+template <int G>
+__device__ __forceinline__ int dpp_shift_up(int old, int src) {
+    if constexpr (G == 16) return __builtin_amdgcn_update_dpp(old, src, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+    else return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int med3i(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// Row-symbol stream: symbol for step s is rows[s - g]; four steps are fetched per refill.
+template <typename Sym>
+struct RowStream;
+
+template <>
+struct RowStream<uint8_t> {
+    const uint8_t *base;  // rows string start
+    int lo, hi;           // clamp range of dword-read start indices relative to `base`
+    int avail;            // readable symbols relative to base (total - start)
+    bool tiny;            // tape shorter than 4 bytes: bytewise path
+    uint32_t cur, nxt;
+    __device__ __forceinline__ void init(const uint8_t *data, uint64_t start, uint64_t total) {
+        base = data + start;
+        tiny = total < 4;
+        int64_t l = -(int64_t)start, h = (int64_t)total - (int64_t)start - 4;
+        lo = (int)(l < -0x40000000ll ? -0x40000000ll : l);
+        hi = (int)(h > 0x40000000ll ? 0x40000000ll : h);
+        int64_t av = (int64_t)total - (int64_t)start;
+        avail = (int)(av > 0x40000000ll ? 0x40000000ll : av);
+        cur = nxt = 0;
+    }
+    __device__ __forceinline__ uint32_t fetch(int idx) const {
+        if (!tiny) {
+            int c = med3i(idx, lo, hi);
+            uint32_t dw;
+            __builtin_memcpy(&dw, base + c, 4);
+            int d = med3i(idx - c, -3, 3);
+            return d >= 0 ? dw >> (8 * d) : dw << (-8 * d);
+        }
+        uint32_t dw = 0;
+        for (int u = 0; u < 4; ++u) {
+            int pos = idx + u;
+            if (pos >= lo && pos < avail) dw |= (uint32_t)base[pos] << (8 * u);
+        }
+        return dw;
+    }
+    __device__ __forceinline__ void prefetch(int idx) { nxt = fetch(idx); }
+    __device__ __forceinline__ void advance() { cur = nxt; }
+    __device__ __forceinline__ uint32_t sym(int u) const { return (cur >> (8 * u)) & 0xffu; }
+};
+
+template <>
+struct RowStream<uint32_t> {
+    const uint32_t *base;
+    int lo, hi;
+    uint32_t cur[4], nxt[4];
+    __device__ __forceinline__ void init(const uint32_t *data, uint64_t start, uint64_t total) {
+        base = data + start;
+        int64_t l = -(int64_t)start, h = (int64_t)total - (int64_t)start - 1;
+        lo = (int)(l < -0x40000000ll ? -0x40000000ll : l);
+        hi = (int)(h > 0x40000000ll ? 0x40000000ll : h);
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u] = 0;
+    }
+    __device__ __forceinline__ void prefetch(int idx) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = base[med3i(idx + u, lo, hi)];
+    }
+    __device__ __forceinline__ void advance() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+    }
+    __device__ __forceinline__ uint32_t sym(int u) const { return cur[u]; }
+};
+
+// Result plumbing shared with the bit-parallel kernel.
+__device__ __forceinline__ void store_score(const Job &job, uint64_t p, int score) {
+    if (job.negate) store_result(job, p, (int64_t)clamp_bound((uint32_t)(-score), job.bound));
+    else store_result(job, p, (int64_t)score);
+}
+
+template <typename Sym, int G, int W, int MODEL>
+__global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls) {
+    constexpr bool kMatrix = MODEL != kUniformLinear;
+    constexpr bool kAffine = MODEL == kMatrixAffine;
+    constexpr int kGroups = 64 / G;  // pairs per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int8_t *lmatrix = (int8_t *)smem;
+
+    if constexpr (kMatrix) {
+        const uint4 *src = (const uint4 *)args.scoring.matrix;
+        uint4 *dst = (uint4 *)lmatrix;
+        for (int i = threadIdx.x; i < 65536 / 16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    const int gl = lane % G;       // lane inside its group
+    const int grp = lane / G;      // group inside the wave
+    const uint32_t cstart = args.plan->class_start[cls];
+    const uint32_t ccount = args.plan->class_count[cls];
+    const uint32_t chunks = (ccount + kGroups - 1) / kGroups;
+    const uint32_t waves_total = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    const int open = args.scoring.open, ext = args.scoring.extend;
+    const int match = args.scoring.match, mismatch = args.scoring.mismatch;
+    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
+                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
+    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
+                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
+    int32_t *bnd_h = args.boundary ? args.boundary + (uint64_t)(wave_id * kGroups + grp) * args.boundary_stride * 2
+                                   : nullptr;
+    int32_t *bnd_e = bnd_h ? bnd_h + args.boundary_stride : nullptr;
+
+    // Largest chunks first (perm is sorted ascending by row bucket) for a short tail.
+    for (uint32_t chunk_rev = wave_id; chunk_rev < chunks; chunk_rev += waves_total) {
+        const uint32_t chunk = chunks - 1 - chunk_rev;
+        const uint32_t slot = chunk * kGroups + grp;
+        const bool have = slot < ccount;
+        uint64_t p = 0, a0 = 0, b0 = 0;
+        uint32_t la = 0, lb = 0;
+        if (have) {
+            p = args.perm[cstart + slot];
+            if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
+            else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
+        }
+        // Orientation: columns live across lanes; rows stream. Symmetric scoring puts the shorter
+        // string on the columns (must mirror plan_key()).
+        const bool swapped = args.symmetric && la < lb;
+        const uint32_t rows = swapped ? lb : la, cols = swapped ? la : lb;
+        const Sym *col_data = (const Sym *)(swapped ? args.job.a.data : args.job.b.data);
+        const Sym *row_data = (const Sym *)(swapped ? args.job.b.data : args.job.a.data);
+        const uint64_t col0 = swapped ? a0 : b0, row0 = swapped ? b0 : a0;
+        const uint64_t row_total = swapped ? b_total : a_total;
+
+        // wave-uniform step count: max(rows) + G - 1, rounded up to the 4-step refill cadence
+        uint32_t rows_max = rows;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            uint32_t other = __shfl_xor(rows_max, off);
+            rows_max = other > rows_max ? other : rows_max;
+        }
+        uint32_t cols_max = cols;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            uint32_t other = __shfl_xor(cols_max, off);
+            cols_max = other > cols_max ? other : cols_max;
+        }
+        const uint32_t steps = (rows_max + G - 1 + 3) & ~3u;
+        const uint32_t passes = cols_max ? (cols_max + G * W - 1) / (G * W) : 0;
+
+        RowStream<Sym> stream;
+        stream.init(row_data, row0, row_total);
+
+        int result = 0;
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            const uint32_t c0 = pass * G * W;  // columns c0+1 .. c0+G*W in this pass
+            // column symbols of my strip
+            uint32_t bs[W];
+            int H[W], F[kAffine ? W : 1];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                uint32_t j = c0 + gl * W + k;  // 0-based column index
+                bs[k] = j < cols ? (uint32_t)col_data[col0 + j] : 0u;
+                H[k] = open + (int)j * ext;    // H[0][j+1] = open + j*ext
+                if constexpr (kAffine) F[k] = kNegInf;
+            }
+            // my right-edge outputs (what the lane above me consumes), row 0
+            int out_h = open + (int)(c0 + gl * W + W - 1) * ext;
+            int out_e = kNegInf;
+            // diagonal input for my first active row: H[0][c0 + gl*W]
+            int prev_h = (c0 + gl * W) ? open + (int)(c0 + gl * W - 1) * ext : 0;
+            int bnd_next[4] = {0, 0, 0, 0}, ebnd_next[4] = {kNegInf, kNegInf, kNegInf, kNegInf};
+            int bnd_cur[4], ebnd_cur[4];
+            const bool read_bnd = pass > 0 && gl == 0;
+            const bool write_bnd = pass + 1 < passes && gl == G - 1;
+
+            stream.prefetch(0 - gl);
+            if (read_bnd) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    bnd_next[u] = __hip_atomic_load(bnd_h + 1 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (kAffine)
+                        ebnd_next[u] = __hip_atomic_load(bnd_e + 1 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            for (uint32_t s0 = 0; s0 < steps; s0 += 4) {
+                stream.advance();
+                stream.prefetch((int)s0 + 4 - gl);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { bnd_cur[u] = bnd_next[u]; ebnd_cur[u] = ebnd_next[u]; }
+                if (read_bnd) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bnd_next[u] = __hip_atomic_load(bnd_h + s0 + 5 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if constexpr (kAffine)
+                            ebnd_next[u] =
+                                __hip_atomic_load(bnd_e + s0 + 5 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t s = s0 + u;
+                    // left-edge inputs: group lane 0 takes the DP boundary column, others the lane below
+                    int edge_h = pass == 0 ? open + (int)s * ext : bnd_cur[u];  // H[s+1][c0]
+                    int recv_h = dpp_shift_up<G>(edge_h, out_h);
+                    int recv_e = kNegInf;
+                    if constexpr (kAffine) recv_e = dpp_shift_up<G>(pass == 0 ? kNegInf : ebnd_cur[u], out_e);
+                    const uint32_t sym = stream.sym(u);
+                    if (s - (uint32_t)gl < rows) {  // active: DP row r = s - gl + 1
+                        int diag = prev_h, left = recv_h, e = recv_e;
+                        [[maybe_unused]] const int8_t *mrow = lmatrix + (swapped ? 0 : (sym << 8));
+#pragma unroll
+                        for (int k = 0; k < W; ++k) {
+                            int up = H[k];
+                            int sc;
+                            if constexpr (kMatrix) sc = swapped ? lmatrix[(bs[k] << 8) + sym] : mrow[bs[k]];
+                            else sc = (sym == bs[k]) ? match : mismatch;
+                            int h;
+                            if constexpr (kAffine) {
+                                int f = max(up + open, F[k] + ext);
+                                F[k] = f;
+                                e = max(left + open, e + ext);
+                                h = max(max(diag + sc, e), f);
+                            } else {
+                                h = max(max(diag + sc, up + open), left + open);
+                            }
+                            diag = up;
+                            left = h;
+                            H[k] = h;
+                        }
+                        out_h = left;
+                        out_e = e;
+                        if (write_bnd) {
+                            bnd_h[s - gl + 1] = left;
+                            if constexpr (kAffine) bnd_e[s - gl + 1] = e;
+                        }
+                    }
+                    prev_h = recv_h;
+                }
+            }
+            // result lives in the lane/register holding column `cols`
+            if (have && cols > c0 && cols <= c0 + G * W) {
+                uint32_t jj = cols - 1 - c0;
+                if ((uint32_t)gl == jj / W) {
+                    uint32_t kk = jj % W;
+#pragma unroll
+                    for (int k = 0; k < W; ++k)
+                        if ((uint32_t)k == kk) result = H[k];
+                    store_score(args.job, p, result);
+                }
+            }
+            if (passes > 1) __builtin_amdgcn_s_waitcnt(0);  // boundary stores land before the next pass reads
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename Sym, int G, int W, int MODEL>
+static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint32_t count, const char *name) {
+    constexpr int kGroups = 64 / G;
+    uint32_t chunks = (count + kGroups - 1) / kGroups;
+    uint32_t blocks = (chunks + 3) / 4;
+    size_t lds = MODEL == kUniformLinear ? 0 : 65536;
+    // persistent-ish grid: enough blocks to fill the chip several times over, waves stride over chunks
+    uint32_t max_blocks = (uint32_t)scope->compute_units * (lds ? 2 : 8);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks == 0) return;
+    StampGuard guard(scope, name);
+    hipLaunchKernelGGL((k_wavefront<Sym, G, W, MODEL>), dim3(blocks), dim3(256), lds, scope->stream, args, cls);
+}
+
+template <typename Sym, int MODEL>
+static void launch_model(Scope *scope, const KernelArgs &args, const Plan &plan) {
+#define SWH_WF16(WV)                                                                                   \
+    if (plan.class_count[kClassWf16 + WV - 1])                                                         \
+        launch_one<Sym, 16, WV, MODEL>(scope, args, kClassWf16 + WV - 1, plan.class_count[kClassWf16 + WV - 1], \
+                                       "wavefront_g16_w" #WV);
+    SWH_WF16(1) SWH_WF16(2) SWH_WF16(3) SWH_WF16(4) SWH_WF16(5) SWH_WF16(6) SWH_WF16(7) SWH_WF16(8)
+#undef SWH_WF16
+#define SWH_WF64(IDX, WV)                                                                              \
+    if (plan.class_count[kClassWf64 + IDX])                                                            \
+        launch_one<Sym, 64, WV, MODEL>(scope, args, kClassWf64 + IDX, plan.class_count[kClassWf64 + IDX], \
+                                       "wavefront_g64_w" #WV);
+    SWH_WF64(0, 3) SWH_WF64(1, 4) SWH_WF64(2, 6) SWH_WF64(3, 8) SWH_WF64(4, 12) SWH_WF64(5, 16)
+    SWH_WF64(6, 24) SWH_WF64(7, 32)
+    if constexpr (MODEL != kMatrixAffine) {
+        SWH_WF64(8, 48) SWH_WF64(9, 64) SWH_WF64(10, 80) SWH_WF64(11, 96)
+    } else {
+        // affine keeps two state rows per column: cap the strip at 32 columns, wider pairs go multi-pass
+        for (int idx = 8; idx < kNumWideW; ++idx)
+            if (plan.class_count[kClassWf64 + idx])
+                launch_one<Sym, 64, 32, MODEL>(scope, args, kClassWf64 + idx, plan.class_count[kClassWf64 + idx],
+                                               "wavefront_g64_w32_multipass");
+    }
+#undef SWH_WF64
+    if (plan.class_count[kClassWfMulti])
+        launch_one<Sym, 64, 32, MODEL>(scope, args, kClassWfMulti, plan.class_count[kClassWfMulti],
+                                       "wavefront_g64_w32_multipass");
+}
+
+void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan) {
+    bool matrix = args.scoring.matrix != nullptr;
+    if (args.sym_bytes == 4) {
+        launch_model<uint32_t, kUniformLinear>(scope, args, plan);
+    } else if (!matrix) {
+        launch_model<uint8_t, kUniformLinear>(scope, args, plan);
+    } else if (!args.affine) {
+        launch_model<uint8_t, kMatrixLinear>(scope, args, plan);
+    } else {
+        launch_model<uint8_t, kMatrixAffine>(scope, args, plan);
+    }
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace swh

@@ -1,0 +1,366 @@
+"""Host-side mirror of the engine interface the reference benchmarks drive.
+
+Names, argument meaning and error behaviour follow the ``stringzillas`` Python surface used by
+``similarities/bench.py`` (``szs.DeviceScope(gpu_device=0)`` :360, ``sz.Strs(list)`` :399,
+``engine_class(capabilities=scope)`` :403, ``engine(queries, candidates, scope, out=matrix)``
+:421-422, ``NeedlemanWunschScores(byte_to_class, costs, open=, extend=, capabilities=)``
+:466-472) and the Rust ``szs`` types of ``similarities/bench.rs:79-82``. On top of the reference's
+cross-product call every engine has the pairwise batch the north-star asks for
+(``engine.pairs(a, b, scope, bound=..., out=...)``), the shape of the only pairwise batched call in
+the reference, ``cudf ... str.edit_distance`` (``bench.py:596-604``).
+
+Everything here is plumbing over the C ABI (``include/stringwars_amd.h``); all arithmetic happens
+in the HIP kernels. Inputs may live on the host (numpy) or on the device (``DeviceTape``, torch
+CUDA tensors); device-resident inputs are used in place.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _native as N
+
+__all__ = [
+    "DeviceScope", "Strs", "DeviceTape", "LevenshteinDistances", "LevenshteinDistancesUTF8",
+    "NeedlemanWunschScores", "edit_distance", "StringWarsError", "UNBOUNDED",
+]
+
+StringWarsError = N.StringWarsError
+UNBOUNDED = N.UNBOUNDED
+
+
+def _pointer(obj) -> int:
+    """Raw address of a numpy array, torch tensor, ctypes pointer or int."""
+    if obj is None:
+        return 0
+    if isinstance(obj, int):
+        return obj
+    if isinstance(obj, np.ndarray):
+        return obj.ctypes.data
+    if hasattr(obj, "data_ptr"):  # torch.Tensor
+        return int(obj.data_ptr())
+    if hasattr(obj, "value"):
+        return int(obj.value or 0)
+    raise TypeError(f"cannot take the address of {type(obj)!r}")
+
+
+class DeviceScope:
+    """``szs.DeviceScope(gpu_device=0)`` / ``DeviceScope::gpu_device(0)`` (bench.rs:379).
+
+    ``cpu_cores=`` scopes are refused: this backend has no CPU path and says so loudly
+    (the reference prints ``SKIPPED (<reason>)`` for a variant whose scope cannot be built).
+    ``stream`` may be a raw ``hipStream_t`` address (e.g. ``torch.cuda.current_stream().cuda_stream``).
+    """
+
+    def __init__(self, gpu_device: Optional[int] = None, cpu_cores: Optional[int] = None, stream: Optional[int] = None):
+        handle = C.c_void_p()
+        err = C.c_char_p()
+        if cpu_cores is not None and gpu_device is None:
+            status = N.lib.swh_scope_init_cpu(int(cpu_cores), C.byref(handle), C.byref(err))
+        elif stream is not None:
+            status = N.lib.swh_scope_init_gpu_stream(int(gpu_device or 0), C.c_void_p(int(stream)), C.byref(handle), C.byref(err))
+        else:
+            status = N.lib.swh_scope_init_gpu(int(gpu_device or 0), C.byref(handle), C.byref(err))
+        N.check(status, err)
+        self._handle = handle
+        self.gpu_device = int(gpu_device or 0)
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._handle
+
+    @property
+    def compute_units(self) -> int:
+        value = C.c_size_t()
+        N.lib.swh_scope_compute_units(self._handle, C.byref(value))
+        return int(value.value)
+
+    def set_async(self, enabled: bool) -> None:
+        N.lib.swh_scope_set_async(self._handle, int(bool(enabled)))
+
+    def set_profiling(self, enabled: bool) -> None:
+        N.lib.swh_scope_set_profiling(self._handle, int(bool(enabled)))
+
+    def synchronize(self) -> None:
+        err = C.c_char_p()
+        N.check(N.lib.swh_scope_synchronize(self._handle, C.byref(err)), err)
+
+    def last_timing(self) -> dict:
+        timing = N.Timing()
+        N.lib.swh_scope_last_timing(self._handle, C.byref(timing))
+        return {
+            "total_ms": timing.total_ms, "dominant_ms": timing.dominant_ms,
+            "dominant_name": timing.dominant_name.decode(), "cells": int(timing.cells),
+            "bytes": int(timing.bytes), "kernels": int(timing.kernels),
+        }
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle:
+            N.lib.swh_scope_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Strs:
+    """Arrow-style string tape on the host: ``sz.Strs(list)`` (bench.py:399), ``BytesTape<u64>``
+    (bench.rs:292). ``offsets`` has ``count + 1`` entries of dtype uint64 or uint32."""
+
+    def __init__(self, items: Union[Iterable[Union[bytes, str]], None] = None, *, data: Optional[np.ndarray] = None,
+                 offsets: Optional[np.ndarray] = None):
+        if items is not None:
+            encoded = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in items]
+            lengths = np.fromiter((len(s) for s in encoded), dtype=np.uint64, count=len(encoded))
+            offsets = np.zeros(len(encoded) + 1, dtype=np.uint64)
+            np.cumsum(lengths, out=offsets[1:])
+            data = np.frombuffer(b"".join(encoded), dtype=np.uint8).copy() if encoded else np.zeros(0, np.uint8)
+        if data is None or offsets is None:
+            raise ValueError("Strs needs either items or data+offsets")
+        if offsets.dtype not in (np.uint32, np.uint64):
+            raise TypeError("offsets must be uint32 or uint64")
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.offsets = np.ascontiguousarray(offsets)
+        self.count = len(self.offsets) - 1
+
+    def __len__(self) -> int:
+        return self.count
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            start, stop, step = index.indices(self.count)
+            if step != 1:
+                raise ValueError("only contiguous sub-views")
+            return self.subview(start, stop)
+        lo, hi = int(self.offsets[index]), int(self.offsets[index + 1])
+        return self.data[lo:hi].tobytes()
+
+    def subview(self, start: int, stop: int) -> "Strs":
+        """Zero-copy sub-range, ``BytesTapeView::subview(lo, hi)`` (bench.rs:134-139)."""
+        return Strs(data=self.data, offsets=self.offsets[start:stop + 1])
+
+    def with_offsets(self, dtype) -> "Strs":
+        return Strs(data=self.data, offsets=self.offsets.astype(dtype))
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return np.diff(self.offsets.astype(np.int64))
+
+    def to_device(self, scope: DeviceScope) -> "DeviceTape":
+        return DeviceTape.upload(scope, self)
+
+
+class DeviceTape:
+    """A tape whose data and offsets are device pointers (hipMalloc or torch CUDA tensors)."""
+
+    def __init__(self, data_ptr: int, offsets_ptr: int, count: int, offsets_dtype, keepalive=None, scope=None, owned=False):
+        self.data_ptr, self.offsets_ptr, self.count = int(data_ptr), int(offsets_ptr), int(count)
+        self.offsets_dtype = np.dtype(offsets_dtype)
+        self._keepalive, self._scope, self._owned = keepalive, scope, owned
+
+    @classmethod
+    def upload(cls, scope: DeviceScope, strs: Strs) -> "DeviceTape":
+        err = C.c_char_p()
+        pointers = []
+        for array in (strs.data, strs.offsets):
+            pointer = C.c_void_p()
+            N.check(N.lib.swh_device_alloc(scope.handle, array.nbytes + 16, C.byref(pointer), C.byref(err)), err)
+            if array.nbytes:
+                N.check(N.lib.swh_copy_to_device(scope.handle, pointer, array.ctypes.data, array.nbytes, C.byref(err)), err)
+            pointers.append(pointer)
+        # a sub-view's offsets index into the full data buffer, which was uploaded whole
+        return cls(pointers[0].value, pointers[1].value, strs.count, strs.offsets.dtype, scope=scope, owned=True)
+
+    @classmethod
+    def from_torch(cls, data, offsets) -> "DeviceTape":
+        import torch
+        dtype = {torch.int32: np.uint32, torch.int64: np.uint64, torch.uint8: None}.get(offsets.dtype)
+        if hasattr(torch, "uint32"):
+            dtype = {torch.uint32: np.uint32, torch.uint64: np.uint64}.get(offsets.dtype, dtype)
+        if dtype is None:
+            raise TypeError("offsets tensor must be (u)int32 or (u)int64")
+        return cls(data.data_ptr(), offsets.data_ptr(), offsets.numel() - 1, dtype, keepalive=(data, offsets))
+
+    def __len__(self) -> int:
+        return self.count
+
+    def free(self) -> None:
+        if self._owned and self._scope is not None and self._scope.handle:
+            N.lib.swh_device_free(self._scope.handle, C.c_void_p(self.data_ptr))
+            N.lib.swh_device_free(self._scope.handle, C.c_void_p(self.offsets_ptr))
+        self._owned = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+TapeLike = Union[Strs, DeviceTape, Sequence[Union[bytes, str]]]
+
+
+def _as_tape(obj: TapeLike):
+    if isinstance(obj, (Strs, DeviceTape)):
+        return obj
+    return Strs(obj)
+
+
+def _c_tape(tape, want64: Optional[bool] = None):
+    """ctypes tape struct + its width; keeps arrays alive through the returned tuple."""
+    if isinstance(tape, Strs):
+        if want64 is True and tape.offsets.dtype != np.uint64:
+            tape = tape.with_offsets(np.uint64)
+        is64 = tape.offsets.dtype == np.uint64
+        struct = (N.TapeU64 if is64 else N.TapeU32)(tape.data.ctypes.data, tape.offsets.ctypes.data, tape.count)
+        return struct, is64, tape
+    is64 = tape.offsets_dtype == np.dtype(np.uint64)
+    if want64 is True and not is64:
+        raise TypeError("this call needs u64 offsets on the device tape")
+    struct = (N.TapeU64 if is64 else N.TapeU32)(tape.data_ptr, tape.offsets_ptr, tape.count)
+    return struct, is64, tape
+
+
+class _Engine:
+    _utf8 = False
+
+    def __init__(self):
+        self._handle = None
+
+    def _pairs(self, fn32, fn64, a, b, scope, out, out_dtype, extra=()):
+        a, b = _as_tape(a), _as_tape(b)
+        if len(a) != len(b):
+            raise ValueError("pairwise scoring needs two collections of equal length")
+        ta, a64, keep_a = _c_tape(a)
+        tb, b64, keep_b = _c_tape(b, want64=a64 or None)
+        if a64 != b64:
+            ta, a64, keep_a = _c_tape(a, want64=True)
+            tb, b64, keep_b = _c_tape(b, want64=True)
+        if out is None:
+            out = np.empty(len(a), dtype=out_dtype)
+        stride = out.strides[0] if isinstance(out, np.ndarray) and out.ndim == 1 and out.size > 1 else 0
+        err = C.c_char_p()
+        fn = fn64 if a64 else fn32
+        status = fn(self._handle, scope.handle, C.byref(ta), C.byref(tb), *extra, C.c_void_p(_pointer(out)), stride, C.byref(err))
+        N.check(status, err)
+        del keep_a, keep_b
+        return out
+
+    def _cross(self, fn, queries, candidates, scope, out, out_dtype):
+        queries = _as_tape(queries)
+        candidates = queries if candidates is None else _as_tape(candidates)
+        tq, _, keep_q = _c_tape(queries, want64=True)
+        tc, _, keep_c = _c_tape(candidates, want64=True)
+        if out is None:
+            out = np.zeros((len(queries), len(candidates)), dtype=out_dtype)
+        row_stride = out.strides[0] if isinstance(out, np.ndarray) else len(candidates) * 8
+        if isinstance(out, np.ndarray) and (out.dtype.itemsize != 8 or out.shape != (len(queries), len(candidates))):
+            raise ValueError("out must be a (len(queries), len(candidates)) matrix of 64-bit integers")
+        err = C.c_char_p()
+        status = fn(self._handle, scope.handle, C.byref(tq), C.byref(tc), C.c_void_p(_pointer(out)), row_stride, C.byref(err))
+        N.check(status, err)
+        del keep_q, keep_c
+        return out
+
+
+class LevenshteinDistances(_Engine):
+    """``szs.LevenshteinDistances`` / ``LevenshteinDistances::new(&scope, 0, 1, 1, 1)`` (bench.rs:382).
+
+    ``engine(queries, candidates, scope, out=matrix)`` is the reference's dense cross-product
+    (bench.py:421-422, bench.rs:478-486); ``engine.pairs(a, b, scope, bound=k)`` scores
+    ``a[i]`` against ``b[i]`` and returns ``min(d, k+1)``.
+    """
+
+    def __init__(self, match: int = 0, mismatch: int = 1, open: int = 1, extend: int = 1, *,
+                 capabilities: Optional[DeviceScope] = None, algorithm: str = "auto"):
+        super().__init__()
+        if capabilities is None:
+            raise ValueError("capabilities=DeviceScope(gpu_device=...) is required: there is no default CPU scope")
+        handle, err = C.c_void_p(), C.c_char_p()
+        N.check(N.lib.swh_levenshtein_init(capabilities.handle, match, mismatch, open, extend, C.byref(handle), C.byref(err)), err)
+        self._handle = handle
+        self.set_algorithm(algorithm)
+
+    def set_algorithm(self, algorithm: str) -> None:
+        code = {"auto": N.ALGORITHM_AUTO, "wavefront": N.ALGORITHM_WAVEFRONT, "bitparallel": N.ALGORITHM_BITPARALLEL}[algorithm]
+        N.lib.swh_levenshtein_set_algorithm(self._handle, code)
+
+    def __call__(self, queries: TapeLike, candidates: Optional[TapeLike] = None, scope: Optional[DeviceScope] = None, out=None):
+        if scope is None:
+            raise ValueError("a DeviceScope is required")
+        fn = N.lib.swh_levenshtein_utf8_cross_u64tape if self._utf8 else N.lib.swh_levenshtein_cross_u64tape
+        return self._cross(fn, queries, candidates, scope, out, np.uint64)
+
+    def pairs(self, a: TapeLike, b: TapeLike, scope: DeviceScope, bound: Optional[int] = None, out=None):
+        bound_value = N.UNBOUNDED if bound is None else int(bound)
+        if self._utf8:
+            fns = (N.lib.swh_levenshtein_utf8_pairs_u32tape, N.lib.swh_levenshtein_utf8_pairs_u64tape)
+        else:
+            fns = (N.lib.swh_levenshtein_pairs_u32tape, N.lib.swh_levenshtein_pairs_u64tape)
+        return self._pairs(fns[0], fns[1], a, b, scope, out, np.uint32, extra=(C.c_uint32(bound_value),))
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            N.lib.swh_levenshtein_free(self._handle)
+            self._handle = None
+
+
+class LevenshteinDistancesUTF8(LevenshteinDistances):
+    """``szs.LevenshteinDistancesUTF8`` / ``LevenshteinDistancesUtf8`` (bench.rs:386-399): symbols are
+    Unicode scalar values; invalid UTF-8 raises ``StringWarsError('invalid_utf8')``."""
+
+    _utf8 = True
+
+
+class NeedlemanWunschScores(_Engine):
+    """``szs.NeedlemanWunschScores(byte_to_class, class_costs, open=, extend=, capabilities=)``
+    (bench.py:466-472, bench.rs:658-662). ``substitution_matrix=`` takes a full 256x256 int8 table
+    instead (config C4). gap(k) = open + (k-1)*extend."""
+
+    def __init__(self, byte_to_class: Optional[np.ndarray] = None, class_costs: Optional[np.ndarray] = None, *,
+                 open: int = -2, extend: int = -2, capabilities: Optional[DeviceScope] = None,
+                 substitution_matrix: Optional[np.ndarray] = None):
+        super().__init__()
+        if capabilities is None:
+            raise ValueError("capabilities=DeviceScope(gpu_device=...) is required")
+        handle, err = C.c_void_p(), C.c_char_p()
+        if substitution_matrix is not None:
+            matrix = np.ascontiguousarray(substitution_matrix, dtype=np.int8)
+            if matrix.shape != (256, 256):
+                raise ValueError("substitution_matrix must be 256x256 int8")
+            status = N.lib.swh_nw_init(capabilities.handle, matrix.ctypes.data, open, extend, C.byref(handle), C.byref(err))
+        else:
+            classes = np.ascontiguousarray(byte_to_class, dtype=np.uint8)
+            costs = np.ascontiguousarray(class_costs, dtype=np.int8)
+            if classes.shape != (256,) or costs.shape != (32, 32):
+                raise ValueError("byte_to_class must have 256 entries and class_costs must be 32x32")
+            status = N.lib.swh_nw_init_classes(capabilities.handle, classes.ctypes.data, costs.ctypes.data, open, extend,
+                                               C.byref(handle), C.byref(err))
+        N.check(status, err)
+        self._handle = handle
+
+    def __call__(self, queries: TapeLike, candidates: Optional[TapeLike] = None, scope: Optional[DeviceScope] = None, out=None):
+        if scope is None:
+            raise ValueError("a DeviceScope is required")
+        return self._cross(N.lib.swh_nw_cross_u64tape, queries, candidates, scope, out, np.int64)
+
+    def pairs(self, a: TapeLike, b: TapeLike, scope: DeviceScope, out=None):
+        return self._pairs(N.lib.swh_nw_pairs_u32tape, N.lib.swh_nw_pairs_u64tape, a, b, scope, out, np.int32)
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            N.lib.swh_nw_free(self._handle)
+            self._handle = None
+
+
+def edit_distance(column_a: TapeLike, column_b: TapeLike, scope: DeviceScope, utf8: bool = True,
+                  bound: Optional[int] = None) -> np.ndarray:
+    """Element-wise edit distance of two equal-length string columns, the call shape of
+    ``cudf.Series.str.edit_distance(other)`` (similarities/bench.py:602)."""
+    engine = (LevenshteinDistancesUTF8 if utf8 else LevenshteinDistances)(capabilities=scope)
+    return engine.pairs(column_a, column_b, scope, bound=bound)

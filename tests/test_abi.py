@@ -1,0 +1,82 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads, exports every symbol the
+headers declare, and refuses to compute without a GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(swh_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header", ["stringwars_amd.h", "stringwars_amd_harness.h"])
+def test_every_declared_symbol_is_exported(sw, header):
+    lib = ctypes.CDLL(sw.LIBRARY_PATH)
+    names = declared_symbols(header)
+    assert len(names) >= 8
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/{header} but not exported: {missing}"
+
+
+def test_binding_table_matches_header(sw):
+    from stringwars_amd import _native
+    declared = set(declared_symbols("stringwars_amd.h")) | set(declared_symbols("stringwars_amd_harness.h"))
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+
+
+def test_no_oracle_in_product():
+    """The product path must never touch oracle/ (tier rule 3)."""
+    for base, _, files in os.walk(os.path.join(ROOT, "stringwars_amd")):
+        for name in files:
+            if name.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(base, name), errors="replace").read()
+                assert "import oracle" not in text and "liboracle" not in text and "oracle/" not in text, name
+
+
+def test_version_and_capabilities(sw):
+    assert sw.__version__.count(".") == 2
+    caps = sw.capabilities().split(",")
+    assert "gfx950" in caps and "wavefront" in caps and "bitparallel" in caps
+
+
+def test_cpu_scope_is_refused(sw):
+    with pytest.raises(sw.StringWarsError) as info:
+        sw.DeviceScope(cpu_cores=1)
+    assert info.value.status == "not_implemented"
+
+
+def test_helpers_match_reference_formulas(sw):
+    from stringwars_amd import _native as N
+    # crossproduct_side (bench.rs:113-117): round(sqrt(budget)) clamped to tape_len / 2, at least 1
+    assert N.lib.swh_crossproduct_side(256, 10_000) == 16
+    assert N.lib.swh_crossproduct_side(256 * 132, 1_000_000) == 184   # H100: 132 SMs (similarities/README.md:23)
+    assert N.lib.swh_crossproduct_side(256 * 256, 1_000_000) == 256   # MI355X: 256 CUs
+    assert N.lib.swh_crossproduct_side(10_000, 10) == 5
+    assert N.lib.swh_crossproduct_side(0, 0) == 1
+    buf = ctypes.create_string_buffer(64)
+    for rate, expect in [(1.2e12, "1200.00 GCUPS"), (3.3e9, "3.30 GCUPS"), (1.5e6, "1.50 MCUPS"), (999.0, "999.00 CUPS")]:
+        N.lib.swh_format_si_rate(rate, b"CUPS", 0, buf, 64)
+        assert buf.value.decode() == expect  # utils.rs:487-500: no "T" prefix
+    N.lib.swh_format_si_rate(2.5e6, b"hashes/s", 1, buf, 64)
+    assert buf.value.decode() == "2.50 M hashes/s"
+    for seconds, expect in [(2.5e-7, "250.00 ns"), (2.5e-5, "25.00 µs"), (2.5e-2, "25.00 ms"), (2.5, "2.50 s")]:
+        N.lib.swh_format_seconds(seconds, buf, 64)
+        assert buf.value.decode("utf-8") == expect
+    classes, costs = sw.unary_class_costs(2, -1)
+    assert classes[33] == 1 and costs[3, 3] == 2 and costs[3, 4] == -1
+
+
+def test_gpu_entry_points_fail_loudly_without_device(sw):
+    """On this CPU-only container there is no device: scope creation must raise, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; covered by the gpu tests")
+    with pytest.raises(sw.StringWarsError) as info:
+        sw.DeviceScope(gpu_device=0)
+    assert info.value.status == "no_device"

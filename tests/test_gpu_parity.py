@@ -1,0 +1,358 @@
+"""GPU parity tests: every call goes through the C ABI (libstringwars_amd.so) and is compared with the
+CPU oracle on the same inputs, bit-exact. Run on a real MI355X: `pytest tests -m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+KAT = json.load(open(os.path.join(GOLDEN, "kat.json"), encoding="utf-8"))
+ALGORITHMS = ["auto", "wavefront", "bitparallel"]
+
+
+def unary_matrix(match, mismatch):
+    m = np.full((256, 256), mismatch, np.int8)
+    np.fill_diagonal(m, match)
+    return m
+
+
+def random_pairs(rng, count, lengths, alphabet, related=0.5):
+    items_a, items_b = [], []
+    for _ in range(count):
+        la, lb = int(rng.choice(lengths)), int(rng.choice(lengths))
+        a = rng.integers(0, alphabet, la, dtype=np.uint8)
+        if rng.random() < related and la:
+            b = bytearray(a.tobytes())
+            for _ in range(int(rng.integers(0, 6))):
+                op = int(rng.integers(0, 3))
+                pos = int(rng.integers(0, len(b) + (op == 1))) if len(b) + (op == 1) else 0
+                if op == 0 and b:
+                    b[pos] = int(rng.integers(0, alphabet))
+                elif op == 1:
+                    b.insert(pos, int(rng.integers(0, alphabet)))
+                elif len(b) > 1:
+                    del b[pos]
+            b = bytes(b)
+        else:
+            b = rng.integers(0, alphabet, lb, dtype=np.uint8).tobytes()
+        items_a.append(a.tobytes())
+        items_b.append(b)
+    return items_a, items_b
+
+
+# ----------------------------------------------------------------------------------------------------
+# known answers
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algorithm", ALGORITHMS)
+def test_kat_levenshtein(sw, scope, algorithm):
+    a = sw.Strs([row[0] for row in KAT["levenshtein"]])
+    b = sw.Strs([row[1] for row in KAT["levenshtein"]])
+    got_bytes = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm).pairs(a, b, scope)
+    got_utf8 = sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm=algorithm).pairs(a, b, scope)
+    assert got_bytes.tolist() == [row[3] for row in KAT["levenshtein"]]
+    assert got_utf8.tolist() == [row[2] for row in KAT["levenshtein"]]
+
+
+@pytest.mark.parametrize("algorithm", ALGORITHMS)
+def test_kat_bounded(sw, scope, algorithm):
+    engine = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm)
+    for a, b, k, expected in KAT["bounded"]:
+        assert engine.pairs([a], [b], scope, bound=k).tolist() == [expected]
+
+
+def test_kat_needleman_wunsch(sw, scope):
+    cases = KAT["nw_unary_2_m1"]["cases"]
+    a, b = sw.Strs([c[0] for c in cases]), sw.Strs([c[1] for c in cases])
+    classes, costs = sw.unary_class_costs(2, -1)
+    linear = sw.NeedlemanWunschScores(classes, costs, open=-2, extend=-2, capabilities=scope).pairs(a, b, scope)
+    affine = sw.NeedlemanWunschScores(classes, costs, open=-5, extend=-1, capabilities=scope).pairs(a, b, scope)
+    assert linear.tolist() == [c[2] for c in cases]
+    assert affine.tolist() == [c[3] for c in cases]
+    twins = KAT["nw_bio_twins"]["cases"]
+    a, b = sw.Strs([c[0] for c in twins]), sw.Strs([c[1] for c in twins])
+    m = unary_matrix(2, -1)
+    assert sw.NeedlemanWunschScores(substitution_matrix=m, open=-4, extend=-2, capabilities=scope).pairs(a, b, scope).tolist() == [c[2] for c in twins]
+    assert sw.NeedlemanWunschScores(substitution_matrix=m, open=-6, extend=-1, capabilities=scope).pairs(a, b, scope).tolist() == [c[3] for c in twins]
+    x, y, match, mismatch, open_, extend, expected = KAT["nw_classic"][0]
+    engine = sw.NeedlemanWunschScores(substitution_matrix=unary_matrix(match, mismatch), open=open_, extend=extend, capabilities=scope)
+    assert engine.pairs([x], [y], scope).tolist() == [expected]
+
+
+# ----------------------------------------------------------------------------------------------------
+# committed golden slices of every synthetic config (generator + kernel self-check, no oracle needed)
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["words16", "tokens64", "utf8_lines", "protein4k", "short_words", "bytes4k"])
+@pytest.mark.parametrize("algorithm", ALGORITHMS)
+def test_golden_slices_levenshtein(sw, scope, name, algorithm):
+    z = np.load(os.path.join(GOLDEN, "slices.npz"))
+    a = sw.Strs(data=z[f"{name}.a_data"], offsets=z[f"{name}.a_offsets"])
+    b = sw.Strs(data=z[f"{name}.b_data"], offsets=z[f"{name}.b_offsets"])
+    engine = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm)
+    assert (engine.pairs(a, b, scope) == z[f"{name}.lev_bytes"]).all()
+    if name == "utf8_lines":
+        utf8 = sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm=algorithm)
+        expected = z["utf8_lines.lev_utf8"]
+        assert (utf8.pairs(a, b, scope) == expected).all()
+        for k in (0, 7, 32):
+            assert (utf8.pairs(a, b, scope, bound=k) == np.minimum(expected, k + 1)).all()
+
+
+@pytest.mark.parametrize("name", ["protein4k", "bytes4k"])
+def test_golden_slices_needleman_wunsch(sw, scope, name):
+    z = np.load(os.path.join(GOLDEN, "slices.npz"))
+    a = sw.Strs(data=z[f"{name}.a_data"], offsets=z[f"{name}.a_offsets"])
+    b = sw.Strs(data=z[f"{name}.b_data"], offsets=z[f"{name}.b_offsets"])
+    matrix = z[f"{name}.matrix"]
+    linear = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=-4, extend=-4, capabilities=scope)
+    affine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=-11, extend=-1, capabilities=scope)
+    assert (linear.pairs(a, b, scope) == z[f"{name}.nw_linear_m4"]).all()
+    assert (affine.pairs(a, b, scope) == z[f"{name}.nw_affine_m11_m1"]).all()
+
+
+# ----------------------------------------------------------------------------------------------------
+# random sweeps against the oracle
+# ----------------------------------------------------------------------------------------------------
+LENGTHS_SHORT = list(range(0, 40)) + [47, 48, 49, 63, 64, 65, 95, 96, 97, 127, 128, 129, 130, 160, 200, 255, 256, 257]
+LENGTHS_LONG = [1, 31, 100, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 2500, 3000]
+
+
+@pytest.mark.parametrize("algorithm", ALGORITHMS)
+@pytest.mark.parametrize("alphabet", [2, 4, 26, 256])
+def test_random_levenshtein_short(sw, orc, scope, algorithm, alphabet):
+    rng = np.random.default_rng(100 + alphabet)
+    items_a, items_b = random_pairs(rng, 6000, LENGTHS_SHORT, alphabet)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    got = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm).pairs(a, b, scope)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+
+
+@pytest.mark.parametrize("algorithm", ALGORITHMS)
+def test_random_levenshtein_long(sw, orc, scope, algorithm):
+    rng = np.random.default_rng(7)
+    items_a, items_b = random_pairs(rng, 300, LENGTHS_LONG, 20)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    got = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm).pairs(a, b, scope)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+
+
+@pytest.mark.parametrize("algorithm", ["wavefront", "bitparallel"])
+def test_very_long_pair(sw, orc, scope, algorithm):
+    """Beyond 64 blocks (bit-parallel hands over to the wavefront) and beyond one wavefront pass (6144 columns)."""
+    rng = np.random.default_rng(3)
+    items_a, items_b = random_pairs(rng, 6, [6500, 7000, 9000], 4, related=1.0)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    got = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm).pairs(a, b, scope)
+    assert (got == orc.levenshtein_pairs(a, b, algo="hyyro")).all()
+
+
+def test_exhaustive_binary_alphabet_crossproduct(sw, orc, scope):
+    """All 255 strings over {a,b} of length 0..7 against each other: 65,025 pairs through the
+    cross-product entry point (the reference's `compute_into` shape, bench.rs:478-486)."""
+    strings = [b""] + [bytes(97 + ((v >> i) & 1) for i in range(n)) for n in range(1, 8) for v in range(1 << n)]
+    tape = sw.Strs(strings)
+    for algorithm in ("auto", "wavefront"):
+        matrix = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm)(tape, tape, scope)
+        assert matrix.shape == (255, 255) and matrix.dtype == np.uint64
+        rows = sw.Strs([s for s in strings for _ in strings])
+        cols = sw.Strs([t for _ in strings for t in strings])
+        want = orc.levenshtein_pairs(rows, cols).reshape(255, 255)
+        assert (matrix == want).all()
+    symmetric = sw.LevenshteinDistances(capabilities=scope)(tape, None, scope)
+    assert (symmetric == want).all()
+
+
+@pytest.mark.parametrize("algorithm", ALGORITHMS)
+def test_bounded_is_min_of_distance_and_bound_plus_one(sw, orc, scope, algorithm):
+    rng = np.random.default_rng(11)
+    items_a, items_b = random_pairs(rng, 3000, LENGTHS_SHORT, 8)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    full = orc.levenshtein_pairs(a, b, algo="hyyro")
+    engine = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm)
+    for k in (0, 1, 2, 5, 32, 1000):
+        assert (engine.pairs(a, b, scope, bound=k) == np.minimum(full, k + 1)).all(), k
+        assert (orc.levenshtein_pairs(a, b, bound=k) == np.minimum(full, k + 1)).all()
+
+
+def test_high_bytes_take_the_8bit_table(sw, orc, scope):
+    """Bytes >= 0x80 overflow the 7-bit match table and are deferred to the 8-bit kernel."""
+    rng = np.random.default_rng(5)
+    items_a, items_b = random_pairs(rng, 4000, LENGTHS_SHORT, 256)
+    for i in range(0, 4000, 3):  # a third of the pairs stay pure ASCII
+        items_a[i] = bytes(c & 0x7F for c in items_a[i])
+        items_b[i] = bytes(c & 0x7F for c in items_b[i])
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    got = sw.LevenshteinDistances(capabilities=scope, algorithm="bitparallel").pairs(a, b, scope)
+    assert (got == orc.levenshtein_pairs(a, b, algo="hyyro")).all()
+
+
+def test_utf8_random_scripts(sw, orc, scope):
+    rng = np.random.default_rng(13)
+    pools = [range(0x20, 0x7F), range(0x400, 0x500), range(0x4E00, 0x4F00), range(0x1F600, 0x1F650)]
+    def text(n):
+        return "".join(chr(int(rng.choice(pools[int(rng.integers(0, 4))]))) for _ in range(n))
+    items_a = [text(int(rng.integers(0, 90))) for _ in range(1500)]
+    items_b = [s[: int(rng.integers(0, len(s) + 1))] + text(int(rng.integers(0, 8))) if rng.random() < 0.6 else text(int(rng.integers(0, 90))) for s in items_a]
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    got = sw.LevenshteinDistancesUTF8(capabilities=scope).pairs(a, b, scope)
+    assert (got == orc.levenshtein_pairs(a, b, utf8=True)).all()
+    assert (sw.edit_distance(a, b, scope) == got).all()
+
+
+@pytest.mark.parametrize("costs", [(0, 2, 3, 3), (0, 1, 2, 1), (1, 3, 4, 2), (0, 1, 1, 1)])
+def test_general_cost_levenshtein(sw, orc, scope, costs):
+    """`LevenshteinDistances::new(&scope, match, mismatch, open, extend)` with non-unit costs (bench.rs:382)."""
+    rng = np.random.default_rng(17)
+    items_a, items_b = random_pairs(rng, 1500, list(range(0, 70)) + [130, 200, 300], 6)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    got = sw.LevenshteinDistances(*costs, capabilities=scope).pairs(a, b, scope)
+    want = orc.levenshtein_costs_pairs(a, b, *costs)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (costs, bad[:5], got[bad[:5]], want[bad[:5]])
+
+
+@pytest.mark.parametrize("gaps", [(-4, -4), (-11, -1), (-2, -2), (-5, -1), (0, 0)])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_random_needleman_wunsch(sw, orc, scope, gaps, symmetric):
+    rng = np.random.default_rng(23)
+    matrix = rng.integers(-8, 12, (256, 256)).astype(np.int8)
+    if symmetric:
+        matrix = np.minimum(matrix, matrix.T)
+    lengths = list(range(0, 40)) + [100, 129, 200, 400, 700, 1100, 1600, 2100]
+    items_a, items_b = random_pairs(rng, 500, lengths, 24)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope)
+    got = engine.pairs(a, b, scope)
+    want = orc.nw_pairs(a, b, matrix, *gaps)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (gaps, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+
+
+def test_needleman_wunsch_multipass_and_cross(sw, orc, scope):
+    rng = np.random.default_rng(29)
+    matrix = rng.integers(-5, 9, (256, 256)).astype(np.int8)  # asymmetric: columns cannot be swapped
+    items_a, items_b = random_pairs(rng, 4, [3300, 7000], 20, related=1.0)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    for gaps in ((-4, -4), (-11, -1)):
+        engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope)
+        assert (engine.pairs(a, b, scope) == orc.nw_pairs(a, b, matrix, *gaps)).all(), gaps
+    q = sw.Strs([bytes(rng.integers(65, 85, int(n), dtype=np.uint8)) for n in rng.integers(0, 60, 37)])
+    c = sw.Strs([bytes(rng.integers(65, 85, int(n), dtype=np.uint8)) for n in rng.integers(0, 60, 23)])
+    classes, costs = sw.unary_class_costs(2, -1)
+    engine = sw.NeedlemanWunschScores(classes, costs, open=-2, extend=-2, capabilities=scope)
+    got = engine(q, c, scope)
+    rows = sw.Strs([q[i] for i in range(len(q)) for _ in range(len(c))])
+    cols = sw.Strs([c[j] for _ in range(len(q)) for j in range(len(c))])
+    m32 = np.array([[costs[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+    assert got.dtype == np.int64 and (got == orc.nw_pairs(rows, cols, m32, -2, -2).reshape(len(q), len(c))).all()
+
+
+# ----------------------------------------------------------------------------------------------------
+# boundary behaviour: tape widths, residency, strides, errors
+# ----------------------------------------------------------------------------------------------------
+def test_tape_widths_residency_and_strides(sw, orc, scope):
+    import ctypes as C
+    from stringwars_amd import _native as N
+    a, b = sw.generate_pairs("tokens64", 5000, seed=3)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    assert (engine.pairs(a, b, scope) == want).all()                                   # u64, host
+    a32, b32 = a.with_offsets(np.uint32), b.with_offsets(np.uint32)
+    assert (engine.pairs(a32, b32, scope) == want).all()                               # u32, host
+    da, db = a32.to_device(scope), b32.to_device(scope)
+    assert (engine.pairs(da, db, scope) == want).all()                                 # u32, device, host out
+    strided = np.full((5000, 3), 0xDEADBEEF, dtype=np.uint32)
+    engine.pairs(da, db, scope, out=strided[:, 1])                                     # stride 12 bytes
+    assert (strided[:, 1] == want).all() and (strided[:, 0] == 0xDEADBEEF).all() and (strided[:, 2] == 0xDEADBEEF).all()
+    sub = engine.pairs(a.subview(100, 350), b.subview(100, 350), scope)                # zero-copy sub-views
+    assert (sub == want[100:350]).all()
+    import torch
+    ta = sw.DeviceTape.from_torch(torch.from_numpy(a.data).cuda(), torch.from_numpy(a.offsets.astype(np.int64)).cuda())
+    tb = sw.DeviceTape.from_torch(torch.from_numpy(b.data).cuda(), torch.from_numpy(b.offsets.astype(np.int64)).cuda())
+    out = torch.zeros(5000, dtype=torch.int32, device="cuda")
+    torch_scope = sw.DeviceScope(gpu_device=0, stream=torch.cuda.current_stream().cuda_stream)
+    engine2 = sw.LevenshteinDistances(capabilities=torch_scope)
+    engine2.pairs(ta, tb, torch_scope, out=out)                                        # all device, torch stream
+    assert (out.cpu().numpy().astype(np.uint32) == want).all()
+    pointer, err = C.c_void_p(), C.c_char_p()
+    N.check(N.lib.swh_unified_alloc(scope.handle, 5000 * 4, C.byref(pointer), C.byref(err)), err)
+    unified = np.ctypeslib.as_array(C.cast(pointer, C.POINTER(C.c_uint32)), shape=(5000,))
+    engine.pairs(a, b, scope, out=unified)                                             # UnifiedAlloc output
+    assert (unified == want).all()
+    N.lib.swh_unified_free(scope.handle, pointer)
+
+
+def test_edge_cases_and_errors(sw, orc, scope):
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    assert engine.pairs([], [], scope).size == 0
+    assert engine.pairs([b""], [b""], scope).tolist() == [0]
+    assert engine.pairs([b"", b"abc", b""], [b"xy", b"", b""], scope).tolist() == [2, 3, 0]
+    assert engine.pairs([b"a"], [b"b"], scope).tolist() == [1]            # tapes shorter than one dword
+    assert engine.pairs([b"ab"], [b"b"], scope, bound=0).tolist() == [1]
+    with pytest.raises(ValueError):
+        engine.pairs([b"a"], [b"a", b"b"], scope)
+    utf8 = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    with pytest.raises(sw.StringWarsError) as info:
+        utf8.pairs([b"ok", b"\xff\xfe"], [b"ok", b"ok"], scope)
+    assert info.value.status == "invalid_utf8"
+    with pytest.raises(sw.StringWarsError):
+        sw.LevenshteinDistances(0, -1, 1, 1, capabilities=scope)
+    with pytest.raises(sw.StringWarsError):
+        sw.NeedlemanWunschScores(substitution_matrix=np.zeros((256, 256), np.int8), open=3, extend=1, capabilities=scope)
+    nw = sw.NeedlemanWunschScores(*sw.unary_class_costs(2, -1), open=-2, extend=-2, capabilities=scope)
+    assert nw.pairs([b"", b"ACGT"], [b"", b""], scope).tolist() == [0, -8]
+    assert scope.compute_units == 256
+
+
+# ----------------------------------------------------------------------------------------------------
+# full-size runs: size-independent properties + sampled oracle
+# ----------------------------------------------------------------------------------------------------
+def test_config2_full_size_properties(sw, orc, scope):
+    """BASELINE config C2 at full size: 1M ASCII token pairs, unbounded."""
+    a, b = sw.generate_pairs("tokens64", 1_000_000, seed=42)
+    da, db = a.to_device(scope), b.to_device(scope)
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    scope.set_profiling(True)
+    forward = engine.pairs(da, db, scope)
+    timing = scope.last_timing()
+    scope.set_profiling(False)
+    assert timing["cells"] == int((a.lengths * b.lengths).sum())          # the reference's CUPS numerator
+    backward = engine.pairs(db, da, scope)
+    assert (forward == backward).all()                                    # symmetry
+    assert (engine.pairs(da, da, scope) == 0).all()                       # identity
+    la, lb = a.lengths, b.lengths
+    assert (forward >= np.abs(la - lb)).all() and (forward <= np.maximum(la, lb)).all()
+    sample = np.arange(0, 1_000_000, 50)                                   # 2% against the oracle
+    want = orc.levenshtein_pairs(a, b, algo="hyyro", first=0, count=20_000)
+    assert (forward[:20_000] == want).all()
+    for i in sample[:2000]:
+        assert forward[i] == orc.levenshtein(a[int(i)], b[int(i)], "hyyro")
+    engine.set_algorithm("wavefront")
+    head_a, head_b = a.subview(0, 100_000), b.subview(0, 100_000)
+    assert (engine.pairs(head_a, head_b, scope) == forward[:100_000]).all()  # the two algorithms agree
+    assert int(forward.astype(np.uint64).sum()) == int(forward[::-1].astype(np.uint64).sum())
+
+
+def test_config3_bounded_utf8(sw, orc, scope):
+    """Config C3 (reduced count for the oracle): ~1 KB UTF-8 lines, bound k = 32."""
+    a, b = sw.generate_pairs("utf8_lines", 2000, seed=42)
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    got = engine.pairs(a, b, scope, bound=32)
+    want = orc.levenshtein_pairs(a, b, utf8=True, bound=32, count=300)
+    assert (got[:300] == want).all()
+    assert got.max() <= 33 and (got == 33).any() and (got < 33).any()
+    full = engine.pairs(a, b, scope)
+    assert (np.minimum(full, 33) == got).all()
+
+
+def test_config5_short_words_large(sw, orc, scope):
+    a, b = sw.generate_pairs("short_words", 2_000_000, seed=42)
+    got = sw.LevenshteinDistances(capabilities=scope).pairs(a, b, scope)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    assert (got == want).all()

@@ -114,14 +114,17 @@ def main():
         engine.pairs(da, db, scope, out=out)
         samples.append(scope.last_timing())
     scope.set_profiling(False)
-    dominant_ms = float(np.mean([s["dominant_ms"] for s in samples]))
+    # the bit-parallel path scores every pair in ONE launch; the wavefront path launches one kernel per
+    # columns-per-lane class, so its "dominant kernel" is the family and its duration their sum
+    dominant_ms = float(np.mean([s["compute_ms"] for s in samples]))
     kernels_ms = float(np.mean([s["total_ms"] for s in samples]))
     timing = samples[-1]
     algorithmic_bytes = timing["bytes"]
     valu_tops = OPS_PER_CELL * cells / (dominant_ms * 1e-3) / 1e12
     hbm_gbs = algorithmic_bytes / (dominant_ms * 1e-3) / 1e9
     roofline = {
-        "bound": "valu", "kernel": timing["dominant_name"], "kernel_ms": round(dominant_ms, 4),
+        "bound": "valu", "kernel": timing["dominant_name"] if args.algorithm != "wavefront" else "wavefront_* (all classes)",
+        "kernel_ms": round(dominant_ms, 4),
         "achieved": round(valu_tops, 3), "peak": round(PEAK_VALU_TOPS, 1), "unit": "Tint32op/s",
         "frac": round(valu_tops / PEAK_VALU_TOPS, 4), "traffic": None,
         "ops_per_cell": OPS_PER_CELL, "cells_per_launch": cells,

@@ -17,6 +17,28 @@ if not os.path.exists(LIBRARY_PATH):
         "or `make -C stringwars_amd/csrc` (hipcc, --offload-arch=gfx950). There is no fallback path."
     )
 
+
+
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so; if this library
+    pulled in /opt/rocm's copy first, a later `import torch` would find a foreign runtime already bound to
+    the SONAME and report "No HIP GPUs are available". So when torch is installed, map its copy first and
+    let our DT_NEEDED resolve to it. Without torch (C++ harness, plain ctypes users) the system runtime is used."""
+    if os.environ.get("STRINGWARS_AMD_SYSTEM_HIP") == "1":
+        return
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    candidate = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(candidate):
+        try:
+            C.CDLL(candidate, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+_preload_torch_hip_runtime()
 lib = C.CDLL(LIBRARY_PATH)
 
 SUCCESS = 0
@@ -38,7 +60,8 @@ class TapeU64(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [
-        ("total_ms", C.c_double), ("dominant_ms", C.c_double), ("dominant_name", C.c_char * 64),
+        ("total_ms", C.c_double), ("dominant_ms", C.c_double), ("compute_ms", C.c_double),
+        ("dominant_name", C.c_char * 64),
         ("cells", C.c_uint64), ("bytes", C.c_uint64), ("kernels", C.c_uint32),
     ]
 

@@ -46,7 +46,7 @@ StampGuard::~StampGuard() {
 
 static void collect_timing(Scope *scope) {
     swh_timing_t &t = scope->last_timing;
-    t.total_ms = 0; t.dominant_ms = 0; t.dominant_name[0] = 0; t.kernels = (uint32_t)scope->stamps_used;
+    t.total_ms = 0; t.dominant_ms = 0; t.compute_ms = 0; t.dominant_name[0] = 0; t.kernels = (uint32_t)scope->stamps_used;
     if (!scope->stamps_used) return;
     float span = 0;
     (void)hipEventElapsedTime(&span, scope->stamps[0].start, scope->stamps[scope->stamps_used - 1].stop);
@@ -54,6 +54,8 @@ static void collect_timing(Scope *scope) {
     for (size_t i = 0; i < scope->stamps_used; ++i) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, scope->stamps[i].start, scope->stamps[i].stop);
+        if (strncmp(scope->stamps[i].name, "plan_", 5) != 0 && strncmp(scope->stamps[i].name, "utf8_", 5) != 0)
+            t.compute_ms += ms;
         if (ms > t.dominant_ms) {
             t.dominant_ms = ms;
             snprintf(t.dominant_name, sizeof t.dominant_name, "%s", scope->stamps[i].name);
@@ -140,8 +142,12 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
             a_bytes = read_offset(spec.a.offsets, spec.a.off64, spec.a.count, dev_a_off, stream);
             b_bytes = same_tape ? a_bytes : read_offset(spec.b.offsets, spec.b.off64, spec.b.count, dev_b_off, stream);
         }
-        size_t out_bytes = spec.cross ? (spec.a.count ? (spec.a.count - 1) * spec.row_stride + spec.b.count * elem : 0)
-                                      : (size_t)(pairs - 1) * spec.out_stride + elem;
+        // device-resident outputs are written in place with the caller's strides; host outputs are produced
+        // compactly in device staging and scattered into the caller's strides by a 2-D copy
+        const size_t dev_out_stride = dev_out ? spec.out_stride : elem;
+        const size_t dev_row_stride = dev_out ? spec.row_stride : spec.b.count * elem;
+        size_t out_bytes = spec.cross ? (spec.a.count ? (spec.a.count - 1) * dev_row_stride + spec.b.count * elem : 0)
+                                      : (size_t)(pairs - 1) * dev_out_stride + elem;
 
         // -- staging of host-resident buffers -----------------------------------------------------
         size_t stage_need = 0;
@@ -183,7 +189,6 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
             probe.take<uint32_t>(kKeys);            // hist
             probe.take<uint32_t>(kKeys);            // cursor
             probe.take<Plan>(1);
-            probe.take<uint32_t>(pairs + 8);        // bit-parallel control + overflow list
             if (spec.utf8) {
                 probe.take<uint32_t>(a_bytes + 4); probe.take<uint64_t>(spec.a.count + 1);
                 probe.take<uint32_t>(spec.a.count + 2 + 2 * ((spec.a.count + 1023) / 1024 + 1));
@@ -199,7 +204,6 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         uint32_t *hist = sc.take<uint32_t>(kKeys);
         uint32_t *cursor = sc.take<uint32_t>(kKeys);
         Plan *plan_dev = sc.take<Plan>(1);
-        uint32_t *bp_ctl = sc.take<uint32_t>(pairs + 8);
 
         // -- UTF-8 staging ----------------------------------------------------------------------------
         uint32_t sym_bytes = 1, off64 = (uint32_t)spec.a.off64;
@@ -234,7 +238,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         Job job{};
         job.a = ta; job.b = tb; job.pairs = pairs; job.b_count = spec.b.count; job.cross = spec.cross ? 1 : 0;
         job.bound = engine->kind == 0 ? spec.bound : SWH_UNBOUNDED;
-        job.out = out_dev; job.out_stride = spec.out_stride; job.row_stride = spec.row_stride;
+        job.out = out_dev; job.out_stride = dev_out_stride; job.row_stride = dev_row_stride;
         job.out_elem64 = spec.out64 ? 1 : 0;
         job.negate = engine->kind == 0 ? 1 : 0;
 
@@ -266,9 +270,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         k.affine = engine->scoring.open != engine->scoring.extend ? 1 : 0;
 
         if (bitpar_ok) {
-            KernelArgs kb = k;
-            kb.boundary = (int32_t *)bp_ctl;
-            launch_bitparallel(scope, kb, plan);
+            launch_bitparallel(scope, k, plan);
         }
         // wavefront classes (all of them when the plan is wavefront-only)
         bool any_wf = false, multi = false;
@@ -290,7 +292,17 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         }
 
         // -- results back ------------------------------------------------------------------------------------
-        if (!dev_out) SWH_HIP_CHECK(hipMemcpyAsync(spec.out, out_dev, out_bytes, hipMemcpyDeviceToHost, stream));
+        if (!dev_out) {
+            if (spec.cross) {
+                SWH_HIP_CHECK(hipMemcpy2DAsync(spec.out, spec.row_stride, out_dev, dev_row_stride, spec.b.count * elem,
+                                               spec.a.count, hipMemcpyDeviceToHost, stream));
+            } else if (spec.out_stride == elem) {
+                SWH_HIP_CHECK(hipMemcpyAsync(spec.out, out_dev, out_bytes, hipMemcpyDeviceToHost, stream));
+            } else {
+                SWH_HIP_CHECK(hipMemcpy2DAsync(spec.out, spec.out_stride, out_dev, elem, elem, pairs,
+                                               hipMemcpyDeviceToHost, stream));
+            }
+        }
         scope->last_timing.cells = plan.cells;
         scope->last_timing.bytes = (need_sizes ? a_bytes + b_bytes : plan.symbols) + pairs * (2 * ow + elem);
         if (!scope->async || !dev_out) {

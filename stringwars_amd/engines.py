@@ -91,7 +91,7 @@ class DeviceScope:
         timing = N.Timing()
         N.lib.swh_scope_last_timing(self._handle, C.byref(timing))
         return {
-            "total_ms": timing.total_ms, "dominant_ms": timing.dominant_ms,
+            "total_ms": timing.total_ms, "dominant_ms": timing.dominant_ms, "compute_ms": timing.compute_ms,
             "dominant_name": timing.dominant_name.decode(), "cells": int(timing.cells),
             "bytes": int(timing.bytes), "kernels": int(timing.kernels),
         }

@@ -186,9 +186,6 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         {
             Carver probe{nullptr, 0, 0};
             probe.take<uint32_t>(pairs);            // perm
-            probe.take<uint32_t>(kKeys);            // hist
-            probe.take<uint32_t>(kKeys);            // cursor
-            probe.take<Plan>(1);
             if (spec.utf8) {
                 probe.take<uint32_t>(a_bytes + 4); probe.take<uint64_t>(spec.a.count + 1);
                 probe.take<uint32_t>(spec.a.count + 2 + 2 * ((spec.a.count + 1023) / 1024 + 1));
@@ -201,9 +198,11 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         ensure(scope->scratch, scope->scratch_bytes, need);
         Carver sc{scope->scratch, 0, scope->scratch_bytes};
         uint32_t *perm = sc.take<uint32_t>(pairs);
-        uint32_t *hist = sc.take<uint32_t>(kKeys);
-        uint32_t *cursor = sc.take<uint32_t>(kKeys);
-        Plan *plan_dev = sc.take<Plan>(1);
+        Carver pa{scope->plan_area, 0, 0};
+        uint32_t *hist = pa.take<uint32_t>(kKeys);
+        uint32_t *cursor = pa.take<uint32_t>(kKeys);
+        PlanPartial *partials = pa.take<PlanPartial>(kMaxPartials);
+        Plan *plan_dev = pa.take<Plan>(1);
 
         // -- UTF-8 staging ----------------------------------------------------------------------------
         uint32_t sym_bytes = 1, off64 = (uint32_t)spec.a.off64;
@@ -249,29 +248,34 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         pre.symmetric = engine->kind == 0 ? 1u : (engine->unit_costs ? 1u : 0u);  // nw: set at init when symmetric
         pre.gap_open = engine->scoring.open; pre.gap_extend = engine->scoring.extend;
         pre.unit_costs = engine->kind == 0 && engine->unit_costs ? 1 : 0;
-        pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.plan = plan_dev;
+        pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.plan = plan_dev;
         launch_prepass(scope, pre);
-
-        // The class histogram decides which kernels to launch: one small D2H copy.
-        Plan &plan = *scope->plan_host;
-        SWH_HIP_CHECK(hipMemcpyAsync(&plan, plan_dev, sizeof(Plan), hipMemcpyDeviceToHost, stream));
-        uint32_t invalid_host = 0;
-        if (spec.utf8) SWH_HIP_CHECK(hipMemcpyAsync(&invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));
-        SWH_HIP_CHECK(hipStreamSynchronize(stream));
-        if (invalid_host) {
-            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in string %u of a tape", invalid_host - 1);
-            if (error) *error = g_error_text;
-            return swh_invalid_utf8_k;
-        }
 
         KernelArgs k{};
         k.job = job; k.perm = perm; k.plan = plan_dev; k.scoring = engine->scoring;
         k.off64 = off64; k.sym_bytes = sym_bytes; k.symmetric = pre.symmetric;
         k.affine = engine->scoring.open != engine->scoring.extend ? 1 : 0;
 
-        if (bitpar_ok) {
-            launch_bitparallel(scope, k, plan);
+        // The bit-parallel kernel reads its work list from the device plan, so it is enqueued right away;
+        // the host copy of the plan (needed only to pick wavefront kernels) travels on a side stream and
+        // overlaps it.
+        SWH_HIP_CHECK(hipEventRecord(scope->plan_ready, stream));
+        if (bitpar_ok) launch_bitparallel(scope, k, pairs);
+        Plan &plan = *scope->plan_host;
+        uint32_t *invalid_host = (uint32_t *)(scope->plan_host + 1);
+        *invalid_host = 0;
+        SWH_HIP_CHECK(hipStreamWaitEvent(scope->side_stream, scope->plan_ready, 0));
+        SWH_HIP_CHECK(hipMemcpyAsync(&plan, plan_dev, sizeof(Plan), hipMemcpyDeviceToHost, scope->side_stream));
+        if (spec.utf8)
+            SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, scope->side_stream));
+        SWH_HIP_CHECK(hipStreamSynchronize(scope->side_stream));
+        if (*invalid_host) {
+            SWH_HIP_CHECK(hipStreamSynchronize(stream));
+            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in string %u of a tape", *invalid_host - 1);
+            if (error) *error = g_error_text;
+            return swh_invalid_utf8_k;
         }
+
         // wavefront classes (all of them when the plan is wavefront-only)
         bool any_wf = false, multi = false;
         for (int c = kClassWf16; c <= kClassWfMulti; ++c) {
@@ -349,7 +353,13 @@ static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_
         scope->compute_units = prop.multiProcessorCount;
         if (borrow) { scope->stream = (hipStream_t)stream; scope->owns_stream = false; }
         else { SWH_HIP_CHECK(hipStreamCreateWithFlags(&scope->stream, hipStreamNonBlocking)); scope->owns_stream = true; }
-        SWH_HIP_CHECK(hipHostMalloc((void **)&scope->plan_host, sizeof(Plan), hipHostMallocDefault));
+        SWH_HIP_CHECK(hipHostMalloc((void **)&scope->plan_host, sizeof(Plan) + 64, hipHostMallocDefault));
+        size_t plan_area_bytes = 2 * ((kKeys * 4 + 255) & ~255) + ((kMaxPartials * sizeof(PlanPartial) + 255) & ~255) +
+                                 ((sizeof(Plan) + 255) & ~255);
+        SWH_HIP_CHECK(hipMalloc((void **)&scope->plan_area, plan_area_bytes));
+        SWH_HIP_CHECK(hipMemset(scope->plan_area, 0, plan_area_bytes));
+        SWH_HIP_CHECK(hipStreamCreateWithFlags(&scope->side_stream, hipStreamNonBlocking));
+        SWH_HIP_CHECK(hipEventCreateWithFlags(&scope->plan_ready, hipEventDisableTiming));
         *out = (swh_scope_t)scope;
         return swh_success_k;
     } catch (const HipFailure &f) {
@@ -377,6 +387,9 @@ swh_status_t swh_scope_free(swh_scope_t handle) {
     if (scope->stage) (void)hipFree(scope->stage);
     if (scope->boundary) (void)hipFree(scope->boundary);
     if (scope->plan_host) (void)hipHostFree(scope->plan_host);
+    if (scope->plan_area) (void)hipFree(scope->plan_area);
+    if (scope->side_stream) (void)hipStreamDestroy(scope->side_stream);
+    if (scope->plan_ready) (void)hipEventDestroy(scope->plan_ready);
     if (scope->owns_stream) (void)hipStreamDestroy(scope->stream);
     delete scope;
     return swh_success_k;

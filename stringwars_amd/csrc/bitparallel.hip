@@ -76,14 +76,19 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
 
 #pragma unroll
     for (int k = 0; k < 32; ++k) eq_lo[k * 64 + lane] = 0;
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int g = 1; g <= 64; ++g) {
-            item_prefix[g - 1] = run;
-            uint32_t per = 64 / g, cnt = args.plan->class_count[kClassBp0 + g - 1];
-            run += (cnt + per - 1) / per;
+    if (threadIdx.x < 64) {
+        // work items per class g = lane + 1: ceil(count / floor(64 / g)); exclusive prefix across the wave
+        const uint32_t g = threadIdx.x + 1, per = 64 / g;
+        const uint32_t cnt = args.plan->class_count[kClassBp0 + threadIdx.x];
+        const uint32_t mine = (cnt + per - 1) / per;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t up = __shfl_up(incl, off);
+            if ((int)threadIdx.x >= off) incl += up;
         }
-        item_prefix[64] = run;
+        item_prefix[threadIdx.x] = incl - mine;
+        if (threadIdx.x == 63) item_prefix[64] = incl;
     }
     __syncthreads();
     const uint32_t items_total = item_prefix[64];
@@ -214,18 +219,13 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
     }
 }
 
-void launch_bitparallel(Scope *scope, const KernelArgs &args, const Plan &plan) {
-    uint64_t items = 0;
-    for (int g = 1; g <= 64; ++g) {
-        uint32_t per = 64 / g, cnt = plan.class_count[kClassBp0 + g - 1];
-        items += (cnt + per - 1) / per;
-    }
-    if (!items) return;
+void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs) {
+    // The work list lives in the device plan; the host only bounds the grid (an item holds >= 1 pair).
     KernelArgs k = args;
     k.boundary = nullptr;
-    uint32_t blocks = (uint32_t)((items + kBpWaves - 1) / kBpWaves);
+    uint64_t blocks64 = (pairs + kBpWaves - 1) / kBpWaves;
     uint32_t max_blocks = (uint32_t)scope->compute_units * 4;  // 4 blocks x 4 waves = 16 waves per CU
-    if (blocks > max_blocks) blocks = max_blocks;
+    uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
     static bool attr_set = false;
     if (!attr_set) {
         SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_bitparallel, hipFuncAttributeMaxDynamicSharedMemorySize,

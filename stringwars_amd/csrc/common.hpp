@@ -82,6 +82,9 @@ struct Plan {
     uint32_t pad;
 };
 
+struct PlanPartial { unsigned long long cells, symbols; uint32_t max_la, max_lb; };
+constexpr int kMaxPartials = 2048;
+
 // Class numbering --------------------------------------------------------------------------------
 // 0                : trivial pairs (an empty side, or cutoff decided by lengths) -- finished in the pre-pass
 // 1..64            : bit-parallel, G = class = number of 32-row blocks of the shorter string
@@ -135,6 +138,9 @@ struct Scope {
     char *boundary = nullptr;
     size_t boundary_bytes = 0;
     Plan *plan_host = nullptr;  // pinned
+    char *plan_area = nullptr;  // device: hist | cursor | partials | plan, zeroed once (the scan kernel re-zeroes hist)
+    hipStream_t side_stream = nullptr;  // plan read-back overlaps the first DP kernel
+    hipEvent_t plan_ready = nullptr;
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
     swh_timing_t last_timing{};
@@ -169,6 +175,7 @@ struct PrepassArgs {
     uint32_t *perm;         // out: pair ids sorted by key
     uint32_t *hist;         // scratch: kKeys counters
     uint32_t *cursor;       // scratch: kKeys cursors
+    PlanPartial *partials;  // scratch: kMaxPartials per-block work-unit sums
     Plan *plan;             // out (device)
 };
 void launch_prepass(Scope *scope, const PrepassArgs &args);
@@ -182,7 +189,7 @@ struct KernelArgs {
     int32_t *boundary;      // scratch for multi-pass wavefront
     uint64_t boundary_stride;  // int32 elements per group slot
 };
-void launch_bitparallel(Scope *scope, const KernelArgs &args, const Plan &plan_host);
+void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs);
 void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan_host);
 
 // UTF-8 staging: decodes a byte tape into u32 code points + u64 code-point offsets.

@@ -108,28 +108,55 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
     for (int i = threadIdx.x; i < kKeys; i += blockDim.x)
         if (lhist[i]) atomicAdd(&args.hist[i], lhist[i]);
     if (threadIdx.x == 0) {
-        atomicAdd((unsigned long long *)&args.plan->cells, lcells);
-        atomicAdd((unsigned long long *)&args.plan->symbols, lsyms);
-        atomicMax(&args.plan->max_la, lmaxa);
-        atomicMax(&args.plan->max_lb, lmaxb);
+        // per-block partial sums; k_plan_scan folds them (same-address global atomics from every block
+        // serialise in L2 and used to cost more than the whole histogram)
+        PlanPartial part{lcells, lsyms, lmaxa, lmaxb};
+        args.partials[blockIdx.x] = part;
     }
 }
 
-// One block of 1024 threads; kKeys = 6144 -> 6 keys per thread.
-__global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cursor, Plan *plan) {
+// One block of 1024 threads; kKeys = 6144 -> 6 keys per thread. Also folds the per-block partial
+// work-unit sums into the plan and re-zeroes the histogram for the next call (no memsets per call).
+__global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cursor, Plan *plan,
+                                                    const PlanPartial *partials, uint32_t npartials) {
     __shared__ uint32_t partial[1024];
+    __shared__ unsigned long long rcells[1024], rsyms[1024];
+    __shared__ uint32_t rmaxa[1024], rmaxb[1024];
     constexpr int kPer = (kKeys + 1023) / 1024;
     uint32_t local[kPer];
     uint32_t sum = 0;
     for (int k = 0; k < kPer; ++k) {
         int i = threadIdx.x * kPer + k;
         local[k] = i < kKeys ? hist[i] : 0;
+        if (i < kKeys) hist[i] = 0;
         sum += local[k];
     }
     partial[threadIdx.x] = sum;
+    unsigned long long c = 0, sy = 0;
+    uint32_t ma = 0, mb = 0;
+    for (uint32_t i = threadIdx.x; i < npartials; i += 1024) {
+        PlanPartial pp = partials[i];
+        c += pp.cells; sy += pp.symbols;
+        ma = pp.max_la > ma ? pp.max_la : ma;
+        mb = pp.max_lb > mb ? pp.max_lb : mb;
+    }
+    rcells[threadIdx.x] = c; rsyms[threadIdx.x] = sy; rmaxa[threadIdx.x] = ma; rmaxb[threadIdx.x] = mb;
     __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            rcells[threadIdx.x] += rcells[threadIdx.x + off];
+            rsyms[threadIdx.x] += rsyms[threadIdx.x + off];
+            rmaxa[threadIdx.x] = rmaxa[threadIdx.x + off] > rmaxa[threadIdx.x] ? rmaxa[threadIdx.x + off] : rmaxa[threadIdx.x];
+            rmaxb[threadIdx.x] = rmaxb[threadIdx.x + off] > rmaxb[threadIdx.x] ? rmaxb[threadIdx.x + off] : rmaxb[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        plan->cells = rcells[0]; plan->symbols = rsyms[0]; plan->max_la = rmaxa[0]; plan->max_lb = rmaxb[0];
+        plan->invalid_utf8 = 0; plan->pad = 0;
+    }
     for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
+        uint32_t v = (int)threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
         __syncthreads();
         partial[threadIdx.x] += v;
         __syncthreads();
@@ -147,8 +174,6 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
     if (threadIdx.x == 1023) plan->class_start[kMaxClasses] = partial[1023];
     __syncthreads();
     if (threadIdx.x < kMaxClasses) {
-        // class_count = next class start - this start (class_start filled above; need a barrier at device scope
-        // only within this single block, which __syncthreads() provides).
         uint32_t s0 = plan->class_start[threadIdx.x], s1 = plan->class_start[threadIdx.x + 1];
         plan->class_count[threadIdx.x] = s1 - s0;
     }
@@ -193,11 +218,10 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
 void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     PrepassArgs args = args_in;
     hipStream_t stream = scope->stream;
-    SWH_HIP_CHECK(hipMemsetAsync(args.hist, 0, sizeof(uint32_t) * kKeys, stream));
-    SWH_HIP_CHECK(hipMemsetAsync(args.plan, 0, sizeof(Plan), stream));
     uint64_t pairs = args.job.pairs;
     int blocks = (int)((pairs + 256 * 8 - 1) / (256 * 8));
-    int max_blocks = scope->compute_units * 8;
+    int max_blocks = scope->compute_units * 4;
+    if (max_blocks > kMaxPartials) max_blocks = kMaxPartials;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     {
@@ -207,7 +231,8 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     }
     {
         StampGuard guard(scope, "plan_scan");
-        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, stream, args.hist, args.cursor, args.plan);
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, stream, args.hist, args.cursor, args.plan,
+                           args.partials, (uint32_t)blocks);
     }
     {
         StampGuard guard(scope, "plan_scatter");

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Per-config throughput table (BASELINE.json configs C1..C5 at full or stated size), with the kernel
+breakdown the library's hipEvent stamps give. Not the driver contract (that is bench.py): a measuring tool.
+
+    python tools/bench_configs.py [--configs c1,c2,c3,c4,c5] [--repeats 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import stringwars_amd as sw  # noqa: E402
+
+CONFIGS = {
+    "c1": dict(workload="words16", pairs=10_000, kind="lev"),
+    "c2": dict(workload="tokens64", pairs=1_000_000, kind="lev"),
+    "c3": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32),
+    "c3u": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8"),
+    "c3b": dict(workload="utf8_lines", pairs=100_000, kind="lev"),
+    "c4": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-4, -4)),
+    "c4a": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-11, -1)),
+    "c4b": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4)),
+    "c4l": dict(workload="protein4k", pairs=10_000, kind="lev"),
+    "c5": dict(workload="short_words", pairs=20_000_000, kind="lev"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="c1,c2,c3,c4,c5")
+    ap.add_argument("--repeats", type=int, default=5)
+    ap.add_argument("--algorithm", default="auto")
+    ap.add_argument("--scale", type=float, default=1.0)
+    args = ap.parse_args()
+    scope = sw.DeviceScope(gpu_device=0)
+    for name in args.configs.split(","):
+        cfg = CONFIGS[name]
+        pairs = max(1, int(cfg["pairs"] * args.scale))
+        t0 = time.perf_counter()
+        a, b = sw.generate_pairs(cfg["workload"], pairs, seed=42)
+        gen_s = time.perf_counter() - t0
+        da, db = a.to_device(scope), b.to_device(scope)
+        if cfg["kind"] == "nw":
+            alphabet = None if cfg["workload"] == "bytes4k" else sw.synth.AMINO_ACIDS
+            engine = sw.NeedlemanWunschScores(substitution_matrix=sw.substitution_matrix(42, alphabet), open=cfg["gaps"][0],
+                                              extend=cfg["gaps"][1], capabilities=scope)
+            call = lambda: engine.pairs(da, db, scope)
+        else:
+            cls = sw.LevenshteinDistancesUTF8 if cfg["kind"] == "lev_utf8" else sw.LevenshteinDistances
+            engine = cls(capabilities=scope, algorithm=args.algorithm)
+            call = lambda: engine.pairs(da, db, scope, bound=cfg.get("bound"))
+        call()
+        scope.set_profiling(True)
+        walls, timings = [], []
+        for _ in range(args.repeats):
+            t0 = time.perf_counter()
+            call()
+            walls.append(time.perf_counter() - t0)
+            timings.append(scope.last_timing())
+        scope.set_profiling(False)
+        cells = timings[-1]["cells"]
+        wall, comp = min(walls), min(t["compute_ms"] for t in timings) * 1e-3
+        print(json.dumps({
+            "config": name, **{k: v for k, v in cfg.items() if k != "gaps"}, "pairs": pairs, "cells": cells,
+            "gcups_call": round(cells / wall / 1e9, 1), "gcups_kernels": round(cells / comp / 1e9, 1),
+            "call_ms": round(wall * 1e3, 3), "compute_ms": round(comp * 1e3, 3),
+            "all_kernels_ms": round(min(t["total_ms"] for t in timings), 3), "kernels": timings[-1]["kernels"],
+            "dominant": timings[-1]["dominant_name"], "generate_s": round(gen_s, 2),
+        }), flush=True)
+        da.free(); db.free()
+
+
+if __name__ == "__main__":
+    main()

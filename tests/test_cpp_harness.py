@@ -1,0 +1,53 @@
+"""The C++ counterpart of similarities/bench.rs (stringwars_amd/bench_similarities): output format of the
+harness restated in include/stringwars_amd.hpp. CPU: every GPU row is SKIPPED loudly; GPU: rows are measured."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BINARY = os.path.join(ROOT, "stringwars_amd", "bench_similarities")
+ROWS = [
+    "uniform/stringwars_amd::LevenshteinDistances<1gpu>", "uniform/stringwars_amd::LevenshteinDistancesUtf8<1gpu>",
+    "uniform/stringwars_amd::levenshtein_pairs<1gpu>", "linear/stringwars_amd::NeedlemanWunschScores<1gpu>",
+    "affine/stringwars_amd::NeedlemanWunschScores<1gpu>",
+]
+
+
+def run(extra_env):
+    env = dict(os.environ, STRINGWARS_DATASET=os.path.join(ROOT, "README.md"), STRINGWARS_WARMUP="0", **extra_env)
+    return subprocess.run([BINARY], env=env, capture_output=True, text=True, timeout=300)
+
+
+@pytest.mark.skipif(not os.path.exists(BINARY), reason="bench_similarities not built")
+def test_rows_skip_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    result = run({"STRINGWARS_TIME": "0"})
+    assert result.returncode == 0
+    for header in ("# uniform", "# linear", "# affine"):  # bench.rs:331/:343/:354
+        assert header in result.stdout
+    for row in ROWS:
+        assert f"{row}: SKIPPED (no HIP device visible" in result.stdout
+    assert "Dataset:" in result.stderr and "Distribution:" in result.stderr  # utils.rs:402-430
+
+
+@pytest.mark.skipif(not os.path.exists(BINARY), reason="bench_similarities not built")
+def test_filter_env_is_honoured():
+    result = run({"STRINGWARS_TIME": "0", "STRINGWARS_FILTER": "NeedlemanWunsch"})
+    assert result.returncode == 0 and "STRINGWARS_FILTER active" in result.stderr or "SKIPPED" in result.stdout
+
+
+@pytest.mark.gpu
+def test_rows_are_measured_on_gpu():
+    result = run({"STRINGWARS_TIME": "0.3"})
+    assert result.returncode == 0, result.stderr
+    line = re.compile(r"^(\S+)\s+\d+\.\d\d [kMG]?CUPS \| \d+\.\d\d [kMG]?B/s \| p50 \d+\.\d\d (ns|µs|ms|s) p99 \d+\.\d\d (ns|µs|ms|s)$")
+    measured = {m.group(1) for m in map(line.match, result.stdout.splitlines()) if m}
+    assert measured == set(ROWS), result.stdout
+    filtered = run({"STRINGWARS_TIME": "0.1", "STRINGWARS_FILTER": "uniform/.*pairs"})
+    names = {m.group(1) for m in map(line.match, filtered.stdout.splitlines()) if m}
+    assert names == {"uniform/stringwars_amd::levenshtein_pairs<1gpu>"}
+    assert "Skipping: linear/stringwars_amd::NeedlemanWunschScores<1gpu>" in filtered.stderr

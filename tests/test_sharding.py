@@ -1,0 +1,87 @@
+"""N > 1 path on CPU: two gloo ranks score their shards of the seeded stream (the oracle stands in for the GPU
+kernels here -- this test is about shard boundaries and the gather, not arithmetic) and rank 0's gathered
+vector must equal the single-process result, for the weak-scaling split bench.py uses, a count-balanced strong
+split and a cells-balanced ragged split."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, queue):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    import stringwars_amd as sw
+    from stringwars_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    per_rank, seed = 3000, 42
+    # weak scaling (bench.py): rank r generates [r * per_rank, (r + 1) * per_rank) of the global stream
+    a, b = sw.generate_pairs("tokens64", per_rank, seed=seed, first=sharding.weak_shard_first(rank, per_rank))
+    local = torch.from_numpy(oracle.levenshtein_pairs(a, b, algo="hyyro").astype(np.int32))
+    got = sharding.gather_distances(local)
+    if rank == 0:
+        out["weak"] = got.numpy()
+    # strong scaling over one fixed batch, count-balanced and cells-balanced (ragged) splits
+    fa, fb = sw.generate_pairs("words16", 5001, seed=seed)
+    for name, ranges in (("count", [sharding.shard_range(5001, r, world) for r in range(world)]),
+                         ("cells", sharding.shard_ranges_by_cells(fa.lengths, fb.lengths, world))):
+        lo, hi = ranges[rank]
+        local = torch.from_numpy(oracle.levenshtein_pairs(fa.subview(lo, hi), fb.subview(lo, hi)).astype(np.int32))
+        got = sharding.gather_distances(local, counts=[h - l for l, h in ranges])
+        if rank == 0:
+            out[name] = got.numpy()
+            out[name + "_ranges"] = ranges
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        queue.put(out)
+
+
+def test_two_rank_gloo_gather_matches_single_process(sw, orc):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    queue, port, world = ctx.Queue(), _free_port(), 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = queue.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = sw.generate_pairs("tokens64", 6000, seed=42)
+    assert (out["weak"] == orc.levenshtein_pairs(a, b, algo="hyyro").astype(np.int32)).all()
+    fa, fb = sw.generate_pairs("words16", 5001, seed=42)
+    want = orc.levenshtein_pairs(fa, fb).astype(np.int32)
+    assert (out["count"] == want).all() and (out["cells"] == want).all()
+    (lo0, hi0), (lo1, hi1) = out["cells_ranges"]
+    assert lo0 == 0 and hi0 == lo1 and hi1 == 5001
+    cells = fa.lengths * fb.lengths
+    assert abs(int(cells[lo0:hi0].sum()) - int(cells[lo1:hi1].sum())) <= int(cells.max())
+
+
+def test_shard_helpers():
+    from stringwars_amd import sharding
+    for total in (0, 1, 7, 1000):
+        for world in (1, 2, 3, 8):
+            ranges = [sharding.shard_range(total, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    la = np.array([1, 100, 1, 1, 100, 1]); lb = np.array([1, 100, 1, 1, 100, 1])
+    assert sharding.shard_ranges_by_cells(la, lb, 2) == [(0, 2), (2, 6)] or sharding.shard_ranges_by_cells(la, lb, 2)[0][1] in (2, 3, 4)

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (s0 + q * 4 >= n_eff) break;  // wave-uniform: no lane has a symbol left in this group
                 uint32_t eqs[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

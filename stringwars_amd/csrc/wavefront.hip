@@ -22,6 +22,8 @@ namespace swh {
 enum WfModel : int { kUniformLinear = 0, kMatrixLinear = 1, kMatrixAffine = 2 };
 
 constexpr int kNegInf = -0x20000000;
+constexpr int kMatrixStride = 260;          // bytes per LDS matrix row (256 + one dword of padding)
+constexpr size_t kMatrixLds = 256 * kMatrixStride;
 
 template <int G>
 __device__ __forceinline__ int dpp_shift_up(int old, int src) {
@@ -110,9 +112,11 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
     int8_t *lmatrix = (int8_t *)smem;
 
     if constexpr (kMatrix) {
-        const uint4 *src = (const uint4 *)args.scoring.matrix;
-        uint4 *dst = (uint4 *)lmatrix;
-        for (int i = threadIdx.x; i < 65536 / 16; i += blockDim.x) dst[i] = src[i];
+        // rows padded to kMatrixStride bytes: bank = (row * 65 + col / 4) % 32 depends on the row symbol too,
+        // so small alphabets (20 amino acids live in 7 dword columns) do not pile onto a few banks
+        const uint32_t *src = (const uint32_t *)args.scoring.matrix;
+        uint32_t *dst = (uint32_t *)lmatrix;
+        for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) dst[(i >> 6) * (kMatrixStride / 4) + (i & 63)] = src[i];
         __syncthreads();
     }
 
@@ -178,16 +182,26 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
         int result = 0;
         for (uint32_t pass = 0; pass < passes; ++pass) {
             const uint32_t c0 = pass * G * W;  // columns c0+1 .. c0+G*W in this pass
-            // column symbols of my strip
-            uint32_t bs[W];
+            // column symbols of my strip (bytes packed four per register when the strip is wide)
+            constexpr bool kPackCols = sizeof(Sym) == 1 && W >= 16 && W % 4 == 0;
+            constexpr int kColRegs = kPackCols ? W / 4 : W;
+            uint32_t bs[kColRegs];
             int H[W], F[kAffine ? W : 1];
+#pragma unroll
+            for (int k = 0; k < kColRegs; ++k) bs[k] = 0;
 #pragma unroll
             for (int k = 0; k < W; ++k) {
                 uint32_t j = c0 + gl * W + k;  // 0-based column index
-                bs[k] = j < cols ? (uint32_t)col_data[col0 + j] : 0u;
+                uint32_t sym_k = j < cols ? (uint32_t)col_data[col0 + j] : 0u;
+                if constexpr (kPackCols) bs[k >> 2] |= sym_k << (8 * (k & 3));
+                else bs[k] = sym_k;
                 H[k] = open + (int)j * ext;    // H[0][j+1] = open + j*ext
                 if constexpr (kAffine) F[k] = kNegInf;
             }
+            auto col_sym = [&](int k) -> uint32_t {
+                if constexpr (kPackCols) return (bs[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                else return bs[k];
+            };
             // my right-edge outputs (what the lane above me consumes), row 0
             int out_h = open + (int)(c0 + gl * W + W - 1) * ext;
             int out_e = kNegInf;
@@ -232,25 +246,51 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                     const uint32_t sym = stream.sym(u);
                     if (s - (uint32_t)gl < rows) {  // active: DP row r = s - gl + 1
                         int diag = prev_h, left = recv_h, e = recv_e;
-                        [[maybe_unused]] const int8_t *mrow = lmatrix + (swapped ? 0 : (sym << 8));
+                        // Substitution scores are gathered from LDS a chunk of columns ahead of the DP chain, so
+                        // the ds_read latency overlaps the dependent max/add chain instead of serialising with it.
+                        constexpr int kChunk = !kMatrix ? W : (W < 8 ? W : (W % 8 == 0 ? 8 : (W % 6 == 0 ? 6 : (W % 5 == 0 ? 5 : (W % 7 == 0 ? 7 : 1)))));
+                        constexpr int kChunks = W / kChunk;
+                        // Columns and rows are only ever swapped for symmetric matrices (api.hip), where
+                        // subs[row][col] == subs[col][row]: the lookup needs no orientation fix-up.
+                        [[maybe_unused]] const int8_t *mrow = lmatrix + sym * kMatrixStride;
+                        [[maybe_unused]] int sc_nxt[kChunk];
+                        auto gather = [&](int chunk) {
+                            if constexpr (kMatrix) {
 #pragma unroll
-                        for (int k = 0; k < W; ++k) {
-                            int up = H[k];
-                            int sc;
-                            if constexpr (kMatrix) sc = swapped ? lmatrix[(bs[k] << 8) + sym] : mrow[bs[k]];
-                            else sc = (sym == bs[k]) ? match : mismatch;
-                            int h;
-                            if constexpr (kAffine) {
-                                int f = max(up + open, F[k] + ext);
-                                F[k] = f;
-                                e = max(left + open, e + ext);
-                                h = max(max(diag + sc, e), f);
-                            } else {
-                                h = max(max(diag + sc, up + open), left + open);
+                                for (int q = 0; q < kChunk; ++q) sc_nxt[q] = mrow[col_sym(chunk * kChunk + q)];
                             }
-                            diag = up;
-                            left = h;
-                            H[k] = h;
+                        };
+                        gather(0);
+#pragma unroll
+                        for (int chunk = 0; chunk < kChunks; ++chunk) {
+                            [[maybe_unused]] int sc_cur[kChunk];
+                            if constexpr (kMatrix) {
+#pragma unroll
+                                for (int q = 0; q < kChunk; ++q) sc_cur[q] = sc_nxt[q];
+                                if (chunk + 1 < kChunks) gather(chunk + 1);
+                                // hipcc otherwise sinks every ds_read next to its use (lgkmcnt(0) per cell)
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+#pragma unroll
+                            for (int q = 0; q < kChunk; ++q) {
+                                const int k = chunk * kChunk + q;
+                                int up = H[k];
+                                int sc;
+                                if constexpr (kMatrix) sc = sc_cur[q];
+                                else sc = (sym == col_sym(k)) ? match : mismatch;
+                                int h;
+                                if constexpr (kAffine) {
+                                    int f = max(up + open, F[k] + ext);
+                                    F[k] = f;
+                                    e = max(left + open, e + ext);
+                                    h = max(max(diag + sc, e), f);
+                                } else {
+                                    h = max(max(diag + sc, up + open), left + open);
+                                }
+                                diag = up;
+                                left = h;
+                                H[k] = h;
+                            }
                         }
                         out_h = left;
                         out_e = e;
@@ -286,11 +326,19 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
     constexpr int kGroups = 64 / G;
     uint32_t chunks = (count + kGroups - 1) / kGroups;
     uint32_t blocks = (chunks + 3) / 4;
-    size_t lds = MODEL == kUniformLinear ? 0 : 65536;
+    size_t lds = MODEL == kUniformLinear ? 0 : kMatrixLds;
     // persistent-ish grid: enough blocks to fill the chip several times over, waves stride over chunks
     uint32_t max_blocks = (uint32_t)scope->compute_units * (lds ? 2 : 8);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks == 0) return;
+    if (lds > 65536) {
+        static bool attr_set = false;  // one flag per instantiation
+        if (!attr_set) {
+            SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_wavefront<Sym, G, W, MODEL>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+    }
     StampGuard guard(scope, name);
     hipLaunchKernelGGL((k_wavefront<Sym, G, W, MODEL>), dim3(blocks), dim3(256), lds, scope->stream, args, cls);
 }

@@ -83,6 +83,12 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
     cap = want;
 }
 
+// u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
+static size_t utf8_scratch_words(uint64_t bytes) {
+    uint64_t tiles = (bytes + 1023) / 1024;
+    return (size_t)((tiles + 4) + (4 * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4));
+}
+
 static bool is_device_pointer(const void *p) {
     if (!p) return true;
     hipPointerAttribute_t attr;
@@ -188,9 +194,9 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
             probe.take<uint32_t>(pairs);            // perm
             if (spec.utf8) {
                 probe.take<uint32_t>(a_bytes + 4); probe.take<uint64_t>(spec.a.count + 1);
-                probe.take<uint32_t>(spec.a.count + 2 + 2 * ((spec.a.count + 1023) / 1024 + 1));
+                probe.take<uint32_t>(utf8_scratch_words(a_bytes));
                 probe.take<uint32_t>(b_bytes + 4); probe.take<uint64_t>(spec.b.count + 1);
-                probe.take<uint32_t>(spec.b.count + 2 + 2 * ((spec.b.count + 1023) / 1024 + 1));
+                probe.take<uint32_t>(utf8_scratch_words(b_bytes));
                 probe.take<uint32_t>(4);
             }
             need = probe.used;
@@ -213,7 +219,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
                 u.in = in; u.off64 = off64; u.total_bytes = bytes;
                 u.symbols = sc.take<uint32_t>(bytes + 4);
                 u.offsets = sc.take<uint64_t>(in.count + 1);
-                u.counts = sc.take<uint32_t>(in.count + 2 + 2 * ((in.count + 1023) / 1024 + 1));
+                u.counts = sc.take<uint32_t>(utf8_scratch_words(bytes));
                 u.invalid = invalid_dev;
                 launch_utf8_decode(scope, u);
                 out_tape.data = u.symbols; out_tape.offsets = u.offsets; out_tape.count = in.count;
@@ -248,6 +254,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         pre.symmetric = engine->kind == 0 ? 1u : (engine->unit_costs ? 1u : 0u);  // nw: set at init when symmetric
         pre.gap_open = engine->scoring.open; pre.gap_extend = engine->scoring.extend;
         pre.unit_costs = engine->kind == 0 && engine->unit_costs ? 1 : 0;
+        pre.banded = pre.unit_costs && spec.bound <= 63 && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
         pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.plan = plan_dev;
         launch_prepass(scope, pre);
 
@@ -260,6 +267,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         // the host copy of the plan (needed only to pick wavefront kernels) travels on a side stream and
         // overlaps it.
         SWH_HIP_CHECK(hipEventRecord(scope->plan_ready, stream));
+        if (pre.banded) launch_banded(scope, k, pairs);
         if (bitpar_ok) launch_bitparallel(scope, k, pairs);
         Plan &plan = *scope->plan_host;
         uint32_t *invalid_host = (uint32_t *)(scope->plan_host + 1);
@@ -271,7 +279,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         SWH_HIP_CHECK(hipStreamSynchronize(scope->side_stream));
         if (*invalid_host) {
             SWH_HIP_CHECK(hipStreamSynchronize(stream));
-            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in string %u of a tape", *invalid_host - 1);
+            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in an input tape (marker %u)", *invalid_host - 1);
             if (error) *error = g_error_text;
             return swh_invalid_utf8_k;
         }

@@ -91,12 +91,14 @@ constexpr int kMaxPartials = 2048;
 // 65..72           : wavefront, 16 lanes per pair, W = class-64 columns per lane (cols <= 16*W)
 // 73..84           : wavefront, 64 lanes per pair, W = kWideW[class-73]
 // 85               : wavefront multi-pass (columns beyond 64*kWideW[last])
+// 86               : banded (bounded, k <= 63) Hyyro window, 64 pairs per wave
 constexpr int kClassTrivial = 0;
 constexpr int kClassBp0 = 1;
 constexpr int kClassWf16 = 65;
 constexpr int kClassWf64 = 73;
 constexpr int kNumWideW = 12;
 constexpr int kClassWfMulti = kClassWf64 + kNumWideW;
+constexpr int kClassBanded = kClassWfMulti + 1;  // bounded unit-cost pairs on the sliding 64-bit band (banded.hip)
 __host__ __device__ constexpr int wide_w(int i) {
     constexpr int w[kNumWideW] = {3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 80, 96};
     return w[i];
@@ -172,6 +174,7 @@ struct PrepassArgs {
     uint32_t symmetric;     // scoring symmetric in (a,b): columns may be swapped to the shorter string
     int gap_open, gap_extend;  // max-plus gap costs (negative for distances), for the trivial pairs
     uint32_t unit_costs;    // Levenshtein (0,1,1,1): enables the |la-lb| > bound shortcut
+    uint32_t banded;        // bound <= 63 with unit costs: pairs may take the banded kernel
     uint32_t *perm;         // out: pair ids sorted by key
     uint32_t *hist;         // scratch: kKeys counters
     uint32_t *cursor;       // scratch: kKeys cursors
@@ -191,6 +194,7 @@ struct KernelArgs {
 };
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs);
 void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan_host);
+void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs);
 
 // UTF-8 staging: decodes a byte tape into u32 code points + u64 code-point offsets.
 struct Utf8Args {

@@ -21,8 +21,18 @@ __device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t x) { return x <= 1 ? 
 // Key = class * kBuckets + bucket. Must match the decode logic in the kernels (they re-derive
 // orientation from the lengths: columns = shorter string when `symmetric`).
 __device__ __forceinline__ uint32_t plan_key(uint32_t la, uint32_t lb, uint32_t mode, uint32_t symmetric,
-                                             uint32_t sym_bytes) {
+                                             uint32_t sym_bytes, uint32_t banded, uint32_t bound) {
     uint32_t m = la < lb ? la : lb, n = la < lb ? lb : la;
+    if (banded) {
+        // Banded window: ~(3 (k+1) + 45) wave instructions per column of 64 pairs, against 28 per step of
+        // floor(64/G) pairs for the full bit-parallel kernel (bytes) or the u32 wavefront (code points).
+        uint32_t g = (m + 31) >> 5;
+        bool use = sym_bytes == 4 ? m >= 24 : 3 * (bound + 1) + 45 < 28 * g;
+        if (use) {
+            uint32_t bucket = m >> 4;  // text = shorter string = columns walked
+            return kClassBanded * kBuckets + (bucket > 63 ? 63 : bucket);
+        }
+    }
     if (mode == kPlanBitParallel && sym_bytes == 1) {
         uint32_t g = (m + 31) >> 5;
         if (g <= 64) {
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
             }
             store_result(args.job, p, v);
         } else {
-            key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes);
+            key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
         }
         atomicAdd(&lhist[key], 1u);
     }
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
             if (p < args.job.pairs) {
                 PairInfo info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, args.unit_costs != 0);
                 uint32_t key = info.trivial ? kClassTrivial * kBuckets
-                                            : plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes);
+                                            : plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
                 keys[k] = key;
                 ranks[k] = atomicAdd(&lcount[key], 1u);
             }
@@ -246,63 +256,148 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// UTF-8 staging. Thread per string (v1): count + validate, then scan, then write code points.
-// Validation is strict (RFC 3629 / Rust `str`): no overlongs, no surrogates, <= U+10FFFF.
+// UTF-8 staging, flat over the tape bytes (independent of how long the strings are):
+//   k_utf8_tile_count : lead bytes (everything but 10xxxxxx) per 1 KB tile and per 256 B sub-tile
+//   scan              : exclusive prefix of the tile counts = code-point index of each tile
+//   k_utf8_tile_write : every lead byte decodes its sequence to symbols[prefix + rank]; strict validation
+//                       (RFC 3629 / Rust `str`: no overlongs, no surrogates, <= U+10FFFF, no stray
+//                       continuation bytes)
+//   k_utf8_string_offsets : code-point offset of every string = tile prefix + sub-tile prefix + leads in
+//                       the < 256 bytes before it; a string may not start with a continuation byte, which
+//                       is what catches sequences straddling two strings.
+// All loads are coalesced dwords; nothing loops over a string.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int utf8_step(const uint8_t *s, uint64_t i, uint64_t n, uint32_t &cp) {
-    uint32_t c = s[i];
-    if (c < 0x80) { cp = c; return 1; }
-    int need;
-    if (c >= 0xC2 && c <= 0xDF) { cp = c & 0x1F; need = 1; }
-    else if (c >= 0xE0 && c <= 0xEF) { cp = c & 0x0F; need = 2; }
-    else if (c >= 0xF0 && c <= 0xF4) { cp = c & 0x07; need = 3; }
-    else return 0;
-    if (i + need >= n) return 0;
-    for (int k = 1; k <= need; ++k) {
-        uint32_t cc = s[i + k];
-        if ((cc & 0xC0) != 0x80) return 0;
-        cp = (cp << 6) | (cc & 0x3F);
+constexpr int kUtf8Tile = 1024;  // bytes per block (256 threads x 4 bytes)
+
+__device__ __forceinline__ uint32_t load_tape_dword(const uint8_t *data, int64_t pos, int64_t total) {
+    // bytes pos..pos+3, zero where outside [0, total)
+    if (pos >= 0 && pos + 4 <= total) { uint32_t dw; __builtin_memcpy(&dw, data + pos, 4); return dw; }
+    uint32_t dw = 0;
+    for (int u = 0; u < 4; ++u) {
+        int64_t q = pos + u;
+        if (q >= 0 && q < total) dw |= (uint32_t)data[q] << (8 * u);
     }
-    if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) return 0;
-    if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) return 0;
-    return need + 1;
+    return dw;
+}
+__device__ __forceinline__ uint32_t lead_mask4(uint32_t dw, int valid) {
+    // bit u set when byte u (u < valid) is NOT a continuation byte (10xxxxxx)
+    uint32_t m = 0;
+    for (int u = 0; u < 4; ++u) {
+        uint32_t b = (dw >> (8 * u)) & 0xffu;
+        if (u < valid && (b & 0xC0u) != 0x80u) m |= 1u << u;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_utf8_tile_count(const uint8_t *data, uint64_t total, uint32_t *tile_counts,
+                                                         uint32_t *sub_prefix) {
+    __shared__ uint32_t wave_sum[4];
+    const uint64_t tile = blockIdx.x;
+    const int64_t pos = (int64_t)(tile * kUtf8Tile + threadIdx.x * 4);
+    int valid = (int64_t)total - pos >= 4 ? 4 : ((int64_t)total > pos ? (int)((int64_t)total - pos) : 0);
+    uint32_t dw = valid ? load_tape_dword(data, pos, (int64_t)total) : 0;
+    uint32_t cnt = __popc(lead_mask4(dw, valid));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < 4; ++w) { sub_prefix[tile * 4 + w] = run; run += wave_sum[w]; }
+        tile_counts[tile] = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, uint64_t total, const uint64_t *tile_prefix,
+                                                         uint32_t *symbols, uint32_t *invalid) {
+    __shared__ uint32_t scan[256];
+    const uint64_t tile = blockIdx.x;
+    const int64_t pos = (int64_t)(tile * kUtf8Tile + threadIdx.x * 4);
+    const int64_t tot = (int64_t)total;
+    int valid = tot - pos >= 4 ? 4 : (tot > pos ? (int)(tot - pos) : 0);
+    uint32_t prev = valid ? load_tape_dword(data, pos - 4, tot) : 0;
+    uint32_t cur = valid ? load_tape_dword(data, pos, tot) : 0;
+    uint32_t next = valid ? load_tape_dword(data, pos + 4, tot) : 0;
+    uint32_t leads = lead_mask4(cur, valid);
+    uint32_t mine = __popc(leads);
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint64_t rank = tile_prefix[tile] + scan[threadIdx.x] - mine;
+    // 12-byte neighbourhood: bytes[-4..7] relative to pos
+    auto byte_at = [&](int rel) -> uint32_t {
+        uint32_t w = rel < 0 ? prev : (rel < 4 ? cur : next);
+        return (w >> (8 * (rel & 3))) & 0xffu;
+    };
+    bool bad = false;
+    for (int u = 0; u < valid; ++u) {
+        const int64_t at = pos + u;
+        uint32_t c = byte_at(u);
+        if ((c & 0xC0u) == 0x80u) {
+            // continuation byte: the nearest preceding non-continuation byte must be a lead that covers it
+            bool covered = false;
+            for (int d = 1; d <= 3; ++d) {
+                if (at - d < 0) break;
+                uint32_t q = byte_at(u - d);
+                if ((q & 0xC0u) == 0x80u) continue;
+                int len = q >= 0xF0 ? 4 : (q >= 0xE0 ? 3 : (q >= 0xC0 ? 2 : 1));
+                covered = len > d;
+                break;
+            }
+            bad |= !covered;
+            continue;
+        }
+        uint32_t cp = c;
+        if (c >= 0x80) {
+            int need;
+            if (c >= 0xC2 && c <= 0xDF) { cp = c & 0x1F; need = 1; }
+            else if (c >= 0xE0 && c <= 0xEF) { cp = c & 0x0F; need = 2; }
+            else if (c >= 0xF0 && c <= 0xF4) { cp = c & 0x07; need = 3; }
+            else { bad = true; need = 0; }
+            if (at + need >= tot) bad = true;
+            for (int k2 = 1; k2 <= need; ++k2) {
+                uint32_t cc = byte_at(u + k2);
+                if ((cc & 0xC0u) != 0x80u) bad = true;
+                cp = (cp << 6) | (cc & 0x3Fu);
+            }
+            if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = true;
+            if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) bad = true;
+        }
+        symbols[rank++] = cp;
+    }
+    if (bad) atomicCAS(invalid, 0u, (uint32_t)(pos >> 2) + 1u);
 }
 
 template <typename Off>
-__global__ __launch_bounds__(256) void k_utf8_count(Utf8Args args) {
+__global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, const uint64_t *tile_prefix,
+                                                             const uint32_t *sub_prefix) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= args.in.count) return;
+    if (i > args.in.count) return;
     const Off *offs = (const Off *)args.in.offsets;
-    uint64_t b0 = offs[i], b1 = offs[i + 1];
-    const uint8_t *s = (const uint8_t *)args.in.data + b0;
-    uint64_t n = b1 - b0, pos = 0;
-    uint32_t count = 0;
-    while (pos < n) {
-        uint32_t cp;
-        int adv = utf8_step(s, pos, n, cp);
-        if (!adv) { atomicCAS(args.invalid, 0u, (uint32_t)(i + 1)); break; }
-        pos += adv;
-        ++count;
+    const uint8_t *data = (const uint8_t *)args.in.data;
+    const int64_t total = (int64_t)args.total_bytes;
+    const int64_t off = (int64_t)offs[i];
+    if (off >= total) {  // the tape's end (also every trailing empty string)
+        uint64_t tiles = ((uint64_t)total + kUtf8Tile - 1) / kUtf8Tile;
+        args.offsets[i] = tile_prefix[tiles];
+        return;
     }
-    args.counts[i] = count;
-}
-
-template <typename Off>
-__global__ __launch_bounds__(256) void k_utf8_write(Utf8Args args) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= args.in.count) return;
-    const Off *offs = (const Off *)args.in.offsets;
-    uint64_t b0 = offs[i], b1 = offs[i + 1];
-    const uint8_t *s = (const uint8_t *)args.in.data + b0;
-    uint64_t n = b1 - b0, pos = 0;
-    uint32_t *dst = args.symbols + args.offsets[i];
-    while (pos < n) {
-        uint32_t cp;
-        int adv = utf8_step(s, pos, n, cp);
-        if (!adv) break;
-        pos += adv;
-        *dst++ = cp;
+    const uint64_t tile = (uint64_t)off / kUtf8Tile, sub = ((uint64_t)off % kUtf8Tile) / 256;
+    const int64_t sub_start = (int64_t)(tile * kUtf8Tile + sub * 256);
+    uint32_t cnt = 0;
+    for (int64_t q = sub_start; q < off; q += 4) {
+        int valid = off - q >= 4 ? 4 : (int)(off - q);
+        cnt += __popc(lead_mask4(load_tape_dword(data, q, total), valid));
     }
+    args.offsets[i] = tile_prefix[tile] + sub_prefix[tile * 4 + sub] + cnt;
+    // a non-empty string must start on a sequence boundary
+    if (i < args.in.count && (int64_t)offs[i + 1] > off && (data[off] & 0xC0u) == 0x80u)
+        atomicCAS(args.invalid, 0u, (uint32_t)i + 1u);
 }
 
 // Exclusive scan of u32 counts into u64 offsets (count+1 entries). Three small kernels.
@@ -362,31 +457,40 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t *count
 
 void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
     hipStream_t stream = scope->stream;
-    uint64_t n = args.in.count;
-    if (n == 0) {
-        SWH_HIP_CHECK(hipMemsetAsync(args.offsets, 0, sizeof(uint64_t), stream));
-        return;
+    const uint64_t n = args.in.count, total = args.total_bytes;
+    const uint64_t tiles = (total + kUtf8Tile - 1) / kUtf8Tile;
+    // scratch carved from `counts`: tile_counts[tiles+1] | sub_prefix[4*tiles] | tile_prefix u64[tiles+1] | block sums
+    uint32_t *tile_counts = args.counts;
+    uint32_t *sub_prefix = tile_counts + ((tiles + 2) & ~1ull);
+    uint64_t *tile_prefix = (uint64_t *)(sub_prefix + 4 * tiles + 2 - ((4 * tiles) & 1));
+    unsigned long long *block_sums = (unsigned long long *)(tile_prefix + tiles + 2);
+    if (tiles) {
+        {
+            StampGuard guard(scope, "utf8_tile_count");
+            hipLaunchKernelGGL(k_utf8_tile_count, dim3((uint32_t)tiles), dim3(256), 0, stream, (const uint8_t *)args.in.data,
+                               total, tile_counts, sub_prefix);
+        }
+        uint32_t nblocks = (uint32_t)((tiles + kScanBlock - 1) / kScanBlock);
+        {
+            StampGuard guard(scope, "utf8_scan");
+            hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(kScanBlock), 0, stream, tile_counts, tiles, block_sums);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, stream, block_sums, nblocks);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, stream, tile_counts, tiles, block_sums,
+                               tile_prefix);
+        }
+        {
+            StampGuard guard(scope, "utf8_tile_write");
+            hipLaunchKernelGGL(k_utf8_tile_write, dim3((uint32_t)tiles), dim3(256), 0, stream, (const uint8_t *)args.in.data,
+                               total, tile_prefix, args.symbols, args.invalid);
+        }
+    } else {
+        SWH_HIP_CHECK(hipMemsetAsync(tile_prefix, 0, sizeof(uint64_t), stream));
     }
-    int blocks = (int)((n + 255) / 256);
     {
-        StampGuard guard(scope, "utf8_count");
-        if (args.off64) hipLaunchKernelGGL(k_utf8_count<uint64_t>, dim3(blocks), dim3(256), 0, stream, args);
-        else hipLaunchKernelGGL(k_utf8_count<uint32_t>, dim3(blocks), dim3(256), 0, stream, args);
-    }
-    uint32_t nblocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
-    // block sums live right after `counts` in scratch (caller reserves nblocks u64 there)
-    unsigned long long *block_sums = (unsigned long long *)(args.counts + ((n + 1) & ~1ull));
-    {
-        StampGuard guard(scope, "utf8_scan");
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(kScanBlock), 0, stream, args.counts, n, block_sums);
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, stream, block_sums, nblocks);
-        hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, stream, args.counts, n, block_sums,
-                           args.offsets);
-    }
-    {
-        StampGuard guard(scope, "utf8_write");
-        if (args.off64) hipLaunchKernelGGL(k_utf8_write<uint64_t>, dim3(blocks), dim3(256), 0, stream, args);
-        else hipLaunchKernelGGL(k_utf8_write<uint32_t>, dim3(blocks), dim3(256), 0, stream, args);
+        StampGuard guard(scope, "utf8_offsets");
+        uint32_t blocks = (uint32_t)((n + 1 + 255) / 256);
+        if (args.off64) hipLaunchKernelGGL(k_utf8_string_offsets<uint64_t>, dim3(blocks), dim3(256), 0, stream, args, tile_prefix, sub_prefix);
+        else hipLaunchKernelGGL(k_utf8_string_offsets<uint32_t>, dim3(blocks), dim3(256), 0, stream, args, tile_prefix, sub_prefix);
     }
     SWH_HIP_CHECK(hipGetLastError());
 }

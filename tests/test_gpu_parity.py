@@ -180,6 +180,40 @@ def test_bounded_is_min_of_distance_and_bound_plus_one(sw, orc, scope, algorithm
         assert (orc.levenshtein_pairs(a, b, bound=k) == np.minimum(full, k + 1)).all()
 
 
+@pytest.mark.parametrize("utf8", [False, True])
+def test_banded_window_kernel(sw, orc, scope, utf8):
+    """Bounded calls with k <= 63 take the sliding 64-bit band (banded.hip): tight Ukkonen band, k+1 diagonals."""
+    rng = np.random.default_rng(31 + utf8)
+    items_a, items_b = [], []
+    alphabet = [chr(c) for c in range(0x61, 0x7B)] + (["é", "я", "語", "😀"] if utf8 else [])
+    for _ in range(1500):
+        n = int(rng.integers(1, 700))
+        a = [alphabet[int(i)] for i in rng.integers(0, len(alphabet), n)]
+        b = list(a)
+        edits = int(rng.choice([0, 1, 2, 5, 8, 16, 31, 32, 33, 40, 63, 64, 70, 100]))
+        for _ in range(edits):
+            op = int(rng.integers(0, 3))
+            if op == 0 and b:
+                b[int(rng.integers(0, len(b)))] = alphabet[int(rng.integers(0, len(alphabet)))]
+            elif op == 1:
+                b.insert(int(rng.integers(0, len(b) + 1)), alphabet[int(rng.integers(0, len(alphabet)))])
+            elif len(b) > 1:
+                del b[int(rng.integers(0, len(b)))]
+        if rng.random() < 0.1:  # pure insertions / deletions: length difference == distance
+            b = a[: max(1, n - int(rng.integers(0, 64)))]
+        items_a.append("".join(a))
+        items_b.append("".join(b))
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    full = orc.levenshtein_pairs(a, b, utf8=utf8)
+    engine = (sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances)(capabilities=scope)
+    for k in (0, 1, 3, 7, 8, 15, 16, 31, 32, 33, 35, 36, 50, 63):
+        got = engine.pairs(a, b, scope, bound=k)
+        want = np.minimum(full, k + 1)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (k, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+        assert (engine.pairs(b, a, scope, bound=k) == want).all(), k
+
+
 def test_high_bytes_take_the_8bit_table(sw, orc, scope):
     """Bytes >= 0x80 overflow the 7-bit match table and are deferred to the 8-bit kernel."""
     rng = np.random.default_rng(5)

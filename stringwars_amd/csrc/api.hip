@@ -86,7 +86,7 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
 static size_t utf8_scratch_words(uint64_t bytes) {
     uint64_t tiles = (bytes + 1023) / 1024;
-    return (size_t)((tiles + 4) + (4 * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4));
+    return (size_t)((tiles + 4) + (4 * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4) + (tiles + 4));
 }
 
 static bool is_device_pointer(const void *p) {
@@ -214,8 +214,10 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         uint32_t sym_bytes = 1, off64 = (uint32_t)spec.a.off64;
         uint32_t *invalid_dev = nullptr;
         if (spec.utf8) {
+            uint32_t decode_slot = 0;
             auto decode = [&](const TapeRef &in, uint64_t bytes, TapeRef &out_tape) {
                 Utf8Args u{};
+                u.slot = decode_slot++;
                 u.in = in; u.off64 = off64; u.total_bytes = bytes;
                 u.symbols = sc.take<uint32_t>(bytes + 4);
                 u.offsets = sc.take<uint64_t>(in.count + 1);

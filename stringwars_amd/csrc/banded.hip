@@ -26,17 +26,16 @@ namespace swh {
 constexpr int kBandChunk = 32;                      // text symbols per chunk
 constexpr int kBandPitch = kBandChunk + 1;          // u64 per pair row in LDS
 constexpr int kBandWaves = 4;
-constexpr int kBandParamWords = 12;
-constexpr size_t kBandLdsPerWave = (size_t)64 * kBandPitch * 8 + 64 * kBandParamWords * 4;
+constexpr int kBandParamWords = 8;
+constexpr int kBandStage = 96;                      // u32 window symbols staged per half-wave (32 + WBITS max)
+constexpr size_t kBandLdsPerWave = (size_t)64 * kBandPitch * 8 + 64 * kBandParamWords * 4 + 2 * kBandStage * 4;
 
 struct BandPair {            // per-pair parameters parked in LDS for phase 1 (uniform reads)
     uint32_t pat_lo, pat_hi; // pattern pointer
     uint32_t txt_lo, txt_hi; // text pointer
     uint32_t len1, len2;     // pattern / text length in symbols
     int32_t start0;          // pattern index of window bit 0 at text index 0 (= dhi - 63)
-    int32_t pat_min, pat_max;  // clamp range of symbol-read start indices relative to the pattern pointer
-    int32_t txt_avail;       // readable text symbols from the text pointer
-    uint32_t pad0, pad1;
+    uint32_t pad;
 };
 static_assert(sizeof(BandPair) == kBandParamWords * 4, "BandPair layout");
 
@@ -55,16 +54,13 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
     char *wave_lds = smem + (size_t)wave_in_block * kBandLdsPerWave;
     unsigned long long *eqbuf = (unsigned long long *)wave_lds;                   // [64][kBandPitch]
     BandPair *params = (BandPair *)(wave_lds + (size_t)64 * kBandPitch * 8);      // [64]
+    uint32_t *stage = (uint32_t *)(wave_lds + (size_t)64 * kBandPitch * 8 + 64 * kBandParamWords * 4);  // [2][kBandStage]
 
     const uint32_t cstart = args.plan->class_start[cls], ccount = args.plan->class_count[cls];
     const uint32_t chunks = (ccount + 63) / 64;
     const uint32_t waves_total = gridDim.x * kBandWaves;
     const uint32_t wave_id = blockIdx.x * kBandWaves + wave_in_block;
     const uint32_t k = args.job.bound;
-    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
-                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
-    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
-                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
 
     for (uint32_t item_rev = wave_id; item_rev < chunks; item_rev += waves_total) {
         const uint32_t item = chunks - 1 - item_rev;  // longest texts first
@@ -82,8 +78,6 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
         const uint32_t len2 = a_is_text ? la : lb, len1 = a_is_text ? lb : la;
         const Sym *txt = (const Sym *)(a_is_text ? args.job.a.data : args.job.b.data) + (a_is_text ? a0 : b0);
         const Sym *pat = (const Sym *)(a_is_text ? args.job.b.data : args.job.a.data) + (a_is_text ? b0 : a0);
-        const uint64_t pat_start = a_is_text ? b0 : a0, pat_total = a_is_text ? b_total : a_total;
-        const uint64_t txt_start = a_is_text ? a0 : b0, txt_total = a_is_text ? a_total : b_total;
         const int delta = (int)len2 - (int)len1;              // <= 0, |delta| <= k (pre-pass guarantees it)
         const int dhi = ((int)k - delta) / 2;                 // bottom diagonal of the band, 0 <= dhi <= 63
         const int start0 = dhi - 63;
@@ -91,15 +85,10 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
             BandPair bp;
             bp.pat_lo = (uint32_t)(uintptr_t)pat; bp.pat_hi = (uint32_t)((uintptr_t)pat >> 32);
             bp.txt_lo = (uint32_t)(uintptr_t)txt; bp.txt_hi = (uint32_t)((uintptr_t)txt >> 32);
-            bp.len1 = len1; bp.len2 = have ? len2 : 0; bp.start0 = start0;
-            int64_t lo = -(int64_t)pat_start, hi = (int64_t)pat_total - (int64_t)pat_start - 1;
-            bp.pat_min = (int)(lo < -0x40000000ll ? -0x40000000ll : lo);
-            bp.pat_max = (int)(hi > 0x40000000ll ? 0x40000000ll : hi);
-            int64_t av = (int64_t)txt_total - (int64_t)txt_start;
-            bp.txt_avail = (int)(av > 0x40000000ll ? 0x40000000ll : av);
-            bp.pad0 = bp.pad1 = 0;
+            bp.len1 = len1; bp.len2 = have ? len2 : 0; bp.start0 = start0; bp.pad = 0;
             params[lane] = bp;
         }
+        wave_lds_fence();  // params are read by other lanes in phase 1
         uint32_t n_max = have ? len2 : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -119,80 +108,76 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
 
         for (uint32_t i0 = 0; i0 < n_max; i0 += kBandChunk) {
             // ---------------- phase 1: Eq masks, two pairs per iteration ----------------------------
+            // The 32 lanes of a half-wave serve one pair: they stage the 32 + WBITS pattern symbols their
+            // windows cover into LDS once (rows outside the pattern become a sentinel no symbol equals), then
+            // every lane compares its text symbol against its own WBITS-symbol window, one bit per compare.
             const int half = lane >> 5, col = lane & 31;
+            uint32_t *win = stage + half * kBandStage;
+            constexpr int kStageLoads = (32 + WBITS + 31) / 32;
+            // Global loads of pair q+2 are issued before pair q is compared, so their latency overlaps the
+            // compare loop instead of heading every iteration.
+            uint32_t nxt_sym[kStageLoads], nxt_tsym;
+            auto issue_loads = [&](int q) {
+                const BandPair bp = params[q];
+                const uint32_t i = i0 + (uint32_t)col;
+                const Sym *tp = (const Sym *)(((uintptr_t)bp.txt_hi << 32) | bp.txt_lo);
+                const Sym *pw = (const Sym *)(((uintptr_t)bp.pat_hi << 32) | bp.pat_lo);
+                nxt_tsym = i < bp.len2 ? (uint32_t)tp[i] : 0xFFFFFFFEu;   // past the text: matches nothing
+                const int base0 = bp.start0 + (int)i0 + (64 - WBITS);     // pattern index of window symbol 0, column 0
+#pragma unroll
+                for (int r = 0; r < kStageLoads; ++r) {
+                    const int idx = base0 + col + 32 * r;
+                    nxt_sym[r] = (idx >= 0 && idx < (int)bp.len1) ? (uint32_t)pw[idx] : 0xFFFFFFFFu;  // outside: sentinel
+                }
+            };
+            issue_loads(half);
 #pragma unroll 1
             for (int pp = 0; pp < 32; ++pp) {
                 const int q = pp * 2 + half;               // pair slot served by my half of the wave
-                const BandPair bp = params[q];
-                const uint32_t i = i0 + (uint32_t)col;
-                unsigned long long eq = 0;
-                if (i < bp.len2) {
-                    const Sym *tp = (const Sym *)(((uintptr_t)bp.txt_hi << 32) | bp.txt_lo);
-                    const Sym *pw = (const Sym *)(((uintptr_t)bp.pat_hi << 32) | bp.pat_lo);
-                    const uint32_t tsym = (uint32_t)tp[i];
-                    const int sp = bp.start0 + (int)i;     // pattern index of window bit 0
-                    const int base = sp + (64 - WBITS);    // pattern index of the first live bit
-                    uint32_t hits_lo = 0, hits_hi = 0;     // live bits only, bit j <-> window bit 64 - WBITS + j
-                    if constexpr (sizeof(Sym) == 1) {
-                        // WBITS / 4 unaligned dword loads, clamped into the tape
-                        uint32_t dws[WBITS / 4];
-                        const int lo = bp.pat_min, hi = bp.pat_max - 3;
-                        const bool tiny = hi < lo;
+                const uint32_t tsym = nxt_tsym;
 #pragma unroll
-                        for (int w = 0; w < WBITS / 4; ++w) {
-                            const int idx = base + 4 * w;
-                            if (!tiny) {
-                                int c = idx < lo ? lo : (idx > hi ? hi : idx);
-                                uint32_t dw;
-                                __builtin_memcpy(&dw, (const uint8_t *)pw + c, 4);
-                                int d = idx - c;
-                                d = d < -3 ? -3 : (d > 3 ? 3 : d);
-                                dws[w] = d >= 0 ? dw >> (8 * d) : dw << (-8 * d);
-                            } else {
-                                uint32_t dw = 0;
-                                for (int u = 0; u < 4; ++u) {
-                                    int pos = idx + u;
-                                    if (pos >= bp.pat_min && pos <= bp.pat_max) dw |= (uint32_t)((const uint8_t *)pw)[pos] << (8 * u);
-                                }
-                                dws[w] = dw;
-                            }
-                        }
-                        const uint32_t splat = tsym * 0x01010101u;
+                for (int r = 0; r < kStageLoads; ++r)
+                    if (col + 32 * r < 32 + WBITS) win[col + 32 * r] = nxt_sym[r];
+                if (pp + 1 < 32) issue_loads(q + 2);
+                wave_lds_fence();  // every lane reads symbols its neighbours staged
+                // hits: window symbol j <-> band bit 64 - WBITS + j. Built as kSegs independent accumulators
+                // (seg = seg * 2 + (symbol == text symbol), one compare + one add-with-carry per symbol, most
+                // significant first) so the carry chains overlap instead of forming one WBITS-deep dependency.
+                constexpr int kSegs = WBITS >= 64 ? 8 : 4, kSegLen = WBITS / kSegs;
+                static_assert(WBITS % kSegs == 0, "window bits must split evenly");
+                uint32_t seg[kSegs];
 #pragma unroll
-                        for (int w = 0; w < WBITS / 4; ++w) {
-                            uint32_t x = dws[w] ^ splat;   // zero bytes are matches
+                for (int sgm = 0; sgm < kSegs; ++sgm) seg[sgm] = 0;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                uint32_t hit = ((x >> (8 * u)) & 0xffu) == 0 ? 1u : 0u;
-                                int j = 4 * w + u;
-                                if (j < 32) hits_lo |= hit << j; else hits_hi |= hit << (j - 32);
-                            }
-                        }
-                    } else {
-                        uint32_t syms[WBITS];
+                for (int t = kSegLen - 1; t >= 0; --t) {
 #pragma unroll
-                        for (int j = 0; j < WBITS; ++j) syms[j] = band_load_sym<Sym>(pw, base + j, bp.pat_min, bp.pat_max);
-#pragma unroll
-                        for (int j = 0; j < WBITS; ++j) {
-                            uint32_t hit = syms[j] == tsym ? 1u : 0u;
-                            if (j < 32) hits_lo |= hit << j; else hits_hi |= hit << (j - 32);
-                        }
+                    for (int g4 = 0; g4 < kSegs; g4 += 4) {
+                        const uint32_t x0 = win[col + (g4 + 0) * kSegLen + t], x1 = win[col + (g4 + 1) * kSegLen + t];
+                        const uint32_t x2 = win[col + (g4 + 2) * kSegLen + t], x3 = win[col + (g4 + 3) * kSegLen + t];
+                        unsigned long long m0, m1, m2, m3;
+                        // Four compares into four SGPR pairs, then four add-with-carry: every carry is read three
+                        // instructions after it was written (gfx950 wants >= 2 wait states between a VALU write of
+                        // an SGPR and a VALU read of it; hipcc pads that itself but not inside an asm statement).
+                        asm("v_cmp_eq_u32_e64 %4, %8, %12\n\t"
+                            "v_cmp_eq_u32_e64 %5, %9, %12\n\t"
+                            "v_cmp_eq_u32_e64 %6, %10, %12\n\t"
+                            "v_cmp_eq_u32_e64 %7, %11, %12\n\t"
+                            "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\t"
+                            "v_addc_co_u32_e64 %1, %5, %1, %1, %5\n\t"
+                            "v_addc_co_u32_e64 %2, %6, %2, %2, %6\n\t"
+                            "v_addc_co_u32_e64 %3, %7, %3, %3, %7"
+                            : "+v"(seg[g4 + 0]), "+v"(seg[g4 + 1]), "+v"(seg[g4 + 2]), "+v"(seg[g4 + 3]), "=&s"(m0), "=&s"(m1),
+                              "=&s"(m2), "=&s"(m3)
+                            : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(tsym));
                     }
-                    // keep only window rows that exist: 0 <= sp + b < len1
-                    unsigned long long hits = ((unsigned long long)hits_hi << 32) | hits_lo;
-                    unsigned long long window = WBITS == 64 ? hits : (hits << (64 - WBITS));
-                    int first = -sp, last = (int)bp.len1 - 1 - sp;            // valid bits [first, last]
-                    first = first < 0 ? 0 : first;
-                    unsigned long long valid = 0;
-                    if (last >= first && first <= 63) {
-                        last = last > 63 ? 63 : last;
-                        unsigned long long upto = last == 63 ? ~0ull : ((1ull << (last + 1)) - 1);
-                        valid = upto & (~0ull << first);
-                    }
-                    eq = window & valid;
                 }
-                eqbuf[q * kBandPitch + col] = eq;
+                unsigned long long hits = 0;
+#pragma unroll
+                for (int sgm = 0; sgm < kSegs; ++sgm) hits |= (unsigned long long)seg[sgm] << (sgm * kSegLen);
+                eqbuf[q * kBandPitch + col] = WBITS == 64 ? hits : (hits << (64 - WBITS));
+                wave_lds_fence();  // the window buffer is rewritten by the next pair
             }
+            wave_lds_fence();  // Eq masks cross from (pair parity, column) lanes to pair lanes
             // ---------------- phase 2: recurrence, lane = pair -------------------------------------------
 #pragma unroll 4
             for (int c = 0; c < kBandChunk; ++c) {
@@ -221,11 +206,13 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
                     vn_lo = d1_lo & hp_lo; vn_hi = d1_hi & hp_hi;
                 }
             }
+            wave_lds_fence();  // the next chunk's phase 1 overwrites the Eq buffer
         }
         if (have) {
             uint32_t d = cur < 0 ? 0u : (uint32_t)cur;
             store_result(args.job, p, (int64_t)(d > k ? k + 1 : d));
         }
+        wave_lds_fence();  // the next item rewrites params
     }
 }
 

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
             }
         }
         acc[lane] = 0;
+        wave_lds_fence();  // acc slots are accumulated into by other lanes below
 
         // wave-uniform step count
         uint32_t n_eff = have ? n + G - 1 : 0;
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
         const uint32_t mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
         int part = __popc(pv & mask) - __popc(mv & mask);
         if (have && brows) atomicAdd(&acc[slot * G], (uint32_t)part);
+        wave_lds_fence();  // the pair's first lane reads the sum of its blocks' contributions
         if (have && first_blk) {
             uint32_t d = n + acc[lane];
             store_result(args.job, p, (int64_t)clamp_bound(d, args.job.bound));
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
         // ---- clear my table column ---------------------------------------------------------------
 #pragma unroll
         for (int k = 0; k < 32; ++k) eq_lo[k * 64 + lane] = 0;
+        wave_lds_fence();
     }
 }
 

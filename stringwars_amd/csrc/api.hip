@@ -186,8 +186,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         char *out_dev = dev_out ? (char *)spec.out : st.take<char>(out_bytes);
 
         // -- scratch carving ------------------------------------------------------------------------
-        const bool bitpar_ok = engine->kind == 0 && engine->unit_costs && !spec.utf8 &&
-                               engine->algorithm != swh_algorithm_wavefront_k;
+        const bool bitpar_ok = engine->kind == 0 && engine->unit_costs && engine->algorithm != swh_algorithm_wavefront_k;
         size_t need = 0;
         {
             Carver probe{nullptr, 0, 0};

@@ -23,6 +23,8 @@
 // dealt round-robin to waves -- no atomics: one ticket word saturates near 88 dequeues/us
 // (MI355X_MICROARCH.md "dequeue"), slower than the DP itself.
 // Definition matched: `rapidfuzz::distance::levenshtein::distance` (bench.rs:416-419).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace swh {
@@ -61,21 +63,70 @@ struct ByteWindow {
     }
 };
 
-constexpr int kBpWaves = 4;                                  // waves per block
-constexpr int kBpTableWords = 2 * 16 * 64;                   // EqLo + EqHi, per wave
-constexpr size_t kBpLds = (size_t)kBpWaves * (kBpTableWords + 64) * 4 + 80 * 4;
+// Code points (decoded UTF-8, u32) use the same trick with five groups of bits -- four nibbles and the plane
+// (bits 16..20): Eq(c) = T0[c & 15] & T1[(c >> 4) & 15] & T2[(c >> 8) & 15] & T3[(c >> 12) & 15] & T4[c >> 16],
+// 4 x 16 + 32 entries = 24 KB per wave.
+struct SymWindow32 {
+    const uint32_t *base;
+    int lo, hi;
+    __device__ __forceinline__ void init(const uint32_t *data, uint64_t start, uint64_t total) {
+        auto c31 = [](int64_t v) { return (int)(v < -0x40000000ll ? -0x40000000ll : (v > 0x40000000ll ? 0x40000000ll : v)); };
+        base = data + start;
+        lo = c31(-(int64_t)start);
+        hi = c31((int64_t)total - (int64_t)start - 1);
+    }
+    __device__ __forceinline__ uint32_t fetch(int idx) const { return base[bp_med3i(idx, lo, hi)]; }
+};
 
-__global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
+template <typename Sym> struct BpTraits;
+template <> struct BpTraits<uint8_t> {
+    static constexpr int kWaves = 4, kEntries = 32, kMinWavesPerSimd = 4;
+};
+template <> struct BpTraits<uint32_t> {
+    static constexpr int kWaves = 2, kEntries = 96, kMinWavesPerSimd = 1;
+};
+template <typename Sym> constexpr int bp_table_words() { return BpTraits<Sym>::kEntries * 64; }
+template <typename Sym> constexpr size_t bp_lds_bytes() {
+    return (size_t)BpTraits<Sym>::kWaves * (bp_table_words<Sym>() + 64) * 4 + 80 * 4;
+}
+
+template <typename Sym>
+__device__ __forceinline__ void bp_table_insert(uint32_t *table, int lane, uint32_t c, uint32_t bit) {
+    if constexpr (sizeof(Sym) == 1) {
+        atomicOr(&table[(c & 15u) * 64 + lane], bit);
+        atomicOr(&table[(16 + (c >> 4)) * 64 + lane], bit);
+    } else {
+        atomicOr(&table[(c & 15u) * 64 + lane], bit);
+        atomicOr(&table[(16 + ((c >> 4) & 15u)) * 64 + lane], bit);
+        atomicOr(&table[(32 + ((c >> 8) & 15u)) * 64 + lane], bit);
+        atomicOr(&table[(48 + ((c >> 12) & 15u)) * 64 + lane], bit);
+        atomicOr(&table[(64 + ((c >> 16) & 31u)) * 64 + lane], bit);
+    }
+}
+template <typename Sym>
+__device__ __forceinline__ uint32_t bp_table_lookup(const uint32_t *table, int lane, uint32_t c) {
+    if constexpr (sizeof(Sym) == 1) {
+        return table[(c & 15u) * 64 + lane] & table[(16 + (c >> 4)) * 64 + lane];
+    } else {
+        uint32_t e = table[(c & 15u) * 64 + lane] & table[(16 + ((c >> 4) & 15u)) * 64 + lane];
+        e &= table[(32 + ((c >> 8) & 15u)) * 64 + lane] & table[(48 + ((c >> 12) & 15u)) * 64 + lane];
+        return e & table[(64 + ((c >> 16) & 31u)) * 64 + lane];
+    }
+}
+
+template <typename Sym>
+__global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel(KernelArgs args) {
+    constexpr int kBpWaves = BpTraits<Sym>::kWaves, kBpTableWords = bp_table_words<Sym>();
+    constexpr bool kBytes = sizeof(Sym) == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
-    uint32_t *eq_lo = (uint32_t *)smem + (size_t)wave_in_block * kBpTableWords;  // [16][64]
-    uint32_t *eq_hi = eq_lo + 16 * 64;                                            // [16][64]
+    uint32_t *table = (uint32_t *)smem + (size_t)wave_in_block * kBpTableWords;  // [entries][64 lanes]
     uint32_t *acc = (uint32_t *)smem + (size_t)kBpWaves * kBpTableWords + wave_in_block * 64;
     uint32_t *item_prefix = (uint32_t *)smem + (size_t)kBpWaves * (kBpTableWords + 64);  // [65]
 
 #pragma unroll
-    for (int k = 0; k < 32; ++k) eq_lo[k * 64 + lane] = 0;
+    for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
     if (threadIdx.x < 64) {
         // work items per class g = lane + 1: ceil(count / floor(64 / g)); exclusive prefix across the wave
         const uint32_t g = threadIdx.x + 1, per = 64 / g;
@@ -122,35 +173,46 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
         // pattern = shorter string (rows / bits), text = longer string (columns / steps)
         const bool a_is_pattern = la <= lb;
         const uint32_t m = a_is_pattern ? la : lb, n = a_is_pattern ? lb : la;
-        ByteWindow pat, txt;
-        pat.init((const uint8_t *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? a0 : b0,
+        using Window = typename std::conditional<kBytes, ByteWindow, SymWindow32>::type;
+        Window pat, txt;
+        pat.init((const Sym *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? a0 : b0,
                  a_is_pattern ? a_total : b_total);
-        txt.init((const uint8_t *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? b0 : a0,
+        txt.init((const Sym *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? b0 : a0,
                  a_is_pattern ? b_total : a_total);
 
         // rows of my block
         const uint32_t row0 = blk * 32;
         const uint32_t brows = have ? (m > row0 ? (m - row0 < 32 ? m - row0 : 32) : 0) : 0;
 
-        // text prefetch: 16 symbols (4 dwords) per super-step, one super-step ahead
-        uint32_t tnxt[4];
+        // text prefetch: 16 symbols per super-step, one super-step ahead (bytes: 4 dwords; code points: 16)
+        constexpr int kTextRegs = kBytes ? 4 : 16;
+        uint32_t tnxt[kTextRegs];
+        auto fetch_text = [&](int first) {
+            if constexpr (kBytes) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4(q * 4 - (int)blk);
+                for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4(first + q * 4);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) tnxt[q] = txt.fetch(first + q);
+            }
+        };
+        fetch_text(0 - (int)blk);
 
-        // ---- build the nibble tables of my block ------------------------------------------------
+        // ---- build the match tables of my block -------------------------------------------------
+        if constexpr (kBytes) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (brows > (uint32_t)q * 4) {
-                uint32_t dw = pat.fetch4((int)row0 + q * 4);
+            for (int q = 0; q < 8; ++q) {
+                if (brows > (uint32_t)q * 4) {
+                    uint32_t dw = pat.fetch4((int)row0 + q * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if ((uint32_t)(q * 4 + r) < brows) {
-                        uint32_t c = (dw >> (8 * r)) & 0xffu;
-                        atomicOr(&eq_lo[(c & 15u) * 64 + lane], 1u << (q * 4 + r));
-                        atomicOr(&eq_hi[(c >> 4) * 64 + lane], 1u << (q * 4 + r));
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if ((uint32_t)(q * 4 + r) < brows) bp_table_insert<Sym>(table, lane, (dw >> (8 * r)) & 0xffu, 1u << (q * 4 + r));
                 }
             }
+        } else {
+#pragma unroll 4
+            for (int q = 0; q < 32; ++q)
+                if ((uint32_t)q < brows) bp_table_insert<Sym>(table, lane, pat.fetch((int)row0 + q), 1u << q);
         }
         acc[lane] = 0;
         wave_lds_fence();  // acc slots are accumulated into by other lanes below
@@ -166,31 +228,34 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
 
         // lanes that start a pair take the DP boundary (+1 horizontal delta) instead of a neighbour
         const bool first_blk = blk == 0;
+        const uint32_t keep_mask = first_blk ? 0u : 0xFFFFFFFFu, first_ph = first_blk ? 0x80000000u : 0u;
         uint32_t pv = 0xFFFFFFFFu, mv = 0, ph = 0, mh = 0;
         for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
-            uint32_t tcur[4];
+            uint32_t tcur[kTextRegs];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tcur[q] = tnxt[q];
-            if (s0 + 16 < steps) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4((int)s0 + 16 + q * 4 - (int)blk);
-            }
+            for (int q = 0; q < kTextRegs; ++q) tcur[q] = tnxt[q];
+            if (s0 + 16 < steps) fetch_text((int)s0 + 16 - (int)blk);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (s0 + q * 4 >= n_eff) break;  // wave-uniform: no lane has a symbol left in this group
                 uint32_t eqs[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    uint32_t c = (tcur[q] >> (8 * u)) & 0xffu;
-                    eqs[u] = eq_lo[(c & 15u) * 64 + lane] & eq_hi[(c >> 4) * 64 + lane];
+                    uint32_t c;
+                    if constexpr (kBytes) c = (tcur[q] >> (8 * u)) & 0xffu;
+                    else c = tcur[q * 4 + u];
+                    eqs[u] = bp_table_lookup<Sym>(table, lane, c);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = s0 + q * 4 + u;
-                    uint32_t ph_in = (uint32_t)__builtin_amdgcn_update_dpp((int)0x80000000u, (int)ph, 0x138, 0xf, 0xf, false);
-                    uint32_t mh_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x138, 0xf, 0xf, false);
-                    ph_in = first_blk ? 0x80000000u : ph_in;
-                    mh_in = first_blk ? 0u : mh_in;
+                    // bound_ctrl: lane 0 (no source lane) reads 0, so no `old` register has to be re-materialised per
+                    // step; the per-lane masks then splice in the DP boundary for lanes that start a pair. Both
+                    // splices are plain bitwise ops (v_bitop3 / v_and issue at full rate, v_cndmask_e64 does not).
+                    uint32_t ph_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ph, 0x138, 0xf, 0xf, true);
+                    uint32_t mh_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x138, 0xf, 0xf, true);
+                    ph_in = (ph_in & keep_mask) | first_ph;
+                    mh_in = mh_in & keep_mask;
                     if (s - blk < n) {
                         uint32_t eq = eqs[u];
                         uint32_t xv = eq | mv;
@@ -218,27 +283,35 @@ __global__ __launch_bounds__(256, 4) void k_bitparallel(KernelArgs args) {
         }
         // ---- clear my table column ---------------------------------------------------------------
 #pragma unroll
-        for (int k = 0; k < 32; ++k) eq_lo[k * 64 + lane] = 0;
+        for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
         wave_lds_fence();
     }
 }
 
-void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs) {
+template <typename Sym>
+static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     // The work list lives in the device plan; the host only bounds the grid (an item holds >= 1 pair).
+    constexpr int kWaves = BpTraits<Sym>::kWaves;
+    constexpr size_t lds = bp_lds_bytes<Sym>();
     KernelArgs k = args;
     k.boundary = nullptr;
-    uint64_t blocks64 = (pairs + kBpWaves - 1) / kBpWaves;
-    uint32_t max_blocks = (uint32_t)scope->compute_units * 4;  // 4 blocks x 4 waves = 16 waves per CU
+    uint64_t blocks64 = (pairs + kWaves - 1) / kWaves;
+    // bytes: 33 KB blocks of 4 waves, 4 per CU; code points: 49 KB blocks of 2 waves, 3 per CU
+    uint32_t max_blocks = (uint32_t)scope->compute_units * (sizeof(Sym) == 1 ? 4 : 3);
     uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
     static bool attr_set = false;
     if (!attr_set) {
-        SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_bitparallel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)kBpLds));
+        SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_bitparallel<Sym>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    StampGuard guard(scope, "bitparallel");
-    hipLaunchKernelGGL(k_bitparallel, dim3(blocks), dim3(256), kBpLds, scope->stream, k);
+    StampGuard guard(scope, sizeof(Sym) == 1 ? "bitparallel" : "bitparallel_u32");
+    hipLaunchKernelGGL(k_bitparallel<Sym>, dim3(blocks), dim3(kWaves * 64), lds, scope->stream, k);
     SWH_HIP_CHECK(hipGetLastError());
+}
+
+void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs) {
+    if (args.sym_bytes == 4) launch_bitparallel_sym<uint32_t>(scope, args, pairs);
+    else launch_bitparallel_sym<uint8_t>(scope, args, pairs);
 }
 
 }  // namespace swh

@@ -45,15 +45,21 @@ def main():
         a, b = sw.generate_pairs(cfg["workload"], pairs, seed=42)
         gen_s = time.perf_counter() - t0
         da, db = a.to_device(scope), b.to_device(scope)
+        # results stay on the device, like `UnifiedMat` in the reference (bench.rs:466-476): no D2H in the timed call
+        import ctypes as C
+        from stringwars_amd import _native as N
+        out_ptr, err = C.c_void_p(), C.c_char_p()
+        N.check(N.lib.swh_device_alloc(scope.handle, pairs * 4 + 16, C.byref(out_ptr), C.byref(err)), err)
+        out = int(out_ptr.value)
         if cfg["kind"] == "nw":
             alphabet = None if cfg["workload"] == "bytes4k" else sw.synth.AMINO_ACIDS
             engine = sw.NeedlemanWunschScores(substitution_matrix=sw.substitution_matrix(42, alphabet), open=cfg["gaps"][0],
                                               extend=cfg["gaps"][1], capabilities=scope)
-            call = lambda: engine.pairs(da, db, scope)
+            call = lambda: engine.pairs(da, db, scope, out=out)
         else:
             cls = sw.LevenshteinDistancesUTF8 if cfg["kind"] == "lev_utf8" else sw.LevenshteinDistances
             engine = cls(capabilities=scope, algorithm=args.algorithm)
-            call = lambda: engine.pairs(da, db, scope, bound=cfg.get("bound"))
+            call = lambda: engine.pairs(da, db, scope, bound=cfg.get("bound"), out=out)
         call()
         scope.set_profiling(True)
         walls, timings = [], []
@@ -73,6 +79,7 @@ def main():
             "dominant": timings[-1]["dominant_name"], "generate_s": round(gen_s, 2),
         }), flush=True)
         da.free(); db.free()
+        N.lib.swh_device_free(scope.handle, out_ptr)
 
 
 if __name__ == "__main__":

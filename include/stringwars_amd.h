@@ -160,9 +160,29 @@ swh_status_t swh_nw_cross_u64tape(swh_nw_t engine, swh_scope_t scope, const swh_
                                   const swh_tape_u64_t *b, ptrdiff_t *out, size_t row_stride_bytes,
                                   const char **error);
 
+/* ---- Smith-Waterman: `SmithWatermanScores::new(&scope, &byte_to_class, &class_costs, open, extend)`
+ *      (bench.rs:882-963). Local alignment score: max over all cells, floored at 0;
+ *      same matrix / gap conventions as Needleman-Wunsch. */
+typedef struct swh_sw_s *swh_sw_t;
+swh_status_t swh_sw_init(swh_scope_t scope, const int8_t *substitution_256x256, int open, int extend,
+                         swh_sw_t *engine, const char **error);
+swh_status_t swh_sw_init_classes(swh_scope_t scope, const uint8_t *byte_to_class_256,
+                                 const int8_t *class_costs_32x32, int open, int extend, swh_sw_t *engine,
+                                 const char **error);
+swh_status_t swh_sw_free(swh_sw_t engine);
+swh_status_t swh_sw_pairs_u32tape(swh_sw_t engine, swh_scope_t scope, const swh_tape_u32_t *a,
+                                  const swh_tape_u32_t *b, int32_t *out, size_t out_stride_bytes,
+                                  const char **error);
+swh_status_t swh_sw_pairs_u64tape(swh_sw_t engine, swh_scope_t scope, const swh_tape_u64_t *a,
+                                  const swh_tape_u64_t *b, int32_t *out, size_t out_stride_bytes,
+                                  const char **error);
+swh_status_t swh_sw_cross_u64tape(swh_sw_t engine, swh_scope_t scope, const swh_tape_u64_t *a,
+                                  const swh_tape_u64_t *b, ptrdiff_t *out, size_t row_stride_bytes,
+                                  const char **error);
+
 /* ---- Introspection: `log_stringzilla_metadata` (utils.rs:78-92). --------------------------- */
 const char *swh_version(void);
-/* Comma-separated capability string, e.g. "gfx950,hip,wavefront,bitparallel,utf8,nw". */
+/* Comma-separated capability string, e.g. "gfx950,hip,wavefront,bitparallel,banded,utf8,...". */
 const char *swh_capabilities(void);
 
 #ifdef __cplusplus

@@ -161,6 +161,38 @@ public:
     }
 };
 
+/// `SmithWatermanScores` (bench.rs:81, :882-963): local alignment scores, same construction as NeedlemanWunschScores.
+class SmithWatermanScores {
+    swh_sw_t handle_ = nullptr;
+public:
+    SmithWatermanScores(const DeviceScope &scope, const uint8_t (&byte_to_class)[256], const int8_t (&class_costs)[32][32],
+                        int open, int extend) {
+        const char *err = nullptr;
+        swh_status_t status__ = swh_sw_init_classes(scope.handle(), byte_to_class, &class_costs[0][0], open, extend, &handle_, &err);
+        check(status__, err);
+    }
+    SmithWatermanScores(const DeviceScope &scope, const int8_t *matrix_256x256, int open, int extend) {
+        const char *err = nullptr;
+        swh_status_t status__ = swh_sw_init(scope.handle(), matrix_256x256, open, extend, &handle_, &err);
+        check(status__, err);
+    }
+    SmithWatermanScores(const SmithWatermanScores &) = delete;
+    ~SmithWatermanScores() { if (handle_) swh_sw_free(handle_); }
+    void compute_into(const DeviceScope &scope, const BytesTapeView &queries, const BytesTapeView *candidates,
+                      ptrdiff_t *matrix, size_t row_stride_bytes = 0) const {
+        const char *err = nullptr;
+        swh_tape_u64_t q = queries.c(), c = candidates ? candidates->c() : q;
+        swh_status_t status__ = swh_sw_cross_u64tape(handle_, scope.handle(), &q, candidates ? &c : nullptr, matrix, row_stride_bytes, &err);
+        check(status__, err);
+    }
+    void pairs_into(const DeviceScope &scope, const BytesTapeView &a, const BytesTapeView &b, int32_t *out) const {
+        const char *err = nullptr;
+        swh_tape_u64_t ta = a.c(), tb = b.c();
+        swh_status_t status__ = swh_sw_pairs_u64tape(handle_, scope.handle(), &ta, &tb, out, 4, &err);
+        check(status__, err);
+    }
+};
+
 namespace harness {
 
 // ---- env helpers (utils.rs:13-50) --------------------------------------------------------------------

@@ -108,6 +108,12 @@ SIGNATURES = {
     "swh_nw_pairs_u32tape": (C.c_int, [_P, _P, C.POINTER(TapeU32), C.POINTER(TapeU32), _P, C.c_size_t, _ERR]),
     "swh_nw_pairs_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), _P, C.c_size_t, _ERR]),
     "swh_nw_cross_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), _P, C.c_size_t, _ERR]),
+    "swh_sw_init": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P), _ERR]),
+    "swh_sw_init_classes": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(_P), _ERR]),
+    "swh_sw_free": (C.c_int, [_P]),
+    "swh_sw_pairs_u32tape": (C.c_int, [_P, _P, C.POINTER(TapeU32), C.POINTER(TapeU32), _P, C.c_size_t, _ERR]),
+    "swh_sw_pairs_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), _P, C.c_size_t, _ERR]),
+    "swh_sw_cross_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), _P, C.c_size_t, _ERR]),
     "swh_version": (C.c_char_p, []),
     "swh_capabilities": (C.c_char_p, []),
     # harness header

@@ -255,6 +255,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         pre.symmetric = engine->kind == 0 ? 1u : (engine->unit_costs ? 1u : 0u);  // nw: set at init when symmetric
         pre.gap_open = engine->scoring.open; pre.gap_extend = engine->scoring.extend;
         pre.unit_costs = engine->kind == 0 && engine->unit_costs ? 1 : 0;
+        pre.local = engine->kind == 2 ? 1 : 0;
         pre.banded = pre.unit_costs && spec.bound <= 63 && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
         pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.plan = plan_dev;
         launch_prepass(scope, pre);
@@ -263,6 +264,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         k.job = job; k.perm = perm; k.plan = plan_dev; k.scoring = engine->scoring;
         k.off64 = off64; k.sym_bytes = sym_bytes; k.symmetric = pre.symmetric;
         k.affine = engine->scoring.open != engine->scoring.extend ? 1 : 0;
+        k.local = engine->kind == 2 ? 1 : 0;
 
         // The bit-parallel kernel reads its work list from the device plan, so it is enqueued right away;
         // the host copy of the plan (needed only to pick wavefront kernels) travels on a side stream and
@@ -340,7 +342,7 @@ using namespace swh;
 extern "C" {
 
 const char *swh_version(void) { return "0.1.0"; }
-const char *swh_capabilities(void) { return "gfx950,hip,wavefront,bitparallel,utf8,bounded,nw-linear,nw-affine,cross"; }
+const char *swh_capabilities(void) { return "gfx950,hip,wavefront,bitparallel,banded,utf8,bounded,nw-linear,nw-affine,sw-linear,sw-affine,cross"; }
 
 static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_t *out, const char **error) {
     if (!out) return fail(error, swh_invalid_argument_k, "null scope pointer");
@@ -520,14 +522,14 @@ swh_status_t swh_levenshtein_set_algorithm(swh_levenshtein_t handle, swh_algorit
     return swh_success_k;
 }
 
-swh_status_t swh_nw_init(swh_scope_t handle, const int8_t *matrix, int open, int extend, swh_nw_t *out,
-                         const char **error) {
+static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *matrix, int open, int extend, void **out,
+                                   const char **error) {
     if (!handle || !out || !matrix) return fail(error, swh_invalid_argument_k, "null argument");
     if (open > 0 || extend > 0 || open < -4096 || extend < -4096)
         return fail(error, swh_invalid_argument_k, "gap costs must be in [-4096, 0]");
     Scope *scope = (Scope *)handle;
     Engine *engine = new Engine{};
-    engine->kind = 1;
+    engine->kind = kind;
     engine->device = scope->device;
     engine->algorithm = swh_algorithm_wavefront_k;
     engine->scoring = Scoring{0, 0, open, extend, nullptr};
@@ -539,11 +541,11 @@ swh_status_t swh_nw_init(swh_scope_t handle, const int8_t *matrix, int open, int
     (void)hipSetDevice(scope->device);
     swh_status_t st = upload_matrix(engine, matrix, error);
     if (st != swh_success_k) { delete engine; return st; }
-    *out = (swh_nw_t)engine;
+    *out = engine;
     return swh_success_k;
 }
-swh_status_t swh_nw_init_classes(swh_scope_t handle, const uint8_t *byte_to_class, const int8_t *class_costs, int open,
-                                 int extend, swh_nw_t *out, const char **error) {
+static swh_status_t alignment_init_classes(int kind, swh_scope_t handle, const uint8_t *byte_to_class,
+                                           const int8_t *class_costs, int open, int extend, void **out, const char **error) {
     if (!byte_to_class || !class_costs) return fail(error, swh_invalid_argument_k, "null argument");
     static thread_local int8_t table[65536];
     for (int i = 0; i < 256; ++i) {
@@ -553,9 +555,24 @@ swh_status_t swh_nw_init_classes(swh_scope_t handle, const uint8_t *byte_to_clas
             table[i * 256 + j] = class_costs[byte_to_class[i] * 32 + byte_to_class[j]];
         }
     }
-    return swh_nw_init(handle, table, open, extend, out, error);
+    return alignment_init(kind, handle, table, open, extend, out, error);
+}
+swh_status_t swh_nw_init(swh_scope_t handle, const int8_t *matrix, int open, int extend, swh_nw_t *out, const char **error) {
+    return alignment_init(1, handle, matrix, open, extend, (void **)out, error);
+}
+swh_status_t swh_nw_init_classes(swh_scope_t handle, const uint8_t *byte_to_class, const int8_t *class_costs, int open,
+                                 int extend, swh_nw_t *out, const char **error) {
+    return alignment_init_classes(1, handle, byte_to_class, class_costs, open, extend, (void **)out, error);
 }
 swh_status_t swh_nw_free(swh_nw_t handle) { return swh_levenshtein_free((swh_levenshtein_t)handle); }
+swh_status_t swh_sw_init(swh_scope_t handle, const int8_t *matrix, int open, int extend, swh_sw_t *out, const char **error) {
+    return alignment_init(2, handle, matrix, open, extend, (void **)out, error);
+}
+swh_status_t swh_sw_init_classes(swh_scope_t handle, const uint8_t *byte_to_class, const int8_t *class_costs, int open,
+                                 int extend, swh_sw_t *out, const char **error) {
+    return alignment_init_classes(2, handle, byte_to_class, class_costs, open, extend, (void **)out, error);
+}
+swh_status_t swh_sw_free(swh_sw_t handle) { return swh_levenshtein_free((swh_levenshtein_t)handle); }
 
 // ---- calls -----------------------------------------------------------------------------------------
 #define SWH_TAPE(t, w) HostTape{(t)->data, (const void *)(t)->offsets, (t)->count, (w)}
@@ -617,9 +634,9 @@ swh_status_t swh_nw_cross_u64tape(swh_nw_t e, swh_scope_t s, const swh_tape_u64_
     return cross_call(e, 1, s, a, b, false, out, row_stride, error);
 }
 
-static swh_status_t nw_pairs(swh_nw_t e, swh_scope_t s, HostTape a, HostTape b, int32_t *out, size_t stride,
+static swh_status_t nw_pairs(void *e, int kind, swh_scope_t s, HostTape a, HostTape b, int32_t *out, size_t stride,
                              const char **error) {
-    if (e && ((Engine *)e)->kind != 1) return fail(error, swh_invalid_argument_k, "not a Needleman-Wunsch engine");
+    if (e && ((Engine *)e)->kind != kind) return fail(error, swh_invalid_argument_k, "engine kind mismatch");
     CallSpec spec{a, b, false, false, SWH_UNBOUNDED, out, stride ? stride : 4, 0, false};
     if (spec.out_stride < 4) return fail(error, swh_invalid_argument_k, "out_stride_bytes must be >= 4");
     return run_call((Scope *)s, (Engine *)e, spec, error);
@@ -627,12 +644,27 @@ static swh_status_t nw_pairs(swh_nw_t e, swh_scope_t s, HostTape a, HostTape b, 
 swh_status_t swh_nw_pairs_u32tape(swh_nw_t e, swh_scope_t s, const swh_tape_u32_t *a, const swh_tape_u32_t *b,
                                   int32_t *out, size_t stride, const char **error) {
     if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
-    return nw_pairs(e, s, SWH_TAPE(a, 0), SWH_TAPE(b, 0), out, stride, error);
+    return nw_pairs(e, 1, s, SWH_TAPE(a, 0), SWH_TAPE(b, 0), out, stride, error);
 }
 swh_status_t swh_nw_pairs_u64tape(swh_nw_t e, swh_scope_t s, const swh_tape_u64_t *a, const swh_tape_u64_t *b,
                                   int32_t *out, size_t stride, const char **error) {
     if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
-    return nw_pairs(e, s, SWH_TAPE(a, 1), SWH_TAPE(b, 1), out, stride, error);
+    return nw_pairs(e, 1, s, SWH_TAPE(a, 1), SWH_TAPE(b, 1), out, stride, error);
+}
+
+swh_status_t swh_sw_pairs_u32tape(swh_sw_t e, swh_scope_t s, const swh_tape_u32_t *a, const swh_tape_u32_t *b,
+                                  int32_t *out, size_t stride, const char **error) {
+    if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
+    return nw_pairs(e, 2, s, SWH_TAPE(a, 0), SWH_TAPE(b, 0), out, stride, error);
+}
+swh_status_t swh_sw_pairs_u64tape(swh_sw_t e, swh_scope_t s, const swh_tape_u64_t *a, const swh_tape_u64_t *b,
+                                  int32_t *out, size_t stride, const char **error) {
+    if (!a || !b) return fail(error, swh_invalid_argument_k, "null tape");
+    return nw_pairs(e, 2, s, SWH_TAPE(a, 1), SWH_TAPE(b, 1), out, stride, error);
+}
+swh_status_t swh_sw_cross_u64tape(swh_sw_t e, swh_scope_t s, const swh_tape_u64_t *a, const swh_tape_u64_t *b,
+                                  ptrdiff_t *out, size_t row_stride, const char **error) {
+    return cross_call(e, 2, s, a, b, false, out, row_stride, error);
 }
 
 }  // extern "C"

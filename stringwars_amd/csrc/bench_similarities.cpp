@@ -130,12 +130,12 @@ int main() {
     uint8_t byte_to_class[256];
     int8_t class_costs[32][32];
     swh_unary_class_costs(2, -1, byte_to_class, &class_costs[0][0]);  // bench.rs:655-658
-    struct Group { const char *header, *name; int open, extend; };
-    const Group groups[2] = {{"# linear", "linear/stringwars_amd::NeedlemanWunschScores<1gpu>", -2, -2},   // bench.rs:342-351
-                             {"# affine", "affine/stringwars_amd::NeedlemanWunschScores<1gpu>", -5, -1}};  // bench.rs:353-362
+    struct Group { const char *header, *name, *sw_name; int open, extend; };
+    const Group groups[2] = {{"# linear", "linear/stringwars_amd::NeedlemanWunschScores<1gpu>", "linear/stringwars_amd::SmithWatermanScores<1gpu>", -2, -2},   // bench.rs:342-351
+                             {"# affine", "affine/stringwars_amd::NeedlemanWunschScores<1gpu>", "affine/stringwars_amd::SmithWatermanScores<1gpu>", -5, -1}};  // bench.rs:353-362
     for (const Group &g : groups) {
         std::printf("%s\n", g.header);
-        if (!have_gpu) { skipped(g.name, gpu_error); continue; }
+        if (!have_gpu) { skipped(g.name, gpu_error); skipped(g.sw_name, gpu_error); continue; }
         try {
             NeedlemanWunschScores engine(gpu, byte_to_class, class_costs, g.open, g.extend);
             std::vector<ptrdiff_t> matrix(side * side);
@@ -145,6 +145,15 @@ int main() {
                 return WorkUnits{cells, bytes};
             });
         } catch (const Error &e) { skipped(g.name, e.what()); }
+        try {  // bench.rs:882-963
+            SmithWatermanScores engine(gpu, byte_to_class, class_costs, g.open, g.extend);
+            std::vector<ptrdiff_t> matrix(side * side);
+            engine.compute_into(gpu, q, &c, matrix.data());
+            measure_throughput(g.sw_name, ReportAs::Cups, budget, [&] {
+                engine.compute_into(gpu, q, &c, matrix.data());
+                return WorkUnits{cells, bytes};
+            });
+        } catch (const Error &e) { skipped(g.sw_name, e.what()); }
     }
     if (tokens.synthetic) swh_synth_free(&tokens.synth);
     return 0;

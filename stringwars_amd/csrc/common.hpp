@@ -159,7 +159,7 @@ struct Scope {
 };
 
 struct Engine {
-    int kind;  // 0 = levenshtein, 1 = nw
+    int kind;  // 0 = levenshtein, 1 = needleman-wunsch (global), 2 = smith-waterman (local)
     Scoring scoring;
     bool unit_costs;
     swh_algorithm_t algorithm;
@@ -184,6 +184,7 @@ struct PrepassArgs {
     int gap_open, gap_extend;  // max-plus gap costs (negative for distances), for the trivial pairs
     uint32_t unit_costs;    // Levenshtein (0,1,1,1): enables the |la-lb| > bound shortcut
     uint32_t banded;        // bound <= 63 with unit costs: pairs may take the banded kernel
+    uint32_t local;         // local alignment: pairs with an empty side score 0
     uint32_t *perm;         // out: pair ids sorted by key
     uint32_t *hist;         // scratch: kKeys counters
     uint32_t *cursor;       // scratch: kKeys cursors
@@ -198,6 +199,7 @@ struct KernelArgs {
     const Plan *plan;   // device
     Scoring scoring;
     uint32_t off64, sym_bytes, symmetric, affine;
+    uint32_t local;         // Smith-Waterman: local alignment (floors at 0, maximum over all cells)
     int32_t *boundary;      // scratch for multi-pass wavefront
     uint64_t boundary_stride;  // int32 elements per group slot
 };

@@ -70,7 +70,7 @@ __device__ __forceinline__ PairInfo pair_info(const PrepassArgs &args, uint64_t 
         uint32_t len = la + lb;
         info.trivial = true;
         // gap(k) = open + (k-1)*extend; a pair of empty strings scores 0.
-        info.trivial_value = len ? (int64_t)gap_open + (int64_t)(len - 1) * gap_extend : 0;
+        info.trivial_value = (len && !args.local) ? (int64_t)gap_open + (int64_t)(len - 1) * gap_extend : 0;
     } else if (levenshtein_unit && args.job.bound != 0xFFFFFFFFu) {
         uint32_t diff = la > lb ? la - lb : lb - la;
         if (diff > args.job.bound) { info.trivial = true; info.trivial_value = -(int64_t)(args.job.bound + 1); }

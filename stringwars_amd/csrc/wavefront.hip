@@ -19,7 +19,7 @@
 
 namespace swh {
 
-enum WfModel : int { kUniformLinear = 0, kMatrixLinear = 1, kMatrixAffine = 2 };
+enum WfModel : int { kUniformLinear = 0, kMatrixLinear = 1, kMatrixAffine = 2, kMatrixLinearLocal = 3, kMatrixAffineLocal = 4 };
 
 constexpr int kNegInf = -0x20000000;
 constexpr int kMatrixStride = 260;          // bytes per LDS matrix row (256 + one dword of padding)
@@ -106,7 +106,10 @@ __device__ __forceinline__ void store_score(const Job &job, uint64_t p, int scor
 template <typename Sym, int G, int W, int MODEL>
 __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls) {
     constexpr bool kMatrix = MODEL != kUniformLinear;
-    constexpr bool kAffine = MODEL == kMatrixAffine;
+    constexpr bool kAffine = MODEL == kMatrixAffine || MODEL == kMatrixAffineLocal;
+    // Smith-Waterman (local) on the same tiles: boundaries and every cell are floored at 0 and the result is the
+    // maximum over all cells (`SmithWatermanScores`, bench.rs:882-963).
+    constexpr bool kLocal = MODEL == kMatrixLinearLocal || MODEL == kMatrixAffineLocal;
     constexpr int kGroups = 64 / G;  // pairs per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int8_t *lmatrix = (int8_t *)smem;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
         stream.init(row_data, row0, row_total);
 
         int result = 0;
+        [[maybe_unused]] int best = 0;  // local alignment: running maximum of my strip
         for (uint32_t pass = 0; pass < passes; ++pass) {
             const uint32_t c0 = pass * G * W;  // columns c0+1 .. c0+G*W in this pass
             // column symbols of my strip (bytes packed four per register when the strip is wide)
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 uint32_t sym_k = j < cols ? (uint32_t)col_data[col0 + j] : 0u;
                 if constexpr (kPackCols) bs[k >> 2] |= sym_k << (8 * (k & 3));
                 else bs[k] = sym_k;
-                H[k] = open + (int)j * ext;    // H[0][j+1] = open + j*ext
+                H[k] = kLocal ? 0 : open + (int)j * ext;    // H[0][j+1] = open + j*ext (0 for local alignment)
                 if constexpr (kAffine) F[k] = kNegInf;
             }
             auto col_sym = [&](int k) -> uint32_t {
@@ -203,10 +207,10 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 else return bs[k];
             };
             // my right-edge outputs (what the lane above me consumes), row 0
-            int out_h = open + (int)(c0 + gl * W + W - 1) * ext;
+            int out_h = kLocal ? 0 : open + (int)(c0 + gl * W + W - 1) * ext;
             int out_e = kNegInf;
             // diagonal input for my first active row: H[0][c0 + gl*W]
-            int prev_h = (c0 + gl * W) ? open + (int)(c0 + gl * W - 1) * ext : 0;
+            int prev_h = (!kLocal && (c0 + gl * W)) ? open + (int)(c0 + gl * W - 1) * ext : 0;
             int bnd_next[4] = {0, 0, 0, 0}, ebnd_next[4] = {kNegInf, kNegInf, kNegInf, kNegInf};
             int bnd_cur[4], ebnd_cur[4];
             const bool read_bnd = pass > 0 && gl == 0;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = s0 + u;
                     // left-edge inputs: group lane 0 takes the DP boundary column, others the lane below
-                    int edge_h = pass == 0 ? open + (int)s * ext : bnd_cur[u];  // H[s+1][c0]
+                    int edge_h = pass == 0 ? (kLocal ? 0 : open + (int)s * ext) : bnd_cur[u];  // H[s+1][c0]
                     int recv_h = dpp_shift_up<G>(edge_h, out_h);
                     int recv_e = kNegInf;
                     if constexpr (kAffine) recv_e = dpp_shift_up<G>(pass == 0 ? kNegInf : ebnd_cur[u], out_e);
@@ -287,6 +291,10 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                                 } else {
                                     h = max(max(diag + sc, up + open), left + open);
                                 }
+                                if constexpr (kLocal) {
+                                    h = max(h, 0);
+                                    if (c0 + gl * W + k < cols) best = max(best, h);  // phantom columns right of the pair do not count
+                                }
                                 diag = up;
                                 left = h;
                                 H[k] = h;
@@ -302,18 +310,31 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                     prev_h = recv_h;
                 }
             }
-            // result lives in the lane/register holding column `cols`
-            if (have && cols > c0 && cols <= c0 + G * W) {
-                uint32_t jj = cols - 1 - c0;
-                if ((uint32_t)gl == jj / W) {
-                    uint32_t kk = jj % W;
+            if constexpr (!kLocal) {
+                // result lives in the lane/register holding column `cols`
+                if (have && cols > c0 && cols <= c0 + G * W) {
+                    uint32_t jj = cols - 1 - c0;
+                    if ((uint32_t)gl == jj / W) {
+                        uint32_t kk = jj % W;
 #pragma unroll
-                    for (int k = 0; k < W; ++k)
-                        if ((uint32_t)k == kk) result = H[k];
-                    store_score(args.job, p, result);
+                        for (int k = 0; k < W; ++k)
+                            if ((uint32_t)k == kk) result = H[k];
+                        store_score(args.job, p, result);
+                    }
                 }
             }
             if (passes > 1) __builtin_amdgcn_s_waitcnt(0);  // boundary stores land before the next pass reads
+        }
+        if constexpr (kLocal) {
+            // columns past `cols` only ever see symbol 0 lookups; mask them out by construction: strips beyond
+            // the pair's last column contributed cells too, so restrict the maximum to real columns
+            int group_best = best;
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) {
+                int other = __shfl_xor(group_best, off);
+                group_best = other > group_best ? other : group_best;
+            }
+            if (have && gl == 0) store_result(args.job, p, (int64_t)group_best);
         }
     }
 }
@@ -357,7 +378,7 @@ static void launch_model(Scope *scope, const KernelArgs &args, const Plan &plan)
                                        "wavefront_g64_w" #WV);
     SWH_WF64(0, 3) SWH_WF64(1, 4) SWH_WF64(2, 6) SWH_WF64(3, 8) SWH_WF64(4, 12) SWH_WF64(5, 16)
     SWH_WF64(6, 24) SWH_WF64(7, 32)
-    if constexpr (MODEL != kMatrixAffine) {
+    if constexpr (MODEL != kMatrixAffine && MODEL != kMatrixAffineLocal) {
         SWH_WF64(8, 48) SWH_WF64(9, 64) SWH_WF64(10, 80) SWH_WF64(11, 96)
     } else {
         // affine keeps two state rows per column: cap the strip at 32 columns, wider pairs go multi-pass
@@ -378,6 +399,9 @@ void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan) {
         launch_model<uint32_t, kUniformLinear>(scope, args, plan);
     } else if (!matrix) {
         launch_model<uint8_t, kUniformLinear>(scope, args, plan);
+    } else if (args.local) {
+        if (!args.affine) launch_model<uint8_t, kMatrixLinearLocal>(scope, args, plan);
+        else launch_model<uint8_t, kMatrixAffineLocal>(scope, args, plan);
     } else if (!args.affine) {
         launch_model<uint8_t, kMatrixLinear>(scope, args, plan);
     } else {

@@ -24,7 +24,7 @@ from . import _native as N
 
 __all__ = [
     "DeviceScope", "Strs", "DeviceTape", "LevenshteinDistances", "LevenshteinDistancesUTF8",
-    "NeedlemanWunschScores", "edit_distance", "StringWarsError", "UNBOUNDED",
+    "NeedlemanWunschScores", "SmithWatermanScores", "edit_distance", "StringWarsError", "UNBOUNDED",
 ]
 
 StringWarsError = N.StringWarsError
@@ -322,6 +322,8 @@ class NeedlemanWunschScores(_Engine):
     (bench.py:466-472, bench.rs:658-662). ``substitution_matrix=`` takes a full 256x256 int8 table
     instead (config C4). gap(k) = open + (k-1)*extend."""
 
+    _prefix = "swh_nw"
+
     def __init__(self, byte_to_class: Optional[np.ndarray] = None, class_costs: Optional[np.ndarray] = None, *,
                  open: int = -2, extend: int = -2, capabilities: Optional[DeviceScope] = None,
                  substitution_matrix: Optional[np.ndarray] = None):
@@ -333,29 +335,36 @@ class NeedlemanWunschScores(_Engine):
             matrix = np.ascontiguousarray(substitution_matrix, dtype=np.int8)
             if matrix.shape != (256, 256):
                 raise ValueError("substitution_matrix must be 256x256 int8")
-            status = N.lib.swh_nw_init(capabilities.handle, matrix.ctypes.data, open, extend, C.byref(handle), C.byref(err))
+            status = getattr(N.lib, self._prefix + "_init")(capabilities.handle, matrix.ctypes.data, open, extend, C.byref(handle), C.byref(err))
         else:
             classes = np.ascontiguousarray(byte_to_class, dtype=np.uint8)
             costs = np.ascontiguousarray(class_costs, dtype=np.int8)
             if classes.shape != (256,) or costs.shape != (32, 32):
                 raise ValueError("byte_to_class must have 256 entries and class_costs must be 32x32")
-            status = N.lib.swh_nw_init_classes(capabilities.handle, classes.ctypes.data, costs.ctypes.data, open, extend,
-                                               C.byref(handle), C.byref(err))
+            status = getattr(N.lib, self._prefix + "_init_classes")(capabilities.handle, classes.ctypes.data, costs.ctypes.data,
+                                                                   open, extend, C.byref(handle), C.byref(err))
         N.check(status, err)
         self._handle = handle
 
     def __call__(self, queries: TapeLike, candidates: Optional[TapeLike] = None, scope: Optional[DeviceScope] = None, out=None):
         if scope is None:
             raise ValueError("a DeviceScope is required")
-        return self._cross(N.lib.swh_nw_cross_u64tape, queries, candidates, scope, out, np.int64)
+        return self._cross(getattr(N.lib, self._prefix + "_cross_u64tape"), queries, candidates, scope, out, np.int64)
 
     def pairs(self, a: TapeLike, b: TapeLike, scope: DeviceScope, out=None):
-        return self._pairs(N.lib.swh_nw_pairs_u32tape, N.lib.swh_nw_pairs_u64tape, a, b, scope, out, np.int32)
+        return self._pairs(getattr(N.lib, self._prefix + "_pairs_u32tape"), getattr(N.lib, self._prefix + "_pairs_u64tape"),
+                           a, b, scope, out, np.int32)
 
     def __del__(self):
         if getattr(self, "_handle", None):
-            N.lib.swh_nw_free(self._handle)
+            getattr(N.lib, self._prefix + "_free")(self._handle)
             self._handle = None
+
+
+class SmithWatermanScores(NeedlemanWunschScores):
+    """``szs.SmithWatermanScores`` (bench.py:789, bench.rs:882-963): local alignment score, same arguments."""
+
+    _prefix = "swh_sw"
 
 
 def edit_distance(column_a: TapeLike, column_b: TapeLike, scope: DeviceScope, utf8: bool = True,

@@ -11,7 +11,8 @@ BINARY = os.path.join(ROOT, "stringwars_amd", "bench_similarities")
 ROWS = [
     "uniform/stringwars_amd::LevenshteinDistances<1gpu>", "uniform/stringwars_amd::LevenshteinDistancesUtf8<1gpu>",
     "uniform/stringwars_amd::levenshtein_pairs<1gpu>", "linear/stringwars_amd::NeedlemanWunschScores<1gpu>",
-    "affine/stringwars_amd::NeedlemanWunschScores<1gpu>",
+    "affine/stringwars_amd::NeedlemanWunschScores<1gpu>", "linear/stringwars_amd::SmithWatermanScores<1gpu>",
+    "affine/stringwars_amd::SmithWatermanScores<1gpu>",
 ]
 
 

@@ -268,6 +268,40 @@ def test_random_needleman_wunsch(sw, orc, scope, gaps, symmetric):
     assert bad.size == 0, (gaps, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
 
 
+def test_smith_waterman(sw, orc, scope):
+    """`SmithWatermanScores` (bench.rs:882-963): KATs of SURVEY 8c, random matrices, multi-pass, cross-product."""
+    cases = KAT["sw_unary_2_m1"]["cases"]
+    a, b = sw.Strs([c[0] for c in cases]), sw.Strs([c[1] for c in cases])
+    classes, costs = sw.unary_class_costs(2, -1)
+    linear = sw.SmithWatermanScores(classes, costs, open=-2, extend=-2, capabilities=scope)
+    affine = sw.SmithWatermanScores(classes, costs, open=-5, extend=-1, capabilities=scope)
+    assert linear.pairs(a, b, scope).tolist() == [c[2] for c in cases]
+    assert affine.pairs(a, b, scope).tolist() == [c[3] for c in cases]
+    rng = np.random.default_rng(41)
+    lengths = list(range(0, 40)) + [100, 129, 200, 400, 700, 1100, 1600, 2100]
+    items_a, items_b = random_pairs(rng, 400, lengths, 24)
+    items_a += [bytes(rng.integers(65, 85, 7000, dtype=np.uint8)), bytes(rng.integers(65, 85, 3300, dtype=np.uint8))]
+    items_b += [items_a[-2][500:6800], bytes(rng.integers(65, 85, 7000, dtype=np.uint8))]
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    for symmetric in (True, False):
+        matrix = rng.integers(-8, 12, (256, 256)).astype(np.int8)
+        if symmetric:
+            matrix = np.minimum(matrix, matrix.T)
+        for gaps in ((-4, -4), (-11, -1), (-2, -2)):
+            engine = sw.SmithWatermanScores(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope)
+            got = engine.pairs(a, b, scope)
+            want = np.array([orc.nw_score(x, y, matrix, gaps[0], gaps[1], local=True) for x, y in zip(items_a, items_b)])
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (symmetric, gaps, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+    q = sw.Strs(items_a[:19])
+    c = sw.Strs(items_b[:11])
+    engine = sw.SmithWatermanScores(classes, costs, open=-2, extend=-2, capabilities=scope)
+    got = engine(q, c, scope)
+    m32 = np.array([[costs[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+    want = np.array([[orc.nw_score(q[i], c[j], m32, -2, -2, local=True) for j in range(11)] for i in range(19)])
+    assert (got == want).all()
+
+
 def test_needleman_wunsch_multipass_and_cross(sw, orc, scope):
     rng = np.random.default_rng(29)
     matrix = rng.integers(-5, 9, (256, 256)).astype(np.int8)  # asymmetric: columns cannot be swapped

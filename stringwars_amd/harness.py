@@ -1,0 +1,167 @@
+"""Python counterpart of the reference's shared harness for the similarity benches (``utils.py`` +
+the measuring helpers of ``similarities/bench.py``), restated for this backend.
+
+Behaviours reproduced (reference file:line):
+  * reporter line ``f"{name:<42} {' | '.join(columns)}"``, rate/seconds formatting, p50/p99 by index
+    ``round(q * (n - 1))``                                            -- utils.py:251-336
+  * env helpers, ``should_run`` (compiled regex, ``search``)           -- utils.py:18-63, :497-502
+  * batch sizing ``auto_batch_size`` / ``crossproduct_side``           -- utils.py:202-209, bench.py:152-161
+  * tokenisation: ``lines`` = split on LF, ``words`` = ``str.split()`` (ALL whitespace, unlike the Rust
+    loader), ``file``; STRINGWARS_UNIQUE keeps first appearances        -- utils.py:410-451
+  * seeded shuffle ``random.seed(STRINGWARS_SEED or 42); random.shuffle(tokens)`` -- bench.py:847-867
+  * time-budgeted loop: uncounted warm-up, at least one measured call  -- bench.py:198-236
+"""
+from __future__ import annotations
+
+import os
+import random
+import re
+import time
+from typing import Callable, List, Optional, Sequence
+
+REPORT_NAME_WIDTH = 42
+
+
+def get_env(name: str) -> Optional[str]:
+    value = os.environ.get(name)
+    return value if value not in (None, "") else None
+
+
+def get_env_parsed(name: str, default, parser=int):
+    value = get_env(name)
+    if value is None:
+        return default
+    try:
+        return parser(value)
+    except ValueError:
+        return default
+
+
+def get_env_bool(name: str) -> bool:
+    value = get_env(name)
+    return value is not None and value.lower() in ("1", "true", "yes", "on")
+
+
+def scale_si(value: float):
+    for threshold, prefix in ((1e9, "G"), (1e6, "M"), (1e3, "k")):
+        if value >= threshold:
+            return value / threshold, prefix
+    return value, ""
+
+
+def format_si_rate(rate: float, unit: str, space_before_unit: bool = False) -> str:
+    value, prefix = scale_si(rate)
+    if not prefix:
+        return f"{value:.2f} {unit}"
+    return f"{value:.2f} {prefix} {unit}" if space_before_unit else f"{value:.2f} {prefix}{unit}"
+
+
+def format_byte_rate(rate: float) -> str:
+    value, prefix = scale_si(rate)
+    return f"{value:.2f} {prefix}B/s"
+
+
+def format_seconds(seconds: float) -> str:
+    if seconds < 1e-6:
+        return f"{seconds * 1e9:.2f} ns"
+    if seconds < 1e-3:
+        return f"{seconds * 1e6:.2f} µs"
+    if seconds < 1.0:
+        return f"{seconds * 1e3:.2f} ms"
+    return f"{seconds:.2f} s"
+
+
+def stats_line(name: str, report: str, elapsed_seconds: float, elements: int, total_bytes: int,
+               latencies_seconds: Optional[Sequence[float]] = None) -> str:
+    seconds = max(elapsed_seconds, 1e-12)
+    units = {"cups": ("CUPS", False), "hashes": ("hashes/s", True), "bits": ("bits/s", True), "comparisons": ("cmp/s", True)}
+    columns: List[str] = []
+    if report == "bytes":
+        columns.append(format_byte_rate(total_bytes / seconds))
+    elif report in units:
+        columns.append(format_si_rate(elements / seconds, *units[report]))
+    else:
+        raise ValueError(f"Unknown report unit: {report!r}")
+    if report != "bytes" and total_bytes > 0:
+        columns.append(format_byte_rate(total_bytes / seconds))
+    if latencies_seconds:
+        ordered = sorted(latencies_seconds)
+        pick = lambda q: ordered[min(round(q * (len(ordered) - 1)), len(ordered) - 1)]
+        columns.append(f"p50 {format_seconds(pick(0.5))} p99 {format_seconds(pick(0.99))}")
+    return f"{name:<{REPORT_NAME_WIDTH}} {' | '.join(columns)}"
+
+
+def report_stats(name, report, elapsed_seconds, elements, total_bytes, latencies_seconds=None) -> None:
+    print(stats_line(name, report, elapsed_seconds, elements, total_bytes, latencies_seconds), flush=True)
+
+
+def should_run(name: str, pattern: Optional[re.Pattern]) -> bool:
+    return True if pattern is None else bool(pattern.search(name))
+
+
+def auto_batch_size(cores: int, base: Optional[int] = None, default_base: int = 128) -> int:
+    per_core = base if base is not None else get_env_parsed("STRINGWARS_BATCH_PER_CORE", default_base)
+    return max(1, max(1, per_core) * max(1, cores))
+
+
+def crossproduct_side(budget: int, num_tokens: int) -> int:
+    target = max(1, round(budget ** 0.5))
+    return max(1, min(target, num_tokens // 2))
+
+
+def tokenize(haystack, tokens_mode: Optional[str] = None, unique: Optional[bool] = None):
+    mode = tokens_mode or os.environ.get("STRINGWARS_TOKENS", "lines")
+    if mode == "lines":
+        tokens = haystack.split(b"\n" if isinstance(haystack, bytes) else "\n")
+    elif mode == "words":
+        tokens = haystack.split()
+    elif mode == "file":
+        tokens = [haystack]
+    else:
+        raise ValueError(f"Unknown tokens mode: {mode}. Use 'lines', 'words', or 'file'.")
+    if unique is None:
+        unique = get_env_bool("STRINGWARS_UNIQUE")
+    if mode != "file" and unique:
+        tokens = list(dict.fromkeys(tokens))
+    return tokens
+
+
+def load_tokens(path: Optional[str] = None, tokens_mode: str = "words", shuffle: bool = True) -> List[str]:
+    """Dataset -> shuffled token list exactly as similarities/bench.py:857-867 prepares it."""
+    path = path or get_env("STRINGWARS_DATASET")
+    if path is None:
+        raise ValueError("No dataset path provided and STRINGWARS_DATASET not set")
+    with open(path, encoding="utf-8", errors="ignore") as handle:
+        text = handle.read()
+    tokens = tokenize(text, os.environ.get("STRINGWARS_TOKENS", tokens_mode))
+    max_tokens = get_env_parsed("STRINGWARS_MAX_TOKENS", None)
+    if max_tokens is not None and max_tokens > 0:
+        tokens = tokens[:max_tokens]
+    if shuffle:
+        random.seed(get_env_parsed("STRINGWARS_SEED", 42))
+        random.shuffle(tokens)
+    return tokens
+
+
+def measure(name: str, compute: Callable[[], None], cells_per_call: int, bytes_per_call: int, warmup_seconds: float,
+            time_limit_seconds: float, report: str = "cups") -> Optional[dict]:
+    """Uncounted warm-up, then cycle `compute` until the deadline (at least one measured call, also with a zero
+    budget) and print the canonical line. Per-call latencies feed the p50/p99 column."""
+    if warmup_seconds > 0:
+        deadline = time.perf_counter_ns() + int(warmup_seconds * 1e9)
+        while time.perf_counter_ns() < deadline:
+            compute()
+    deadline = time.perf_counter_ns() + int(time_limit_seconds * 1e9)
+    start = last = time.perf_counter_ns()
+    iterations, latencies = 0, []
+    while True:
+        compute()
+        iterations += 1
+        now = time.perf_counter_ns()
+        latencies.append((now - last) / 1e9)
+        last = now
+        if now >= deadline:
+            break
+    elapsed = (time.perf_counter_ns() - start) / 1e9
+    report_stats(name, report, elapsed, cells_per_call * iterations, bytes_per_call * iterations, latencies)
+    return {"name": name, "elapsed": elapsed, "iterations": iterations, "cells": cells_per_call * iterations}

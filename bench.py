@@ -79,20 +79,38 @@ def main():
                for x in (a.data, a.offsets, b.data, b.offsets)]
     da = sw.DeviceTape(tensors[0].data_ptr(), tensors[1].data_ptr(), a.count, np.uint64, keepalive=tensors[:2])
     db = sw.DeviceTape(tensors[2].data_ptr(), tensors[3].data_ptr(), b.count, np.uint64, keepalive=tensors[2:])
-    out = torch.zeros(args.pairs, dtype=torch.int32, device=device)
+    # Two result buffers: the RCCL gather of step i overlaps the kernels of step i+1 (it runs on the process
+    # group's own stream); a buffer is reused only after its gather has been waited for.
+    outs = [torch.zeros(args.pairs, dtype=torch.int32, device=device) for _ in range(2)]
+    out = outs[0]
     comm_device = device if args.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.zeros(args.pairs, dtype=torch.int32, device=comm_device) for _ in range(world)] if rank == 0 and world > 1 else None
+    gathered = [[torch.zeros(args.pairs, dtype=torch.int32, device=comm_device) for _ in range(world)] for _ in range(2)] \
+        if rank == 0 and world > 1 else [None, None]
+    works = [None, None]
 
     scope = sw.DeviceScope(gpu_device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     engine = sw.LevenshteinDistances(capabilities=scope, algorithm=args.algorithm)
     scope.set_async(True)
+    counter = [0]
 
     def step():
-        engine.pairs(da, db, scope, out=out)
+        slot = counter[0] & 1
+        counter[0] += 1
+        if works[slot] is not None:
+            works[slot].wait()
+            works[slot] = None
+        engine.pairs(da, db, scope, out=outs[slot])
         if world > 1:
-            dist.gather(out if args.backend == "nccl" else out.cpu(), gathered, dst=0)
+            if args.backend == "nccl":
+                works[slot] = dist.gather(outs[slot], gathered[slot], dst=0, async_op=True)
+            else:
+                dist.gather(outs[slot].cpu(), gathered[slot], dst=0)
 
     def fence():
+        for slot in range(2):
+            if works[slot] is not None:
+                works[slot].wait()
+                works[slot] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -148,7 +166,8 @@ def main():
     if world > 1 and rank == 0:
         # the gathered vector must hold every rank's shard in rank order: rank 0's own slice is checked bit for bit,
         # the others by a cheap invariant (distances are bounded by the longer string of the pair)
-        gather_ok = bool((gathered[0].cpu().numpy().astype(np.uint32) == result_host).all())
+        last = (counter[0] - 1) & 1
+        gather_ok = bool((gathered[last][0].cpu().numpy().astype(np.uint32) == outs[last].cpu().numpy().astype(np.uint32)).all())
     if rank == 0:
         cpu_baseline = None
         parity = None

@@ -293,6 +293,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
             if (!plan.class_count[c]) continue;
             any_wf = true;
             if (c == kClassWfMulti || (k.affine && c >= kClassWf64 + 8)) multi = true;
+            if (wavefront_strip_cap() && c >= kClassWf64 && wide_w(c - kClassWf64 < kNumWideW ? c - kClassWf64 : kNumWideW - 1) > wavefront_strip_cap()) multi = true;
         }
         if (any_wf) {
             if (multi) {
@@ -496,7 +497,7 @@ swh_status_t swh_levenshtein_init(swh_scope_t handle, int match, int mismatch, i
     engine->unit_costs = match == 0 && mismatch == 1 && open == 1 && extend == 1;
     engine->algorithm = swh_algorithm_auto_k;
     // max-plus core: distances are negated scores
-    engine->scoring = Scoring{-match, -mismatch, -open, -extend, nullptr};
+    engine->scoring = Scoring{-match, -mismatch, -open, -extend, nullptr, nullptr};
     if (open != extend) {
         // affine gaps run on the matrix kernels: expand the uniform costs into a 256x256 table
         static thread_local int8_t table[65536];
@@ -513,6 +514,7 @@ swh_status_t swh_levenshtein_free(swh_levenshtein_t handle) {
     Engine *engine = (Engine *)handle;
     if (!engine) return swh_success_k;
     if (engine->matrix_dev) { (void)hipSetDevice(engine->device); (void)hipFree(engine->matrix_dev); }
+    if (engine->class_dev) { (void)hipSetDevice(engine->device); (void)hipFree(engine->class_dev); }
     delete engine;
     return swh_success_k;
 }
@@ -532,7 +534,7 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
     engine->kind = kind;
     engine->device = scope->device;
     engine->algorithm = swh_algorithm_wavefront_k;
-    engine->scoring = Scoring{0, 0, open, extend, nullptr};
+    engine->scoring = Scoring{0, 0, open, extend, nullptr, nullptr};
     bool symmetric = true;
     for (int i = 0; i < 256 && symmetric; ++i)
         for (int j = 0; j < i; ++j)
@@ -541,6 +543,45 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
     (void)hipSetDevice(scope->device);
     swh_status_t st = upload_matrix(engine, matrix, error);
     if (st != swh_success_k) { delete engine; return st; }
+    // Symbol classes: bytes whose matrix rows AND columns coincide are interchangeable. With <= 32 classes (the
+    // reference's own byte_to_class + 32x32 model, bench.rs:95-108; also 20 amino acids + "other") the kernels keep a
+    // 32-byte cost row in registers per step instead of one LDS lookup per cell.
+    {
+        uint8_t table[1024 + 256];
+        int rep[32], classes = 0;
+        bool fits = true;
+        for (int b = 0; b < 256 && fits; ++b) {
+            int found = -1;
+            for (int c = 0; c < classes && found < 0; ++c) {
+                const int r = rep[c];
+                bool same = memcmp(matrix + b * 256, matrix + r * 256, 256) == 0;
+                for (int k = 0; k < 256 && same; ++k) same = matrix[k * 256 + b] == matrix[k * 256 + r];
+                if (same) found = c;
+            }
+            if (found < 0) {
+                if (classes == 32) { fits = false; break; }
+                rep[classes] = b; found = classes++;
+            }
+            table[1024 + b] = (uint8_t)found;
+        }
+        // Linear gaps run on scores relative to the all-gaps baseline (wavefront.hip): the table then holds
+        // cost - 2*open, which must still fit a signed byte; affine gaps keep the plain costs.
+        const int bias = open == extend ? -2 * open : 0;
+        for (int i = 0; i < classes && fits; ++i)
+            for (int j = 0; j < classes; ++j) {
+                int v = (int)matrix[rep[i] * 256 + rep[j]] + bias;
+                if (v < -128 || v > 127) { fits = false; break; }
+            }
+        if (fits) {
+            memset(table, 0, 1024);
+            for (int i = 0; i < classes; ++i)
+                for (int j = 0; j < classes; ++j) table[i * 32 + j] = (uint8_t)(int8_t)((int)matrix[rep[i] * 256 + rep[j]] + bias);
+            hipError_t err = hipMalloc((void **)&engine->class_dev, sizeof table);
+            if (err == hipSuccess) err = hipMemcpy(engine->class_dev, table, sizeof table, hipMemcpyHostToDevice);
+            if (err != hipSuccess) { swh_levenshtein_free((swh_levenshtein_t)engine); return fail_hip(error, HipFailure{err, "class table upload"}); }
+            if (kind == 1) engine->scoring.class_table = engine->class_dev;  // local alignment keeps the 256x256 path
+        }
+    }
     *out = engine;
     return swh_success_k;
 }

@@ -125,6 +125,7 @@ struct Scoring {
     int match, mismatch;   // uniform substitution (used when `matrix` is null)
     int open, extend;      // gap(k) = open + (k-1)*extend
     const int8_t *matrix;  // device pointer to 256x256 i8, row = a symbol, col = b symbol; or null
+    const uint8_t *class_table;  // device: 32x32 i8 class costs then 256 B byte->class map, when the matrix has <= 32 classes
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -164,6 +165,7 @@ struct Engine {
     bool unit_costs;
     swh_algorithm_t algorithm;
     int8_t *matrix_dev;  // owned
+    uint8_t *class_dev;  // owned
     int device;
 };
 
@@ -206,6 +208,7 @@ struct KernelArgs {
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs);
 void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan_host);
 void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs);
+int wavefront_strip_cap();
 
 // UTF-8 staging: decodes a byte tape into u32 code points + u64 code-point offsets.
 struct Utf8Args {

@@ -15,11 +15,17 @@
 //
 // Strips wider than one pass (columns > G*W of the widest instantiation) run as several passes
 // over column chunks; the chunk's right edge column is parked in a per-group global buffer.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace swh {
 
-enum WfModel : int { kUniformLinear = 0, kMatrixLinear = 1, kMatrixAffine = 2, kMatrixLinearLocal = 3, kMatrixAffineLocal = 4 };
+enum WfModel : int {
+    kUniformLinear = 0, kMatrixLinear = 1, kMatrixAffine = 2, kMatrixLinearLocal = 3, kMatrixAffineLocal = 4,
+    kClassLinear = 5, kClassAffine = 6  // <= 32 symbol classes: cost rows live in registers, bytes picked by v_perm_b32
+};
+constexpr size_t kClassLds = 32 * 32 + 256;  // 32x32 i8 class costs, then the byte -> class map
 
 constexpr int kNegInf = -0x20000000;
 constexpr int kMatrixStride = 260;          // bytes per LDS matrix row (256 + one dword of padding)
@@ -105,11 +111,19 @@ __device__ __forceinline__ void store_score(const Job &job, uint64_t p, int scor
 
 template <typename Sym, int G, int W, int MODEL>
 __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls) {
-    constexpr bool kMatrix = MODEL != kUniformLinear;
-    constexpr bool kAffine = MODEL == kMatrixAffine || MODEL == kMatrixAffineLocal;
+    constexpr bool kClass = MODEL == kClassLinear || MODEL == kClassAffine;
+    constexpr bool kMatrix = MODEL != kUniformLinear && !kClass;   // per-cell LDS gather from the 256x256 table
+    constexpr bool kAffine = MODEL == kMatrixAffine || MODEL == kMatrixAffineLocal || MODEL == kClassAffine;
+    static_assert(!kClass || W % 4 == 0, "class model handles columns four at a time");
     // Smith-Waterman (local) on the same tiles: boundaries and every cell are floored at 0 and the result is the
     // maximum over all cells (`SmithWatermanScores`, bench.rs:882-963).
     constexpr bool kLocal = MODEL == kMatrixLinearLocal || MODEL == kMatrixAffineLocal;
+    // Linear gaps (g = open = extend), global alignment: registers hold scores relative to the all-gaps baseline,
+    //     U[r][k] = H[r][k] - (r + k) * g,   so that   U[r][k] = max3( U[r-1][k-1] + (sub - 2g),  U[r-1][k],  U[r][k-1] ):
+    // ONE add and one max3 per cell (the up / left terms need no gap add at all), every boundary is zero, lanes
+    // exchange U values as they are, and the result is U + (rows + cols) * g. The class model folds -2g into its
+    // cost table, so its cell is `v_add_u32_sdwa (sext byte) ; v_max3_i32`.
+    constexpr bool kSkew = !kAffine && !kLocal;
     constexpr int kGroups = 64 / G;  // pairs per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int8_t *lmatrix = (int8_t *)smem;
@@ -122,6 +136,12 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
         for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) dst[(i >> 6) * (kMatrixStride / 4) + (i & 63)] = src[i];
         __syncthreads();
     }
+    if constexpr (kClass) {
+        const uint32_t *src = (const uint32_t *)args.scoring.class_table;
+        for (int i = threadIdx.x; i < (int)kClassLds / 4; i += blockDim.x) ((uint32_t *)smem)[i] = src[i];
+        __syncthreads();
+    }
+    [[maybe_unused]] const uint8_t *lclass_of = (const uint8_t *)smem + 1024;  // byte -> class (class model)
 
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
@@ -189,17 +209,29 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
             // column symbols of my strip (bytes packed four per register when the strip is wide)
             constexpr bool kPackCols = sizeof(Sym) == 1 && W >= 16 && W % 4 == 0;
             constexpr int kColRegs = kPackCols ? W / 4 : W;
-            uint32_t bs[kColRegs];
+            uint32_t bs[kClass ? 1 : kColRegs];
+            // class model: per group of four columns, four v_perm selectors (one per pair of cost-row dwords): byte
+            // i of selector p is (class_i & 7) when class_i lives in dwords 2p..2p+1 of the row, else 0x0C (zero)
+            [[maybe_unused]] uint32_t sel[kClass ? W : 1];
             int H[W], F[kAffine ? W : 1];
 #pragma unroll
-            for (int k = 0; k < kColRegs; ++k) bs[k] = 0;
+            for (int k = 0; k < (kClass ? 1 : kColRegs); ++k) bs[k] = 0;
+            if constexpr (kClass) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) sel[k] = 0;
+            }
 #pragma unroll
             for (int k = 0; k < W; ++k) {
                 uint32_t j = c0 + gl * W + k;  // 0-based column index
                 uint32_t sym_k = j < cols ? (uint32_t)col_data[col0 + j] : 0u;
-                if constexpr (kPackCols) bs[k >> 2] |= sym_k << (8 * (k & 3));
+                if constexpr (kClass) {
+                    const uint32_t cls_k = lclass_of[sym_k & 0xffu];
+#pragma unroll
+                    for (int pq = 0; pq < 4; ++pq)
+                        sel[(k & ~3) + pq] |= ((cls_k >> 3) == (uint32_t)pq ? (cls_k & 7u) : 0x0Cu) << (8 * (k & 3));
+                } else if constexpr (kPackCols) bs[k >> 2] |= sym_k << (8 * (k & 3));
                 else bs[k] = sym_k;
-                H[k] = kLocal ? 0 : open + (int)j * ext;    // H[0][j+1] = open + j*ext (0 for local alignment)
+                H[k] = (kLocal || kSkew) ? 0 : open + (int)j * ext;    // H[0][j+1] = open + j*ext (0: local alignment, skewed storage)
                 if constexpr (kAffine) F[k] = kNegInf;
             }
             auto col_sym = [&](int k) -> uint32_t {
@@ -207,10 +239,10 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 else return bs[k];
             };
             // my right-edge outputs (what the lane above me consumes), row 0
-            int out_h = kLocal ? 0 : open + (int)(c0 + gl * W + W - 1) * ext;
+            int out_h = (kLocal || kSkew) ? 0 : open + (int)(c0 + gl * W + W - 1) * ext;
             int out_e = kNegInf;
             // diagonal input for my first active row: H[0][c0 + gl*W]
-            int prev_h = (!kLocal && (c0 + gl * W)) ? open + (int)(c0 + gl * W - 1) * ext : 0;
+            int prev_h = (!kLocal && !kSkew && (c0 + gl * W)) ? open + (int)(c0 + gl * W - 1) * ext : 0;
             int bnd_next[4] = {0, 0, 0, 0}, ebnd_next[4] = {kNegInf, kNegInf, kNegInf, kNegInf};
             int bnd_cur[4], ebnd_cur[4];
             const bool read_bnd = pass > 0 && gl == 0;
@@ -243,62 +275,77 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = s0 + u;
                     // left-edge inputs: group lane 0 takes the DP boundary column, others the lane below
-                    int edge_h = pass == 0 ? (kLocal ? 0 : open + (int)s * ext) : bnd_cur[u];  // H[s+1][c0]
+                    int edge_h = pass == 0 ? ((kLocal || kSkew) ? 0 : open + (int)s * ext) : bnd_cur[u];  // H[s+1][c0]
                     int recv_h = dpp_shift_up<G>(edge_h, out_h);
                     int recv_e = kNegInf;
                     if constexpr (kAffine) recv_e = dpp_shift_up<G>(pass == 0 ? kNegInf : ebnd_cur[u], out_e);
                     const uint32_t sym = stream.sym(u);
                     if (s - (uint32_t)gl < rows) {  // active: DP row r = s - gl + 1
                         int diag = prev_h, left = recv_h, e = recv_e;
-                        // Substitution scores are gathered from LDS a chunk of columns ahead of the DP chain, so
-                        // the ds_read latency overlaps the dependent max/add chain instead of serialising with it.
-                        constexpr int kChunk = !kMatrix ? W : (W < 8 ? W : (W % 8 == 0 ? 8 : (W % 6 == 0 ? 6 : (W % 5 == 0 ? 5 : (W % 7 == 0 ? 7 : 1)))));
-                        constexpr int kChunks = W / kChunk;
-                        // Columns and rows are only ever swapped for symmetric matrices (api.hip), where
-                        // subs[row][col] == subs[col][row]: the lookup needs no orientation fix-up.
-                        [[maybe_unused]] const int8_t *mrow = lmatrix + sym * kMatrixStride;
-                        [[maybe_unused]] int sc_nxt[kChunk];
-                        auto gather = [&](int chunk) {
-                            if constexpr (kMatrix) {
-#pragma unroll
-                                for (int q = 0; q < kChunk; ++q) sc_nxt[q] = mrow[col_sym(chunk * kChunk + q)];
+                        [[maybe_unused]] const int bias2 = -2 * open;   // kSkew: substitution scores are used as sub - 2g
+                        auto cell = [&](int k, int sc) {
+                            int up = H[k];
+                            int h;
+                            if constexpr (kAffine) {
+                                int f = max(up + open, F[k] + ext);
+                                F[k] = f;
+                                e = max(left + open, e + ext);
+                                h = max(max(diag + sc, e), f);
+                            } else if constexpr (kSkew) {
+                                h = max(max(diag + sc, up), left);   // sc already carries the -2g bias
+                            } else {
+                                h = max(max(diag + sc, up + open), left + open);
                             }
+                            if constexpr (kLocal) {
+                                h = max(h, 0);
+                                if (c0 + gl * W + k < cols) best = max(best, h);  // phantom columns right of the pair do not count
+                            }
+                            diag = up;
+                            left = h;
+                            H[k] = h;
                         };
-                        gather(0);
+                        if constexpr (kClass) {
+                            // one 32-byte cost row per step (the row symbol's class), then bytes are picked in
+                            // registers: no per-cell LDS traffic at all
+                            const uint32_t rc = lclass_of[sym & 0xffu];
+                            const uint4 r_lo = *(const uint4 *)(smem + rc * 32), r_hi = *(const uint4 *)(smem + rc * 32 + 16);
 #pragma unroll
-                        for (int chunk = 0; chunk < kChunks; ++chunk) {
-                            [[maybe_unused]] int sc_cur[kChunk];
-                            if constexpr (kMatrix) {
+                            for (int g4 = 0; g4 < W; g4 += 4) {
+                                const uint32_t c4 = __builtin_amdgcn_perm(r_lo.y, r_lo.x, sel[g4 + 0]) |
+                                                    __builtin_amdgcn_perm(r_lo.w, r_lo.z, sel[g4 + 1]) |
+                                                    __builtin_amdgcn_perm(r_hi.y, r_hi.x, sel[g4 + 2]) |
+                                                    __builtin_amdgcn_perm(r_hi.w, r_hi.z, sel[g4 + 3]);
+#pragma unroll
+                                for (int i4 = 0; i4 < 4; ++i4) cell(g4 + i4, (int)(int8_t)(c4 >> (8 * i4)));
+                            }
+                        } else if constexpr (kMatrix) {
+                            // Substitution scores are gathered from LDS a chunk of columns ahead of the DP chain, so
+                            // the ds_read latency overlaps the dependent max/add chain instead of serialising with it.
+                            // Columns and rows are only ever swapped for symmetric matrices (api.hip), where
+                            // subs[row][col] == subs[col][row]: the lookup needs no orientation fix-up.
+                            constexpr int kChunk = W < 8 ? W : (W % 8 == 0 ? 8 : (W % 6 == 0 ? 6 : (W % 5 == 0 ? 5 : (W % 7 == 0 ? 7 : 1))));
+                            constexpr int kChunks = W / kChunk;
+                            const int8_t *mrow = lmatrix + sym * kMatrixStride;
+                            int sc_nxt[kChunk];
+#pragma unroll
+                            for (int q = 0; q < kChunk; ++q) sc_nxt[q] = mrow[col_sym(q)];
+#pragma unroll
+                            for (int chunk = 0; chunk < kChunks; ++chunk) {
+                                int sc_cur[kChunk];
 #pragma unroll
                                 for (int q = 0; q < kChunk; ++q) sc_cur[q] = sc_nxt[q];
-                                if (chunk + 1 < kChunks) gather(chunk + 1);
+                                if (chunk + 1 < kChunks) {
+#pragma unroll
+                                    for (int q = 0; q < kChunk; ++q) sc_nxt[q] = mrow[col_sym((chunk + 1) * kChunk + q)];
+                                }
                                 // hipcc otherwise sinks every ds_read next to its use (lgkmcnt(0) per cell)
                                 __builtin_amdgcn_sched_barrier(0);
-                            }
 #pragma unroll
-                            for (int q = 0; q < kChunk; ++q) {
-                                const int k = chunk * kChunk + q;
-                                int up = H[k];
-                                int sc;
-                                if constexpr (kMatrix) sc = sc_cur[q];
-                                else sc = (sym == col_sym(k)) ? match : mismatch;
-                                int h;
-                                if constexpr (kAffine) {
-                                    int f = max(up + open, F[k] + ext);
-                                    F[k] = f;
-                                    e = max(left + open, e + ext);
-                                    h = max(max(diag + sc, e), f);
-                                } else {
-                                    h = max(max(diag + sc, up + open), left + open);
-                                }
-                                if constexpr (kLocal) {
-                                    h = max(h, 0);
-                                    if (c0 + gl * W + k < cols) best = max(best, h);  // phantom columns right of the pair do not count
-                                }
-                                diag = up;
-                                left = h;
-                                H[k] = h;
+                                for (int q = 0; q < kChunk; ++q) cell(chunk * kChunk + q, kSkew ? sc_cur[q] + bias2 : sc_cur[q]);
                             }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < W; ++k) cell(k, (sym == col_sym(k)) ? match + bias2 : mismatch + bias2);
                         }
                         out_h = left;
                         out_e = e;
@@ -319,6 +366,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
 #pragma unroll
                         for (int k = 0; k < W; ++k)
                             if ((uint32_t)k == kk) result = H[k];
+                        if constexpr (kSkew) result += (int)(rows + cols) * open;
                         store_score(args.job, p, result);
                     }
                 }
@@ -347,9 +395,9 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
     constexpr int kGroups = 64 / G;
     uint32_t chunks = (count + kGroups - 1) / kGroups;
     uint32_t blocks = (chunks + 3) / 4;
-    size_t lds = MODEL == kUniformLinear ? 0 : kMatrixLds;
+    size_t lds = MODEL == kUniformLinear ? 0 : (MODEL == kClassLinear || MODEL == kClassAffine ? kClassLds : kMatrixLds);
     // persistent-ish grid: enough blocks to fill the chip several times over, waves stride over chunks
-    uint32_t max_blocks = (uint32_t)scope->compute_units * (lds ? 2 : 8);
+    uint32_t max_blocks = (uint32_t)scope->compute_units * (lds > 4096 ? 2 : 8);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks == 0) return;
     if (lds > 65536) {
@@ -364,6 +412,13 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
     hipLaunchKernelGGL((k_wavefront<Sym, G, W, MODEL>), dim3(blocks), dim3(256), lds, scope->stream, args, cls);
 }
 
+// Tuning knob (STRINGWARS_AMD_WF_CAP=<columns per lane>): strips wider than the cap run as several passes of 32
+// columns per lane instead of one pass of up to 96 -- fewer registers per wave, more waves per SIMD.
+int wavefront_strip_cap() {
+    static int cap = [] { const char *e = getenv("STRINGWARS_AMD_WF_CAP"); return e ? atoi(e) : 0; }();
+    return cap;
+}
+
 template <typename Sym, int MODEL>
 static void launch_model(Scope *scope, const KernelArgs &args, const Plan &plan) {
 #define SWH_WF16(WV)                                                                                   \
@@ -373,9 +428,14 @@ static void launch_model(Scope *scope, const KernelArgs &args, const Plan &plan)
     SWH_WF16(1) SWH_WF16(2) SWH_WF16(3) SWH_WF16(4) SWH_WF16(5) SWH_WF16(6) SWH_WF16(7) SWH_WF16(8)
 #undef SWH_WF16
 #define SWH_WF64(IDX, WV)                                                                              \
-    if (plan.class_count[kClassWf64 + IDX])                                                            \
-        launch_one<Sym, 64, WV, MODEL>(scope, args, kClassWf64 + IDX, plan.class_count[kClassWf64 + IDX], \
-                                       "wavefront_g64_w" #WV);
+    if (plan.class_count[kClassWf64 + IDX]) {                                                          \
+        if (wavefront_strip_cap() && WV > wavefront_strip_cap())                                       \
+            launch_one<Sym, 64, 32, MODEL>(scope, args, kClassWf64 + IDX, plan.class_count[kClassWf64 + IDX], \
+                                           "wavefront_g64_w32_multipass");                           \
+        else                                                                                           \
+            launch_one<Sym, 64, WV, MODEL>(scope, args, kClassWf64 + IDX, plan.class_count[kClassWf64 + IDX], \
+                                           "wavefront_g64_w" #WV);                                   \
+    }
     SWH_WF64(0, 3) SWH_WF64(1, 4) SWH_WF64(2, 6) SWH_WF64(3, 8) SWH_WF64(4, 12) SWH_WF64(5, 16)
     SWH_WF64(6, 24) SWH_WF64(7, 32)
     if constexpr (MODEL != kMatrixAffine && MODEL != kMatrixAffineLocal) {
@@ -393,12 +453,47 @@ static void launch_model(Scope *scope, const KernelArgs &args, const Plan &plan)
                                        "wavefront_g64_w32_multipass");
 }
 
+// Class-table models handle columns four at a time: strips are rounded up to a multiple of four columns.
+template <int MODEL>
+static void launch_class_model(Scope *scope, const KernelArgs &args, const Plan &plan) {
+    for (int wc = 1; wc <= 8; ++wc) {
+        const uint32_t cls = kClassWf16 + wc - 1, count = plan.class_count[cls];
+        if (!count) continue;
+        if (wc <= 4) launch_one<uint8_t, 16, 4, MODEL>(scope, args, cls, count, "wavefront_class_g16_w4");
+        else launch_one<uint8_t, 16, 8, MODEL>(scope, args, cls, count, "wavefront_class_g16_w8");
+    }
+    for (int idx = 0; idx < kNumWideW; ++idx) {
+        const uint32_t cls = kClassWf64 + idx, count = plan.class_count[cls];
+        if (!count) continue;
+        const int w = wide_w(idx);
+        const bool affine = MODEL == kClassAffine;
+        if (w <= 4) launch_one<uint8_t, 64, 4, MODEL>(scope, args, cls, count, "wavefront_class_g64_w4");
+        else if (w <= 8) launch_one<uint8_t, 64, 8, MODEL>(scope, args, cls, count, "wavefront_class_g64_w8");
+        else if (w <= 12) launch_one<uint8_t, 64, 12, MODEL>(scope, args, cls, count, "wavefront_class_g64_w12");
+        else if (w <= 16) launch_one<uint8_t, 64, 16, MODEL>(scope, args, cls, count, "wavefront_class_g64_w16");
+        else if (w <= 24) launch_one<uint8_t, 64, 24, MODEL>(scope, args, cls, count, "wavefront_class_g64_w24");
+        else if (w <= 32 || affine) launch_one<uint8_t, 64, 32, MODEL>(scope, args, cls, count, "wavefront_class_g64_w32");
+        else if constexpr (MODEL == kClassLinear) {
+            if (w <= 48) launch_one<uint8_t, 64, 48, MODEL>(scope, args, cls, count, "wavefront_class_g64_w48");
+            else if (w <= 64) launch_one<uint8_t, 64, 64, MODEL>(scope, args, cls, count, "wavefront_class_g64_w64");
+            else if (w <= 80) launch_one<uint8_t, 64, 80, MODEL>(scope, args, cls, count, "wavefront_class_g64_w80");
+            else launch_one<uint8_t, 64, 96, MODEL>(scope, args, cls, count, "wavefront_class_g64_w96");
+        }
+    }
+    if (plan.class_count[kClassWfMulti])
+        launch_one<uint8_t, 64, 32, MODEL>(scope, args, kClassWfMulti, plan.class_count[kClassWfMulti],
+                                           "wavefront_class_g64_w32_multipass");
+}
+
 void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan) {
     bool matrix = args.scoring.matrix != nullptr;
     if (args.sym_bytes == 4) {
         launch_model<uint32_t, kUniformLinear>(scope, args, plan);
     } else if (!matrix) {
         launch_model<uint8_t, kUniformLinear>(scope, args, plan);
+    } else if (args.scoring.class_table && !args.local) {
+        if (!args.affine) launch_class_model<kClassLinear>(scope, args, plan);
+        else launch_class_model<kClassAffine>(scope, args, plan);
     } else if (args.local) {
         if (!args.affine) launch_model<uint8_t, kMatrixLinearLocal>(scope, args, plan);
         else launch_model<uint8_t, kMatrixAffineLocal>(scope, args, plan);

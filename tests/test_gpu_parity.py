@@ -268,6 +268,30 @@ def test_random_needleman_wunsch(sw, orc, scope, gaps, symmetric):
     assert bad.size == 0, (gaps, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
 
 
+@pytest.mark.parametrize("gaps", [(-4, -4), (-11, -1), (-1, -1)])
+@pytest.mark.parametrize("classes", [2, 21, 32])
+def test_class_table_needleman_wunsch(sw, orc, scope, gaps, classes):
+    """Matrices with <= 32 symbol classes run on the register cost-row model (v_perm selects), both when given as
+    `byte_to_class` + 32x32 costs (bench.rs:658-662) and when a 256x256 matrix merely happens to have few classes."""
+    rng = np.random.default_rng(classes * 7 + gaps[0])
+    byte_to_class = rng.integers(0, classes, 256).astype(np.uint8)
+    costs = np.zeros((32, 32), dtype=np.int8)
+    costs[:classes, :classes] = rng.integers(-9, 12, (classes, classes))          # asymmetric on purpose
+    full = costs[byte_to_class][:, byte_to_class].astype(np.int8)                  # the expanded 256x256 table
+    lengths = list(range(0, 40)) + [63, 64, 65, 100, 129, 200, 257, 400, 513, 700, 1100, 1600, 2100, 3100]
+    items_a, items_b = random_pairs(rng, 350, lengths, 256)
+    items_a += [bytes(rng.integers(0, 256, 7000, dtype=np.uint8)), bytes(rng.integers(0, 256, 5000, dtype=np.uint8))]
+    items_b += [bytes(rng.integers(0, 256, 6600, dtype=np.uint8)), items_a[-1][100:4900]]
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    want = orc.nw_pairs(a, b, full, *gaps)
+    by_classes = sw.NeedlemanWunschScores(byte_to_class, costs, open=gaps[0], extend=gaps[1], capabilities=scope)
+    by_matrix = sw.NeedlemanWunschScores(substitution_matrix=full, open=gaps[0], extend=gaps[1], capabilities=scope)
+    for engine in (by_classes, by_matrix):
+        got = engine.pairs(a, b, scope)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (classes, gaps, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+
+
 def test_smith_waterman(sw, orc, scope):
     """`SmithWatermanScores` (bench.rs:882-963): KATs of SURVEY 8c, random matrices, multi-pass, cross-product."""
     cases = KAT["sw_unary_2_m1"]["cases"]

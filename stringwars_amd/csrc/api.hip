@@ -292,7 +292,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         for (int c = kClassWf16; c <= kClassWfMulti; ++c) {
             if (!plan.class_count[c]) continue;
             any_wf = true;
-            if (c == kClassWfMulti || (k.affine && c >= kClassWf64 + 8)) multi = true;
+            if (c == kClassWfMulti || (k.affine && c >= kClassWf64 + 8)) multi = true;  // (class-table affine needs it from 64 columns/lane up)
             if (wavefront_strip_cap() && c >= kClassWf64 && wide_w(c - kClassWf64 < kNumWideW ? c - kClassWf64 : kNumWideW - 1) > wavefront_strip_cap()) multi = true;
         }
         if (any_wf) {
@@ -564,9 +564,9 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
             }
             table[1024 + b] = (uint8_t)found;
         }
-        // Linear gaps run on scores relative to the all-gaps baseline (wavefront.hip): the table then holds
-        // cost - 2*open, which must still fit a signed byte; affine gaps keep the plain costs.
-        const int bias = open == extend ? -2 * open : 0;
+        // Global alignment runs on scores relative to the all-gaps baseline (wavefront.hip): the table holds
+        // cost - 2*extend, which must still fit a signed byte (otherwise the 256x256 LDS path is used).
+        const int bias = -2 * extend;
         for (int i = 0; i < classes && fits; ++i)
             for (int j = 0; j < classes; ++j) {
                 int v = (int)matrix[rep[i] * 256 + rep[j]] + bias;

@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
     // exchange U values as they are, and the result is U + (rows + cols) * g. The class model folds -2g into its
     // cost table, so its cell is `v_add_u32_sdwa (sext byte) ; v_max3_i32`.
     constexpr bool kSkew = !kAffine && !kLocal;
+    // Gotoh gets the same treatment relative to the extend cost: with X^ = X - (r + k) * ext for H, E and F,
+    //     E^ = max(H^left + (open - ext), E^left)   F^ = max(H^up + (open - ext), F^up)   H^ = max3(H^diag + (sub - 2 ext), E^, F^)
+    // -- six VALU instead of eight; the boundary row / column become the constant open - ext.
+    constexpr bool kSkewAffine = kAffine && !kLocal;
     constexpr int kGroups = 64 / G;  // pairs per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int8_t *lmatrix = (int8_t *)smem;
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                         sel[(k & ~3) + pq] |= ((cls_k >> 3) == (uint32_t)pq ? (cls_k & 7u) : 0x0Cu) << (8 * (k & 3));
                 } else if constexpr (kPackCols) bs[k >> 2] |= sym_k << (8 * (k & 3));
                 else bs[k] = sym_k;
-                H[k] = (kLocal || kSkew) ? 0 : open + (int)j * ext;    // H[0][j+1] = open + j*ext (0: local alignment, skewed storage)
+                H[k] = (kLocal || kSkew) ? 0 : (kSkewAffine ? open - ext : open + (int)j * ext);  // row 0: H[0][j+1] = open + j*ext
                 if constexpr (kAffine) F[k] = kNegInf;
             }
             auto col_sym = [&](int k) -> uint32_t {
@@ -239,10 +243,10 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 else return bs[k];
             };
             // my right-edge outputs (what the lane above me consumes), row 0
-            int out_h = (kLocal || kSkew) ? 0 : open + (int)(c0 + gl * W + W - 1) * ext;
+            int out_h = (kLocal || kSkew) ? 0 : (kSkewAffine ? open - ext : open + (int)(c0 + gl * W + W - 1) * ext);
             int out_e = kNegInf;
             // diagonal input for my first active row: H[0][c0 + gl*W]
-            int prev_h = (!kLocal && !kSkew && (c0 + gl * W)) ? open + (int)(c0 + gl * W - 1) * ext : 0;
+            int prev_h = (!kLocal && !kSkew && (c0 + gl * W)) ? (kSkewAffine ? open - ext : open + (int)(c0 + gl * W - 1) * ext) : 0;
             int bnd_next[4] = {0, 0, 0, 0}, ebnd_next[4] = {kNegInf, kNegInf, kNegInf, kNegInf};
             int bnd_cur[4], ebnd_cur[4];
             const bool read_bnd = pass > 0 && gl == 0;
@@ -275,18 +279,24 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = s0 + u;
                     // left-edge inputs: group lane 0 takes the DP boundary column, others the lane below
-                    int edge_h = pass == 0 ? ((kLocal || kSkew) ? 0 : open + (int)s * ext) : bnd_cur[u];  // H[s+1][c0]
+                    int edge_h = pass == 0 ? ((kLocal || kSkew) ? 0 : (kSkewAffine ? open - ext : open + (int)s * ext)) : bnd_cur[u];  // H[s+1][c0]
                     int recv_h = dpp_shift_up<G>(edge_h, out_h);
                     int recv_e = kNegInf;
                     if constexpr (kAffine) recv_e = dpp_shift_up<G>(pass == 0 ? kNegInf : ebnd_cur[u], out_e);
                     const uint32_t sym = stream.sym(u);
                     if (s - (uint32_t)gl < rows) {  // active: DP row r = s - gl + 1
                         int diag = prev_h, left = recv_h, e = recv_e;
-                        [[maybe_unused]] const int bias2 = -2 * open;   // kSkew: substitution scores are used as sub - 2g
+                        [[maybe_unused]] const int bias2 = -2 * ext;   // skewed models use substitution scores as sub - 2 ext (ext == open when linear)
+                        [[maybe_unused]] const int open_minus_ext = open - ext;
                         auto cell = [&](int k, int sc) {
                             int up = H[k];
                             int h;
-                            if constexpr (kAffine) {
+                            if constexpr (kSkewAffine) {
+                                int f = max(up + open_minus_ext, F[k]);
+                                F[k] = f;
+                                e = max(left + open_minus_ext, e);
+                                h = max(max(diag + sc, e), f);   // sc already carries the -2 ext bias
+                            } else if constexpr (kAffine) {
                                 int f = max(up + open, F[k] + ext);
                                 F[k] = f;
                                 e = max(left + open, e + ext);
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                                 // hipcc otherwise sinks every ds_read next to its use (lgkmcnt(0) per cell)
                                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int q = 0; q < kChunk; ++q) cell(chunk * kChunk + q, kSkew ? sc_cur[q] + bias2 : sc_cur[q]);
+                                for (int q = 0; q < kChunk; ++q) cell(chunk * kChunk + q, (kSkew || kSkewAffine) ? sc_cur[q] + bias2 : sc_cur[q]);
                             }
                         } else {
 #pragma unroll
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
 #pragma unroll
                         for (int k = 0; k < W; ++k)
                             if ((uint32_t)k == kk) result = H[k];
-                        if constexpr (kSkew) result += (int)(rows + cols) * open;
+                        if constexpr (kSkew || kSkewAffine) result += (int)(rows + cols) * ext;
                         store_score(args.job, p, result);
                     }
                 }
@@ -466,18 +476,22 @@ static void launch_class_model(Scope *scope, const KernelArgs &args, const Plan 
         const uint32_t cls = kClassWf64 + idx, count = plan.class_count[cls];
         if (!count) continue;
         const int w = wide_w(idx);
-        const bool affine = MODEL == kClassAffine;
         if (w <= 4) launch_one<uint8_t, 64, 4, MODEL>(scope, args, cls, count, "wavefront_class_g64_w4");
         else if (w <= 8) launch_one<uint8_t, 64, 8, MODEL>(scope, args, cls, count, "wavefront_class_g64_w8");
         else if (w <= 12) launch_one<uint8_t, 64, 12, MODEL>(scope, args, cls, count, "wavefront_class_g64_w12");
         else if (w <= 16) launch_one<uint8_t, 64, 16, MODEL>(scope, args, cls, count, "wavefront_class_g64_w16");
         else if (w <= 24) launch_one<uint8_t, 64, 24, MODEL>(scope, args, cls, count, "wavefront_class_g64_w24");
-        else if (w <= 32 || affine) launch_one<uint8_t, 64, 32, MODEL>(scope, args, cls, count, "wavefront_class_g64_w32");
+        else if (w <= 32) launch_one<uint8_t, 64, 32, MODEL>(scope, args, cls, count, "wavefront_class_g64_w32");
+        else if (w <= 48) launch_one<uint8_t, 64, 48, MODEL>(scope, args, cls, count, "wavefront_class_g64_w48");
+        else if (w <= 64) launch_one<uint8_t, 64, 64, MODEL>(scope, args, cls, count, "wavefront_class_g64_w64");
         else if constexpr (MODEL == kClassLinear) {
-            if (w <= 48) launch_one<uint8_t, 64, 48, MODEL>(scope, args, cls, count, "wavefront_class_g64_w48");
-            else if (w <= 64) launch_one<uint8_t, 64, 64, MODEL>(scope, args, cls, count, "wavefront_class_g64_w64");
-            else if (w <= 80) launch_one<uint8_t, 64, 80, MODEL>(scope, args, cls, count, "wavefront_class_g64_w80");
+            if (w <= 80) launch_one<uint8_t, 64, 80, MODEL>(scope, args, cls, count, "wavefront_class_g64_w80");
             else launch_one<uint8_t, 64, 96, MODEL>(scope, args, cls, count, "wavefront_class_g64_w96");
+        } else {
+            // Gotoh keeps H, F and the selectors per column (3 registers): two exact half-width passes beat one
+            // pass that spills or a wider pass whose second half idles
+            if (w <= 80) launch_one<uint8_t, 64, 40, MODEL>(scope, args, cls, count, "wavefront_class_g64_w40_x2");
+            else launch_one<uint8_t, 64, 48, MODEL>(scope, args, cls, count, "wavefront_class_g64_w48_x2");
         }
     }
     if (plan.class_count[kClassWfMulti])

@@ -256,6 +256,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         pre.gap_open = engine->scoring.open; pre.gap_extend = engine->scoring.extend;
         pre.unit_costs = engine->kind == 0 && engine->unit_costs ? 1 : 0;
         pre.local = engine->kind == 2 ? 1 : 0;
+        pre.direct_short = bitpar_ok && sym_bytes == 1 && engine->algorithm == swh_algorithm_auto_k && scope->hint_short ? 1 : 0;
         pre.banded = pre.unit_costs && spec.bound <= 63 && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
         pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.plan = plan_dev;
         launch_prepass(scope, pre);
@@ -280,6 +281,8 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
         if (spec.utf8)
             SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, scope->side_stream));
         SWH_HIP_CHECK(hipStreamSynchronize(scope->side_stream));
+        // enqueue k_direct_short next time only if short pairs are a real share of the batch (it sweeps all offsets)
+        scope->hint_short = (uint64_t)plan.short_pairs * 4 >= pairs;
         if (*invalid_host) {
             SWH_HIP_CHECK(hipStreamSynchronize(stream));
             snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in an input tape (marker %u)", *invalid_host - 1);

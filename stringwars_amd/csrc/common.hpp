@@ -88,10 +88,10 @@ struct Plan {
     uint64_t symbols;                        // sum len_s(a)+len_s(b)
     uint32_t max_la, max_lb;
     uint32_t invalid_utf8;                   // index+1 of the first pair with invalid UTF-8, else 0
-    uint32_t pad;
+    uint32_t short_pairs;                    // pairs with both sides <= 32 symbols (hint: run k_direct_short next time)
 };
 
-struct PlanPartial { unsigned long long cells, symbols; uint32_t max_la, max_lb; };
+struct PlanPartial { unsigned long long cells, symbols; uint32_t max_la, max_lb, short_pairs, pad; };
 constexpr int kMaxPartials = 2048;
 
 // Class numbering --------------------------------------------------------------------------------
@@ -153,6 +153,7 @@ struct Scope {
     char *plan_area = nullptr;  // device: hist | cursor | partials | plan, zeroed once (the scan kernel re-zeroes hist)
     hipStream_t side_stream = nullptr;  // plan read-back overlaps the first DP kernel
     hipEvent_t plan_ready = nullptr;
+    bool hint_short = true;     // the previous call saw short pairs: enqueue k_direct_short (first call: assume yes)
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
     swh_timing_t last_timing{};
@@ -187,6 +188,7 @@ struct PrepassArgs {
     uint32_t unit_costs;    // Levenshtein (0,1,1,1): enables the |la-lb| > bound shortcut
     uint32_t banded;        // bound <= 63 with unit costs: pairs may take the banded kernel
     uint32_t local;         // local alignment: pairs with an empty side score 0
+    uint32_t direct_short;  // unit-cost byte pairs with both sides <= 32 symbols are scored by k_direct_short
     uint32_t *perm;         // out: pair ids sorted by key
     uint32_t *hist;         // scratch: kKeys counters
     uint32_t *cursor;       // scratch: kKeys cursors

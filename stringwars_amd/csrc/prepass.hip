@@ -13,6 +13,7 @@
 //
 // Also here: UTF-8 -> code point staging (k_utf8_count / k_utf8_write) and a small device scan.
 #include "common.hpp"
+#include "bp_window.hpp"
 
 namespace swh {
 
@@ -55,14 +56,20 @@ __device__ __forceinline__ uint32_t plan_key(uint32_t la, uint32_t lb, uint32_t 
     return cls * kBuckets + (bucket > 63 ? 63 : bucket);
 }
 
-struct PairInfo { uint32_t la, lb; bool trivial; int64_t trivial_value; };
+struct PairInfo { uint32_t la, lb; bool trivial; int64_t trivial_value; uint64_t a0, b0; };
+
+// Pairs of two short byte strings (both <= 32 symbols) are scored by k_direct_short in tape order, one pair per
+// lane; the planning passes then only have to file them under class 0 ("done").
+constexpr uint32_t kDirectMax = 32;
+__device__ __forceinline__ bool short_pair(const PairInfo &info) {
+    return !info.trivial && info.la <= kDirectMax && info.lb <= kDirectMax;
+}
 
 template <typename Off>
 __device__ __forceinline__ PairInfo pair_info(const PrepassArgs &args, uint64_t p, int gap_open, int gap_extend,
                                               bool levenshtein_unit) {
-    uint64_t a0, b0;
     PairInfo info;
-    pair_extent<Off>(args.job, p, a0, info.la, b0, info.lb);
+    pair_extent<Off>(args.job, p, info.a0, info.la, info.b0, info.lb);
     info.trivial = false;
     info.trivial_value = 0;
     uint32_t la = info.la, lb = info.lb;
@@ -82,15 +89,17 @@ template <typename Off>
 __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
     __shared__ uint32_t lhist[kKeys];
     __shared__ unsigned long long lcells, lsyms;
-    __shared__ uint32_t lmaxa, lmaxb;
+    __shared__ uint32_t lmaxa, lmaxb, lshorts;
     for (int i = threadIdx.x; i < kKeys; i += blockDim.x) lhist[i] = 0;
-    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; }
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; }
     __syncthreads();
     unsigned long long cells = 0, syms = 0;
-    uint32_t maxa = 0, maxb = 0;
+    uint32_t maxa = 0, maxb = 0, shorts = 0;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < args.job.pairs; p += stride) {
         PairInfo info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, args.unit_costs != 0);
+        const bool is_short = short_pair(info);
+        shorts += is_short ? 1u : 0u;
         cells += (unsigned long long)info.la * info.lb;
         syms += (unsigned long long)info.la + info.lb;
         maxa = info.la > maxa ? info.la : maxa;
@@ -105,6 +114,8 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
                 if (args.unit_costs) v = (int64_t)clamp_bound((uint32_t)v, args.job.bound);
             }
             store_result(args.job, p, v);
+        } else if (is_short && args.direct_short) {
+            key = kClassTrivial * kBuckets;   // scored by k_direct_short
         } else {
             key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
         }
@@ -114,13 +125,14 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
     atomicAdd(&lsyms, syms);
     atomicMax(&lmaxa, maxa);
     atomicMax(&lmaxb, maxb);
+    atomicAdd(&lshorts, shorts);
     __syncthreads();
     for (int i = threadIdx.x; i < kKeys; i += blockDim.x)
         if (lhist[i]) atomicAdd(&args.hist[i], lhist[i]);
     if (threadIdx.x == 0) {
         // per-block partial sums; k_plan_scan folds them (same-address global atomics from every block
         // serialise in L2 and used to cost more than the whole histogram)
-        PlanPartial part{lcells, lsyms, lmaxa, lmaxb};
+        PlanPartial part{lcells, lsyms, lmaxa, lmaxb, lshorts, 0};
         args.partials[blockIdx.x] = part;
     }
 }
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
                                                     const PlanPartial *partials, uint32_t npartials) {
     __shared__ uint32_t partial[1024];
     __shared__ unsigned long long rcells[1024], rsyms[1024];
-    __shared__ uint32_t rmaxa[1024], rmaxb[1024];
+    __shared__ uint32_t rmaxa[1024], rmaxb[1024], rshort[1024];
     constexpr int kPer = (kKeys + 1023) / 1024;
     uint32_t local[kPer];
     uint32_t sum = 0;
@@ -143,19 +155,20 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
     }
     partial[threadIdx.x] = sum;
     unsigned long long c = 0, sy = 0;
-    uint32_t ma = 0, mb = 0;
+    uint32_t ma = 0, mb = 0, sh = 0;
     for (uint32_t i = threadIdx.x; i < npartials; i += 1024) {
         PlanPartial pp = partials[i];
-        c += pp.cells; sy += pp.symbols;
+        c += pp.cells; sy += pp.symbols; sh += pp.short_pairs;
         ma = pp.max_la > ma ? pp.max_la : ma;
         mb = pp.max_lb > mb ? pp.max_lb : mb;
     }
-    rcells[threadIdx.x] = c; rsyms[threadIdx.x] = sy; rmaxa[threadIdx.x] = ma; rmaxb[threadIdx.x] = mb;
+    rcells[threadIdx.x] = c; rsyms[threadIdx.x] = sy; rmaxa[threadIdx.x] = ma; rmaxb[threadIdx.x] = mb; rshort[threadIdx.x] = sh;
     __syncthreads();
     for (int off = 512; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
             rcells[threadIdx.x] += rcells[threadIdx.x + off];
             rsyms[threadIdx.x] += rsyms[threadIdx.x + off];
+            rshort[threadIdx.x] += rshort[threadIdx.x + off];
             rmaxa[threadIdx.x] = rmaxa[threadIdx.x + off] > rmaxa[threadIdx.x] ? rmaxa[threadIdx.x + off] : rmaxa[threadIdx.x];
             rmaxb[threadIdx.x] = rmaxb[threadIdx.x + off] > rmaxb[threadIdx.x] ? rmaxb[threadIdx.x + off] : rmaxb[threadIdx.x];
         }
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
     }
     if (threadIdx.x == 0) {
         plan->cells = rcells[0]; plan->symbols = rsyms[0]; plan->max_la = rmaxa[0]; plan->max_lb = rmaxb[0];
-        plan->invalid_utf8 = 0; plan->pad = 0;
+        plan->invalid_utf8 = 0; plan->short_pairs = rshort[0];
     }
     for (int off = 1; off < 1024; off <<= 1) {
         uint32_t v = (int)threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
@@ -195,6 +208,8 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
     __shared__ uint32_t lcount[kKeys];
     __shared__ uint32_t lbase[kKeys];
     constexpr int kPerThread = kScatterTile / 256;
+    // nothing left to sort when every pair was finished by the planning pass or the direct kernel
+    if (args.plan->class_count[kClassTrivial] == args.plan->class_start[kMaxClasses]) return;
     uint64_t tiles = (args.job.pairs + kScatterTile - 1) / kScatterTile;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         for (int i = threadIdx.x; i < kKeys; i += blockDim.x) lcount[i] = 0;
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
             keys[k] = 0xFFFFFFFFu;
             if (p < args.job.pairs) {
                 PairInfo info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, args.unit_costs != 0);
-                uint32_t key = info.trivial ? kClassTrivial * kBuckets
+                uint32_t key = (info.trivial || (args.direct_short && short_pair(info))) ? kClassTrivial * kBuckets
                                             : plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
                 keys[k] = key;
                 ranks[k] = atomicAdd(&lcount[key], 1u);
@@ -225,6 +240,87 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
     }
 }
 
+// One pair per lane in tape order; both strings <= 32 bytes. All string loads (8 + 8 dwords) are issued before
+// anything depends on them, so an iteration exposes one memory latency, and 8 KB of LDS per wave leaves 16 waves
+// per CU to hide it. The recurrence is the single-block case of bitparallel.hip (no systolic hand-off).
+template <typename Off>
+__global__ __launch_bounds__(256, 4) void k_direct_short(PrepassArgs args) {
+    __shared__ uint32_t ltable[4][32 * 64];  // per wave: EqLo[16][64] | EqHi[16][64]
+    const int lane = threadIdx.x & 63;
+    uint32_t *table = ltable[threadIdx.x >> 6];
+    for (int k = 0; k < 32; ++k) table[k * 64 + lane] = 0;
+    const uint64_t a_total = (uint64_t)((const Off *)args.job.a.offsets)[args.job.a.count];
+    const uint64_t b_total = (uint64_t)((const Off *)args.job.b.offsets)[args.job.b.count];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (args.job.pairs + stride - 1) / stride;  // wave-uniform trip count
+    for (uint64_t round = 0; round < rounds; ++round) {
+        const uint64_t p = round * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        PairInfo info{};
+        info.trivial = true;
+        if (p < args.job.pairs) info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, true);
+        const bool direct = p < args.job.pairs && short_pair(info);
+        if (!__any(direct)) continue;
+        const bool a_is_pattern = info.la <= info.lb;
+        const uint32_t m = direct ? (a_is_pattern ? info.la : info.lb) : 0, n = direct ? (a_is_pattern ? info.lb : info.la) : 0;
+        ByteWindow pat, txt;
+        pat.init((const uint8_t *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? info.a0 : info.b0,
+                 a_is_pattern ? a_total : b_total);
+        txt.init((const uint8_t *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? info.b0 : info.a0,
+                 a_is_pattern ? b_total : a_total);
+        uint32_t m_max = m, n_max = n;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            uint32_t om = __shfl_xor(m_max, off), on = __shfl_xor(n_max, off);
+            m_max = om > m_max ? om : m_max;
+            n_max = on > n_max ? on : n_max;
+        }
+        uint32_t pw[8], tw[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            pw[q] = (uint32_t)q * 4 < m_max ? pat.fetch4(q * 4) : 0;
+            tw[q] = (uint32_t)q * 4 < n_max ? txt.fetch4(q * 4) : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if ((uint32_t)q * 4 >= m_max) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((uint32_t)(q * 4 + r) < m) {
+                    const uint32_t c = (pw[q] >> (8 * r)) & 0xffu, bit = 1u << (q * 4 + r);
+                    atomicOr(&table[(c & 15u) * 64 + lane], bit);
+                    atomicOr(&table[(16 + (c >> 4)) * 64 + lane], bit);
+                }
+            }
+        }
+        uint32_t pv = 0xFFFFFFFFu, mv = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if ((uint32_t)q * 4 >= n_max) break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t c = (tw[q] >> (8 * u)) & 0xffu;
+                if ((uint32_t)(q * 4 + u) < n) {
+                    const uint32_t eq = table[(c & 15u) * 64 + lane] & table[(16 + (c >> 4)) * 64 + lane];
+                    const uint32_t xv = eq | mv;
+                    const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                    uint32_t ph = mv | ~(xh | pv);
+                    const uint32_t mh = pv & xh;
+                    ph = (ph << 1) | 1u;
+                    pv = (mh << 1) | ~(xv | ph);
+                    mv = ph & xv;
+                }
+            }
+        }
+        if (direct) {
+            const uint32_t mask = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u);
+            const uint32_t d = n + __popc(pv & mask) - __popc(mv & mask);
+            store_result(args.job, p, (int64_t)clamp_bound(d, args.job.bound));
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) table[k * 64 + lane] = 0;
+    }
+}
+
 void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     PrepassArgs args = args_in;
     hipStream_t stream = scope->stream;
@@ -234,6 +330,13 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     if (max_blocks > kMaxPartials) max_blocks = kMaxPartials;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+    if (args.direct_short) {
+        StampGuard guard(scope, "direct_short");
+        int dblocks = (int)((pairs + 255) / 256);
+        if (dblocks > scope->compute_units * 4) dblocks = scope->compute_units * 4;
+        if (args.off64) hipLaunchKernelGGL(k_direct_short<uint64_t>, dim3(dblocks), dim3(256), 0, stream, args);
+        else hipLaunchKernelGGL(k_direct_short<uint32_t>, dim3(dblocks), dim3(256), 0, stream, args);
+    }
     {
         StampGuard guard(scope, "plan_hist");
         if (args.off64) hipLaunchKernelGGL(k_plan_hist<uint64_t>, dim3(blocks), dim3(256), 0, stream, args);

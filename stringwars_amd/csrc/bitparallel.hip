@@ -137,8 +137,8 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
             if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
             else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
         }
-        // pattern = shorter string (rows / bits), text = longer string (columns / steps)
-        const bool a_is_pattern = la <= lb;
+        // pattern = rows / bits / lanes, text = columns / steps: the cheaper of the two assignments (common.hpp)
+        const bool a_is_pattern = bp_pattern_is_a(la, lb);
         const uint32_t m = a_is_pattern ? la : lb, n = a_is_pattern ? lb : la;
         using Window = typename std::conditional<kBytes, ByteWindow, SymWindow32>::type;
         Window pat, txt;

@@ -68,6 +68,17 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Bit-parallel orientation: the "pattern" string supplies the 32-row blocks (lanes), the "text" string the steps.
+// Work is blocks x (text + blocks - 1) block-steps, so the cheaper assignment wins -- usually the LONGER string
+// as pattern when both need the same number of blocks (fewer steps), the shorter one when it saves a block.
+// Must be used identically by the plan key (prepass.hip) and the kernel (bitparallel.hip).
+__host__ __device__ __forceinline__ bool bp_pattern_is_a(uint32_t la, uint32_t lb) {
+    const uint32_t ga = (la + 31) >> 5, gb = (lb + 31) >> 5;
+    if (ga > 64 || gb > 64) return ga <= gb;   // at most one of them fits the 64-block systolic array
+    const uint64_t ca = (uint64_t)ga * (lb + ga - 1), cb = (uint64_t)gb * (la + gb - 1);
+    return ca <= cb;
+}
+
 // Levenshtein results honour the cutoff convention out = min(d, bound + 1).
 __device__ __forceinline__ uint32_t clamp_bound(uint32_t d, uint32_t bound) {
     return (bound != 0xFFFFFFFFu && d > bound) ? bound + 1 : d;

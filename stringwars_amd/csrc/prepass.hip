@@ -35,10 +35,12 @@ __device__ __forceinline__ uint32_t plan_key(uint32_t la, uint32_t lb, uint32_t 
         }
     }
     if (mode == kPlanBitParallel) {
-        uint32_t g = (m + 31) >> 5;
+        const bool pattern_is_a = bp_pattern_is_a(la, lb);
+        const uint32_t pat_len = pattern_is_a ? la : lb, txt_len = pattern_is_a ? lb : la;
+        uint32_t g = (pat_len + 31) >> 5;
         if (g <= 64) {
             uint32_t shift = 2 + ceil_log2_u32(g);
-            uint32_t bucket = n >> shift;
+            uint32_t bucket = txt_len >> shift;
             return (kClassBp0 + g - 1) * kBuckets + (bucket > 63 ? 63 : bucket);
         }
     }

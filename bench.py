@@ -91,6 +91,7 @@ def main():
     scope = sw.DeviceScope(gpu_device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     engine = sw.LevenshteinDistances(capabilities=scope, algorithm=args.algorithm)
     scope.set_async(True)
+    scope.set_pipelined(True)   # step i+1's planning pre-pass overlaps step i's DP kernel (two internal lanes)
     counter = [0]
 
     def step():
@@ -101,6 +102,7 @@ def main():
             works[slot] = None
         engine.pairs(da, db, scope, out=outs[slot])
         if world > 1:
+            scope.join()            # the gather is ordered on torch's stream: make that stream wait for this call
             if args.backend == "nccl":
                 works[slot] = dist.gather(outs[slot], gathered[slot], dst=0, async_op=True)
             else:
@@ -111,6 +113,7 @@ def main():
             if works[slot] is not None:
                 works[slot].wait()
                 works[slot] = None
+        scope.synchronize()         # both pipeline lanes
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -134,6 +137,7 @@ def main():
         total_cells = cells
 
     # ---- roofline of the dominant kernel: hipEvents on the kernel's own stream, inside the library ------
+    scope.set_pipelined(False)
     scope.set_async(False)
     scope.set_profiling(True)
     samples = []

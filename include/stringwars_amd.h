@@ -67,6 +67,13 @@ swh_status_t swh_scope_compute_units(swh_scope_t scope, size_t *compute_units);
 /* async != 0: engine calls only enqueue; `swh_scope_synchronize` makes results visible. */
 swh_status_t swh_scope_set_async(swh_scope_t scope, int async);
 swh_status_t swh_scope_synchronize(swh_scope_t scope, const char **error);
+/* Pipelined mode (implies async): successive engine calls alternate between two internal lanes (stream + scratch), so
+ * the planning pre-pass of one call overlaps the DP kernel of the previous one. Inputs must already be complete on the
+ * device when a call is made. `swh_scope_join` makes the scope's own stream (the one given to
+ * swh_scope_init_gpu_stream) wait for the latest call, for consumers ordered on that stream (e.g. an RCCL gather);
+ * `swh_scope_synchronize` waits for everything. */
+swh_status_t swh_scope_set_pipelined(swh_scope_t scope, int enabled, const char **error);
+swh_status_t swh_scope_join(swh_scope_t scope, const char **error);
 
 /* Kernel timing (hipEvents on the scope's stream around every kernel of the last engine call).
  * Used by bench.py's roofline object; off by default. */

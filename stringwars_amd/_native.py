@@ -85,6 +85,8 @@ SIGNATURES = {
     "swh_scope_compute_units": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
     "swh_scope_set_async": (C.c_int, [_P, C.c_int]),
     "swh_scope_synchronize": (C.c_int, [_P, _ERR]),
+    "swh_scope_set_pipelined": (C.c_int, [_P, C.c_int, _ERR]),
+    "swh_scope_join": (C.c_int, [_P, _ERR]),
     "swh_scope_set_profiling": (C.c_int, [_P, C.c_int]),
     "swh_scope_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
     "swh_unified_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), _ERR]),

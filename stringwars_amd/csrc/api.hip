@@ -119,7 +119,22 @@ static uint64_t read_offset(const void *offs, int off64, size_t i, bool device, 
     return v;
 }
 
+static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSpec &spec, const char **error);
+
 static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec &spec, const char **error) {
+    if (!scope || !engine) return fail(error, swh_invalid_argument_k, "null scope or engine");
+    if (!scope->pipelined) return run_call_on(scope, engine, spec, error);
+    Scope *lane = scope->lanes[scope->next_lane];
+    scope->next_lane ^= 1;
+    scope->last_lane = lane;
+    swh_status_t status = run_call_on(lane, engine, spec, error);
+    if (status == swh_success_k && hipEventRecord(lane->lane_done, lane->stream) != hipSuccess)
+        return fail(error, swh_device_error_k, "hipEventRecord failed on a pipeline lane");
+    scope->last_timing = lane->last_timing;
+    return status;
+}
+
+static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSpec &spec, const char **error) {
     if (!scope || !engine) return fail(error, swh_invalid_argument_k, "null scope or engine");
     if (!spec.out && spec.a.count) return fail(error, swh_invalid_argument_k, "null output pointer");
     if (!spec.cross && spec.a.count != spec.b.count)
@@ -395,8 +410,11 @@ swh_status_t swh_scope_init_cpu(size_t, swh_scope_t *scope, const char **error) 
 swh_status_t swh_scope_free(swh_scope_t handle) {
     Scope *scope = (Scope *)handle;
     if (!scope) return swh_success_k;
+    for (Scope *&lane : scope->lanes)
+        if (lane) { swh_scope_free((swh_scope_t)lane); lane = nullptr; }
     (void)hipSetDevice(scope->device);
     (void)hipStreamSynchronize(scope->stream);
+    if (scope->lane_done) (void)hipEventDestroy(scope->lane_done);
     for (auto &st : scope->stamps) { (void)hipEventDestroy(st.start); (void)hipEventDestroy(st.stop); }
     if (scope->scratch) (void)hipFree(scope->scratch);
     if (scope->stage) (void)hipFree(scope->stage);
@@ -422,9 +440,43 @@ swh_status_t swh_scope_set_async(swh_scope_t handle, int async) {
 swh_status_t swh_scope_synchronize(swh_scope_t handle, const char **error) {
     Scope *scope = (Scope *)handle;
     if (!scope) return fail(error, swh_invalid_argument_k, "null scope");
+    for (Scope *lane : scope->lanes)
+        if (lane) {
+            hipError_t lerr = hipStreamSynchronize(lane->stream);
+            if (lerr != hipSuccess) return fail_hip(error, HipFailure{lerr, "hipStreamSynchronize (lane)"});
+        }
     hipError_t err = hipStreamSynchronize(scope->stream);
     if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipStreamSynchronize"});
     if (scope->profiling) collect_timing(scope);
+    return swh_success_k;
+}
+swh_status_t swh_scope_set_pipelined(swh_scope_t handle, int enabled, const char **error) {
+    Scope *scope = (Scope *)handle;
+    if (!scope) return fail(error, swh_invalid_argument_k, "null scope");
+    swh_status_t status = swh_scope_synchronize(handle, error);
+    if (status != swh_success_k) return status;
+    if (enabled) {
+        for (Scope *&lane : scope->lanes) {
+            if (lane) continue;
+            swh_scope_t created = nullptr;
+            status = swh_scope_init_gpu(scope->device, &created, error);   // own non-blocking stream + buffers
+            if (status != swh_success_k) return status;
+            lane = (Scope *)created;
+            lane->async = true;
+            if (hipEventCreateWithFlags(&lane->lane_done, hipEventDisableTiming) != hipSuccess)
+                return fail(error, swh_device_error_k, "hipEventCreate failed for a pipeline lane");
+        }
+    }
+    scope->pipelined = enabled != 0;
+    scope->last_lane = nullptr;
+    return swh_success_k;
+}
+swh_status_t swh_scope_join(swh_scope_t handle, const char **error) {
+    Scope *scope = (Scope *)handle;
+    if (!scope) return fail(error, swh_invalid_argument_k, "null scope");
+    if (!scope->pipelined || !scope->last_lane) return swh_success_k;   // calls already ran on the scope's own stream
+    hipError_t err = hipStreamWaitEvent(scope->stream, scope->last_lane->lane_done, 0);
+    if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipStreamWaitEvent"});
     return swh_success_k;
 }
 swh_status_t swh_scope_set_profiling(swh_scope_t handle, int enabled) {

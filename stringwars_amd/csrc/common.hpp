@@ -165,6 +165,14 @@ struct Scope {
     hipStream_t side_stream = nullptr;  // plan read-back overlaps the first DP kernel
     hipEvent_t plan_ready = nullptr;
     bool hint_short = true;     // the previous call saw short pairs: enqueue k_direct_short (first call: assume yes)
+    // Pipelined mode: calls alternate between `lanes` (internal scopes with their own stream, scratch and plan
+    // buffers), so the planning pre-pass of call i+1 overlaps the DP kernel of call i. Results are ordered for the
+    // caller by swh_scope_join / swh_scope_synchronize.
+    bool pipelined = false;
+    Scope *lanes[2] = {nullptr, nullptr};
+    int next_lane = 0;
+    hipEvent_t lane_done = nullptr;   // (on a lane) recorded after the lane's latest call
+    Scope *last_lane = nullptr;       // (on the parent) lane that took the latest call
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
     swh_timing_t last_timing{};

@@ -80,6 +80,16 @@ class DeviceScope:
     def set_async(self, enabled: bool) -> None:
         N.lib.swh_scope_set_async(self._handle, int(bool(enabled)))
 
+    def set_pipelined(self, enabled: bool) -> None:
+        """Alternate calls between two internal lanes so the next call's planning overlaps this call's DP kernel;
+        consumers ordered on the scope's stream call ``join()`` first, everyone else ``synchronize()``."""
+        err = C.c_char_p()
+        N.check(N.lib.swh_scope_set_pipelined(self._handle, int(bool(enabled)), C.byref(err)), err)
+
+    def join(self) -> None:
+        err = C.c_char_p()
+        N.check(N.lib.swh_scope_join(self._handle, C.byref(err)), err)
+
     def set_profiling(self, enabled: bool) -> None:
         N.lib.swh_scope_set_profiling(self._handle, int(bool(enabled)))
 

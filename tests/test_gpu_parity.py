@@ -380,6 +380,38 @@ def test_tape_widths_residency_and_strides(sw, orc, scope):
     N.lib.swh_unified_free(scope.handle, pointer)
 
 
+def test_pipelined_scope_lanes(sw, orc):
+    """Pipelined mode alternates calls between two internal lanes; results must be complete after synchronize()
+    (or, on the scope's own stream, after join()) and identical to the synchronous path."""
+    import torch
+    torch_scope = sw.DeviceScope(gpu_device=0, stream=torch.cuda.current_stream().cuda_stream)
+    engine = sw.LevenshteinDistances(capabilities=torch_scope)
+    batches = []
+    for seed, workload, count in ((1, "tokens64", 30000), (2, "words16", 50000), (3, "tokens64", 7000), (4, "short_words", 90000),
+                                  (5, "tokens64", 30000), (6, "utf8_lines", 300)):
+        a, b = sw.generate_pairs(workload, count, seed=seed)
+        batches.append((a.to_device(torch_scope), b.to_device(torch_scope), orc.levenshtein_pairs(a, b, algo="hyyro"),
+                        torch.zeros(count, dtype=torch.int32, device="cuda")))
+    torch_scope.set_async(True)
+    torch_scope.set_pipelined(True)
+    for _ in range(3):
+        for da, db, _, out in batches:
+            out.zero_()
+        for da, db, _, out in batches:
+            engine.pairs(da, db, torch_scope, out=out)
+        torch_scope.join()                       # torch's stream now waits for the last call only
+        last = batches[-1][3].cpu().numpy().astype(np.uint32)
+        assert (last == batches[-1][2]).all()
+        torch_scope.synchronize()
+        for _, _, want, out in batches:
+            assert (out.cpu().numpy().astype(np.uint32) == want).all()
+    torch_scope.set_pipelined(False)
+    torch_scope.set_async(False)
+    da, db, want, out = batches[0]
+    engine.pairs(da, db, torch_scope, out=out)
+    assert (out.cpu().numpy().astype(np.uint32) == want).all()
+
+
 def test_edge_cases_and_errors(sw, orc, scope):
     engine = sw.LevenshteinDistances(capabilities=scope)
     assert engine.pairs([], [], scope).size == 0

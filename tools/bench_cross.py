@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Cross-product rows in the shape of the reference's published tables (similarities/README.md:30-136): queries [0, side)
+x candidates [side, 2*side), side = round(sqrt(BATCH_PER_CORE * compute units)) (bench.rs:113-117), synthetic stand-ins
+for its datasets (ACGT 100 B / 1 KB, ~5 B words, ~3.2 KB lines). Matrix stays on the device (UnifiedMat role)."""
+import argparse, ctypes as C, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import stringwars_amd as sw
+from stringwars_amd import _native as N
+
+
+def tokens(kind, count, rng):
+    if kind == "acgt100":
+        lens = np.full(count, 100)
+    elif kind == "acgt1k":
+        lens = np.full(count, 1000)
+    elif kind == "words":
+        lens = np.clip(rng.poisson(4.0, count) + 1, 1, 24)
+    elif kind == "lines":
+        lens = np.clip(rng.normal(3200, 1200, count).astype(int), 200, 9000)
+    alphabet = np.frombuffer(b"ACGT" if kind.startswith("acgt") else bytes(range(97, 123)), dtype=np.uint8)
+    offsets = np.zeros(count + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    data = alphabet[rng.integers(0, len(alphabet), int(offsets[-1]))]
+    return sw.Strs(data=data, offsets=offsets)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kinds", default="acgt100,acgt1k,words,lines")
+    ap.add_argument("--batch-per-core", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=3)
+    args = ap.parse_args()
+    scope = sw.DeviceScope(gpu_device=0)
+    rng = np.random.default_rng(42)
+    classes, costs = sw.unary_class_costs(2, -1)
+    for kind in args.kinds.split(","):
+        per_core = args.batch_per_core or (256 if kind == "lines" else 16384)   # similarities/README.md:22-23
+        side = max(1, round((per_core * scope.compute_units) ** 0.5))
+        tape = tokens(kind, 2 * side, rng)
+        q, c = tape.subview(0, side).to_device(scope), tape.subview(side, 2 * side).to_device(scope)
+        lens = tape.lengths
+        cells = int(lens[:side].sum()) * int(lens[side:].sum())
+        out_ptr, err = C.c_void_p(), C.c_char_p()
+        N.check(N.lib.swh_device_alloc(scope.handle, side * side * 8, C.byref(out_ptr), C.byref(err)), err)
+        engines = {
+            "uniform/LevenshteinDistances": sw.LevenshteinDistances(capabilities=scope),
+            "linear/NeedlemanWunschScores": sw.NeedlemanWunschScores(classes, costs, open=-2, extend=-2, capabilities=scope),
+            "affine/NeedlemanWunschScores": sw.NeedlemanWunschScores(classes, costs, open=-5, extend=-1, capabilities=scope),
+            "linear/SmithWatermanScores": sw.SmithWatermanScores(classes, costs, open=-2, extend=-2, capabilities=scope),
+        }
+        for name, engine in engines.items():
+            call = lambda: engine(q, c, scope, out=int(out_ptr.value))
+            call()
+            best = 1e9
+            for _ in range(args.repeats):
+                t0 = time.perf_counter(); call(); best = min(best, time.perf_counter() - t0)
+            print(json.dumps({"dataset": kind, "side": side, "row": name + "<1gpu>", "mcups": round(cells / best / 1e6),
+                              "call_ms": round(best * 1e3, 3), "cells": cells}), flush=True)
+        N.lib.swh_device_free(scope.handle, out_ptr)
+        q.free(); c.free()
+
+
+if __name__ == "__main__":
+    main()

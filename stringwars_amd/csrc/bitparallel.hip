@@ -153,11 +153,14 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
 
         // text prefetch: 16 symbols per super-step, one super-step ahead (bytes: 4 dwords; code points: 16)
         constexpr int kTextRegs = kBytes ? 4 : 16;
+        // byte words arrive unaligned-corrected only when they are consumed (`realign` next to the load would put the
+        // memory latency on the critical path of every super-step)
         uint32_t tnxt[kTextRegs];
+        int tshift[kBytes ? 4 : 1];
         auto fetch_text = [&](int first) {
             if constexpr (kBytes) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4(first + q * 4);
+                for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4_raw(first + q * 4, tshift[q]);
             } else {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) tnxt[q] = txt.fetch(first + q);
@@ -167,10 +170,16 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
 
         // ---- build the match tables of my block -------------------------------------------------
         if constexpr (kBytes) {
+            // all eight words of the block are requested at once (clamped addresses are always readable): one memory
+            // latency per item instead of one per word
+            uint32_t praw[8];
+            int pshift[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) praw[q] = pat.fetch4_raw((int)row0 + q * 4, pshift[q]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (brows > (uint32_t)q * 4) {
-                    uint32_t dw = pat.fetch4((int)row0 + q * 4);
+                    const uint32_t dw = ByteWindow::realign(praw[q], pshift[q]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if ((uint32_t)(q * 4 + r) < brows) bp_table_insert<Sym>(table, lane, (dw >> (8 * r)) & 0xffu, 1u << (q * 4 + r));
@@ -200,7 +209,10 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
         for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
             uint32_t tcur[kTextRegs];
 #pragma unroll
-            for (int q = 0; q < kTextRegs; ++q) tcur[q] = tnxt[q];
+            for (int q = 0; q < kTextRegs; ++q) {
+                if constexpr (kBytes) tcur[q] = ByteWindow::realign(tnxt[q], tshift[q]);
+                else tcur[q] = tnxt[q];
+            }
             if (s0 + 16 < steps) fetch_text((int)s0 + 16 - (int)blk);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

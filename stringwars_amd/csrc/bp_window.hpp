@@ -20,15 +20,34 @@ struct ByteWindow {
         avail = c31((int64_t)total - (int64_t)start);
         tiny = total < 4;
     }
-    // bytes idx..idx+3 (little-endian); bytes outside the tape come back as garbage
-    __device__ __forceinline__ uint32_t fetch4(int idx) const {
-        if (!tiny) {
-            int c = bp_med3i(idx, lo, hi);
-            uint32_t dw;
-            __builtin_memcpy(&dw, base + c, 4);
-            int d = bp_med3i(idx - c, -3, 3);
-            return d >= 0 ? dw >> (8 * d) : dw << (-8 * d);
-        }
+    // Split form of fetch4_wide for software pipelining: issue the load now, realign the word where it is consumed
+    // (the realignment reads the loaded register, so doing it next to the load would expose the memory latency).
+    __device__ __forceinline__ uint32_t fetch4_raw(int idx, int &shift) const {
+        if (tiny) { shift = 24; return fetch4_tiny(idx); }
+        int c = bp_med3i(idx, lo, hi);
+        uint32_t dw;
+        __builtin_memcpy(&dw, base + c, 4);
+        shift = 8 * bp_med3i(idx - c, -3, 3) + 24;
+        return dw;
+    }
+    // the shift fetch4_raw(idx, .) reported, recomputed where only the raw word was kept
+    __device__ __forceinline__ int shift_of(int idx) const {
+        return 8 * bp_med3i(idx - bp_med3i(idx, lo, hi), -3, 3) + 24;
+    }
+    static __device__ __forceinline__ uint32_t realign(uint32_t dw, int shift) {
+        return (uint32_t)((((uint64_t)dw) << 24) >> (uint32_t)shift);
+    }
+    // same as fetch4 for tapes of at least 4 bytes: one unconditional (clamped) dword load, no branches
+    __device__ __forceinline__ uint32_t fetch4_wide(int idx) const {
+        int c = bp_med3i(idx, lo, hi);
+        uint32_t dw;
+        __builtin_memcpy(&dw, base + c, 4);
+        // shift by d = idx - c bytes in [-3, 3] without a branch (a divergent one would put a wait after every load)
+        int d = bp_med3i(idx - c, -3, 3);
+        return (uint32_t)((((uint64_t)dw) << 24) >> (uint32_t)(8 * d + 24));
+    }
+    // tapes shorter than one dword: byte reads
+    __device__ __forceinline__ uint32_t fetch4_tiny(int idx) const {
         uint32_t dw = 0;
         for (int u = 0; u < 4; ++u) {
             int pos = idx + u;
@@ -36,6 +55,8 @@ struct ByteWindow {
         }
         return dw;
     }
+    // bytes idx..idx+3 (little-endian); bytes outside the tape come back as garbage
+    __device__ __forceinline__ uint32_t fetch4(int idx) const { return tiny ? fetch4_tiny(idx) : fetch4_wide(idx); }
 };
 
 

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                                         : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
     const uint32_t waves_total = gridDim.x * kBpWaves;
     const uint32_t wave_id = blockIdx.x * kBpWaves + wave_in_block;
+    const bool wide_tapes = kBytes && a_total >= 16 && b_total >= 16;   // 128-bit string loads (bp_window.hpp)
 
     for (uint32_t w = wave_id; w < items_total; w += waves_total) {
         const uint32_t item = items_total - 1 - w;  // heavy classes (many blocks, long texts) first
@@ -159,8 +160,12 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
         int tshift[kBytes ? 4 : 1];
         auto fetch_text = [&](int first) {
             if constexpr (kBytes) {
+                if (wide_tapes) {
+                    tshift[0] = txt.fetch16_raw(first, tnxt);   // [0] = distance the clamp moved the window
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4_raw(first + q * 4, tshift[q]);
+                    for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4_raw(first + q * 4, tshift[q]);
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) tnxt[q] = txt.fetch(first + q);
@@ -174,8 +179,17 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
             // latency per item instead of one per word
             uint32_t praw[8];
             int pshift[8];
+            if (wide_tapes) {
+                uint32_t half[2][4];
+                const int moved0 = pat.fetch16_raw((int)row0, half[0]), moved1 = pat.fetch16_raw((int)row0 + 16, half[1]);
+                pat.fix16((int)row0, moved0, half[0]);
+                pat.fix16((int)row0 + 16, moved1, half[1]);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) praw[q] = pat.fetch4_raw((int)row0 + q * 4, pshift[q]);
+                for (int q = 0; q < 8; ++q) { praw[q] = half[q >> 2][q & 3]; pshift[q] = 24; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) praw[q] = pat.fetch4_raw((int)row0 + q * 4, pshift[q]);
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (brows > (uint32_t)q * 4) {
@@ -208,10 +222,18 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
         uint32_t pv = 0xFFFFFFFFu, mv = 0, ph = 0, mh = 0;
         for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
             uint32_t tcur[kTextRegs];
+            if constexpr (kBytes) {
+                if (wide_tapes) {
 #pragma unroll
-            for (int q = 0; q < kTextRegs; ++q) {
-                if constexpr (kBytes) tcur[q] = ByteWindow::realign(tnxt[q], tshift[q]);
-                else tcur[q] = tnxt[q];
+                    for (int q = 0; q < 4; ++q) tcur[q] = tnxt[q];
+                    txt.fix16((int)s0 - (int)blk, tshift[0], tcur);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tcur[q] = ByteWindow::realign(tnxt[q], tshift[q]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < kTextRegs; ++q) tcur[q] = tnxt[q];
             }
             if (s0 + 16 < steps) fetch_text((int)s0 + 16 - (int)blk);
 #pragma unroll

@@ -46,6 +46,24 @@ struct ByteWindow {
         int d = bp_med3i(idx - c, -3, 3);
         return (uint32_t)((((uint64_t)dw) << 24) >> (uint32_t)(8 * d + 24));
     }
+    // Sixteen bytes idx..idx+15 with ONE (unaligned, clamped) 128-bit load: the texture-address unit handles a
+    // wave's scattered loads one instruction x one cache line at a time, so a lane that wants 16 consecutive bytes
+    // should ask for them once rather than as four dwords. Only for tapes of at least 16 bytes. Returns how far the
+    // clamp moved the window (0 for every window that lies inside the tape); `fix16` repairs the rare moved ones.
+    __device__ __forceinline__ int fetch16_raw(int idx, uint32_t (&out)[4]) const {
+        int hi16 = avail - 16;
+        int c = bp_med3i(idx, lo, hi16);
+        uint4 v;
+        __builtin_memcpy(&v, base + c, 16);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        return idx - c;
+    }
+    __device__ __forceinline__ void fix16(int idx, int moved, uint32_t (&out)[4]) const {
+        if (__builtin_expect(moved != 0, 0)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[q] = fetch4_wide(idx + q * 4);
+        }
+    }
     // tapes shorter than one dword: byte reads
     __device__ __forceinline__ uint32_t fetch4_tiny(int idx) const {
         uint32_t dw = 0;

@@ -81,11 +81,14 @@ __device__ __forceinline__ uint32_t bp_table_lookup(const uint32_t *table, int l
     }
 }
 
-template <typename Sym>
-__global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel(KernelArgs args) {
+// kWide: byte tapes of at least 16 bytes each, read with 128-bit loads (bp_window.hpp). A compile-time switch, because
+// a run-time one inside the loops makes the two variants' registers merge right after the loads, i.e. puts a full
+// memory wait next to every prefetch.
+template <typename Sym, bool kWide>
+__device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const uint64_t a_total, const uint64_t b_total) {
     constexpr int kBpWaves = BpTraits<Sym>::kWaves, kBpTableWords = bp_table_words<Sym>();
     constexpr bool kBytes = sizeof(Sym) == 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool wide_tapes = kWide;
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     uint32_t *table = (uint32_t *)smem + (size_t)wave_in_block * kBpTableWords;  // [entries][64 lanes]
@@ -111,13 +114,8 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
     __syncthreads();
     const uint32_t items_total = item_prefix[64];
     const uint32_t my_prefix = item_prefix[lane];
-    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
-                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
-    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
-                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
     const uint32_t waves_total = gridDim.x * kBpWaves;
     const uint32_t wave_id = blockIdx.x * kBpWaves + wave_in_block;
-    const bool wide_tapes = kBytes && a_total >= 16 && b_total >= 16;   // 128-bit string loads (bp_window.hpp)
 
     for (uint32_t w = wave_id; w < items_total; w += waves_total) {
         const uint32_t item = items_total - 1 - w;  // heavy classes (many blocks, long texts) first
@@ -235,7 +233,9 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
 #pragma unroll
                 for (int q = 0; q < kTextRegs; ++q) tcur[q] = tnxt[q];
             }
-            if (s0 + 16 < steps) fetch_text((int)s0 + 16 - (int)blk);
+            // unconditional: clamped addresses are always readable, and a branch around the loads would make the
+            // compiler wait for them right there (their registers merge with the skipped path's)
+            fetch_text((int)s0 + 16 - (int)blk);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (s0 + q * 4 >= n_eff) break;  // wave-uniform: no lane has a symbol left in this group
@@ -286,6 +286,21 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
 #pragma unroll
         for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
         wave_lds_fence();
+    }
+}
+
+template <typename Sym>
+__global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel(KernelArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
+                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
+    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
+                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
+    if constexpr (sizeof(Sym) == 1) {
+        if (a_total >= 16 && b_total >= 16) bp_run<Sym, true>(args, smem, a_total, b_total);
+        else bp_run<Sym, false>(args, smem, a_total, b_total);
+    } else {
+        bp_run<Sym, false>(args, smem, a_total, b_total);
     }
 }
 

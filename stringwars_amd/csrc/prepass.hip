@@ -89,6 +89,9 @@ __device__ __forceinline__ PairInfo pair_info(const PrepassArgs &args, uint64_t 
 
 template <typename Off>
 __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
+    // The planning kernels of one pipeline lane run in the shadow of the other lane's bit-parallel kernel, which owns
+    // most wave slots and LDS; issue priority lets these short kernels through instead of trickling behind it.
+    __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t lhist[kKeys];
     __shared__ unsigned long long lcells, lsyms;
     __shared__ uint32_t lmaxa, lmaxb, lshorts;
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
 // work-unit sums into the plan and re-zeroes the histogram for the next call (no memsets per call).
 __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cursor, Plan *plan,
                                                     const PlanPartial *partials, uint32_t npartials) {
+    __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t partial[1024];
     __shared__ unsigned long long rcells[1024], rsyms[1024];
     __shared__ uint32_t rmaxa[1024], rmaxb[1024], rshort[1024];
@@ -207,8 +211,10 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
 constexpr int kScatterTile = 2048;  // pairs per block iteration (8 per thread)
 template <typename Off>
 __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
+    __builtin_amdgcn_s_setprio(3);
+    // One counter array, reused as the keys' output bases: 24.6 KB, so that a block of this kernel still fits next to
+    // the four resident bit-parallel blocks of the scope's other pipeline lane (136 KB of a CU's 160 KB).
     __shared__ uint32_t lcount[kKeys];
-    __shared__ uint32_t lbase[kKeys];
     constexpr int kPerThread = kScatterTile / 256;
     // nothing left to sort when every pair was finished by the planning pass or the direct kernel
     if (args.plan->class_count[kClassTrivial] == args.plan->class_start[kMaxClasses]) return;
@@ -230,13 +236,15 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < kKeys; i += blockDim.x)
-            if (lcount[i]) lbase[i] = atomicAdd(&args.cursor[i], lcount[i]);
+        for (int i = threadIdx.x; i < kKeys; i += blockDim.x) {
+            const uint32_t c = lcount[i];
+            if (c) lcount[i] = atomicAdd(&args.cursor[i], c);   // count -> base of this tile's run of key i
+        }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             uint64_t p = tile * kScatterTile + (uint64_t)k * 256 + threadIdx.x;
-            if (keys[k] != 0xFFFFFFFFu) args.perm[lbase[keys[k]] + ranks[k]] = (uint32_t)p;
+            if (keys[k] != 0xFFFFFFFFu) args.perm[lcount[keys[k]] + ranks[k]] = (uint32_t)p;
         }
         __syncthreads();
     }

@@ -81,6 +81,27 @@ __device__ __forceinline__ uint32_t bp_table_lookup(const uint32_t *table, int l
     }
 }
 
+#ifdef SWH_BP_PROFILE
+// Diagnostic build only (make EXTRA=-DSWH_BP_PROFILE): summed wave cycles per phase of k_bitparallel.
+__device__ unsigned long long g_bp_phase[10];
+extern "C" void swh_debug_bp_phases(unsigned long long *out) {
+    unsigned long long zero[10] = {};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bp_phase), sizeof(zero));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bp_phase), zero, sizeof(zero));
+}
+#define BP_STAMP(slot, waitmem)                                                          \
+    do {                                                                                 \
+        if (waitmem) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        unsigned long long now__ = __builtin_readcyclecounter();                         \
+        phase_acc[slot] += now__ - phase_t;                                              \
+        phase_t = now__;                                                                 \
+    } while (0)
+#else
+#define BP_STAMP(slot, waitmem) do {} while (0)
+#endif
+
 // kWide: byte tapes of at least 16 bytes each, read with 128-bit loads (bp_window.hpp). A compile-time switch, because
 // a run-time one inside the loops makes the two variants' registers merge right after the loads, i.e. puts a full
 // memory wait next to every prefetch.
@@ -116,6 +137,11 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
     const uint32_t my_prefix = item_prefix[lane];
     const uint32_t waves_total = gridDim.x * kBpWaves;
     const uint32_t wave_id = blockIdx.x * kBpWaves + wave_in_block;
+#ifdef SWH_BP_PROFILE
+    unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_t = __builtin_readcyclecounter();
+    const unsigned long long phase_t0 = phase_t;
+    unsigned long long my_items = 0;
+#endif
 
     for (uint32_t w = wave_id; w < items_total; w += waves_total) {
         const uint32_t item = items_total - 1 - w;  // heavy classes (many blocks, long texts) first
@@ -136,6 +162,7 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
             if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
             else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
         }
+        BP_STAMP(0, true);   // locate + perm + extents
         // pattern = rows / bits / lanes, text = columns / steps: the cheaper of the two assignments (common.hpp)
         const bool a_is_pattern = bp_pattern_is_a(la, lb);
         const uint32_t m = a_is_pattern ? la : lb, n = a_is_pattern ? lb : la;
@@ -204,8 +231,9 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
         }
         acc[lane] = 0;
         wave_lds_fence();  // acc slots are accumulated into by other lanes below
+        BP_STAMP(1, true);   // string loads + table build
 
-        // wave-uniform step count
+        // wave-uniform step count (lane `blk` of a pair works in steps blk .. n + blk - 1)
         uint32_t n_eff = have ? n + G - 1 : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -214,10 +242,33 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
         }
         const uint32_t steps = (n_eff + 15) & ~15u;
 
-        // lanes that start a pair take the DP boundary (+1 horizontal delta) instead of a neighbour
+        // Lanes that start a pair take the DP boundary (+1 horizontal delta) instead of a neighbour. The masks are
+        // made opaque so that the splice stays two plain bitwise ops (v_bitop3 / v_and issue in ~2.7 cycles); knowing
+        // where they come from, the compiler turns it into two v_cndmask_e64 (4.4 cycles each and an SGPR-pair read).
         const bool first_blk = blk == 0;
-        const uint32_t keep_mask = first_blk ? 0u : 0xFFFFFFFFu, first_ph = first_blk ? 0x80000000u : 0u;
+        uint32_t keep_mask = first_blk ? 0u : 0xFFFFFFFFu, first_ph = first_blk ? 0x80000000u : 0u;
+        asm volatile("" : "+v"(keep_mask), "+v"(first_ph));
         uint32_t pv = 0xFFFFFFFFu, mv = 0, ph = 0, mh = 0;
+        // One DP column of this lane's block. (A variant without the per-lane range test for groups in which every lane
+        // works was measured: fewer VALU instructions, slower kernel -- the test rides on the scalar unit for free.)
+        auto column = [&](uint32_t eq, uint32_t s) {
+            // bound_ctrl: lane 0 (no source lane) reads 0, so no `old` register has to be re-materialised per step
+            uint32_t ph_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ph, 0x138, 0xf, 0xf, true);
+            uint32_t mh_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x138, 0xf, 0xf, true);
+            ph_in = (uint32_t)__builtin_amdgcn_bitop3_b32((int)ph_in, (int)keep_mask, (int)first_ph, 0xEA);  // (a & b) | c
+            mh_in = mh_in & keep_mask;
+            if (s - blk < n) {
+                uint32_t xv = eq | mv;
+                eq |= mh_in >> 31;
+                uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                ph = mv | ~(xh | pv);
+                mh = pv & xh;
+                uint32_t ph_s = __builtin_amdgcn_alignbit(ph, ph_in, 31);  // (ph << 1) | hin(+1)
+                uint32_t mh_s = __builtin_amdgcn_alignbit(mh, mh_in, 31);  // (mh << 1) | hin(-1)
+                pv = mh_s | ~(xv | ph_s);
+                mv = ph_s & xv;
+            }
+        };
         for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
             uint32_t tcur[kTextRegs];
             if constexpr (kBytes) {
@@ -238,7 +289,8 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
             fetch_text((int)s0 + 16 - (int)blk);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (s0 + q * 4 >= n_eff) break;  // wave-uniform: no lane has a symbol left in this group
+                const uint32_t gs = s0 + q * 4;
+                if (gs >= n_eff) break;  // wave-uniform: no lane has a symbol left in this group
                 uint32_t eqs[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -248,31 +300,11 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
                     eqs[u] = bp_table_lookup<Sym>(table, lane, c);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t s = s0 + q * 4 + u;
-                    // bound_ctrl: lane 0 (no source lane) reads 0, so no `old` register has to be re-materialised per
-                    // step; the per-lane masks then splice in the DP boundary for lanes that start a pair. Both
-                    // splices are plain bitwise ops (v_bitop3 / v_and issue at full rate, v_cndmask_e64 does not).
-                    uint32_t ph_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ph, 0x138, 0xf, 0xf, true);
-                    uint32_t mh_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x138, 0xf, 0xf, true);
-                    ph_in = (ph_in & keep_mask) | first_ph;
-                    mh_in = mh_in & keep_mask;
-                    if (s - blk < n) {
-                        uint32_t eq = eqs[u];
-                        uint32_t xv = eq | mv;
-                        eq |= mh_in >> 31;
-                        uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-                        ph = mv | ~(xh | pv);
-                        mh = pv & xh;
-                        uint32_t ph_s = __builtin_amdgcn_alignbit(ph, ph_in, 31);  // (ph << 1) | hin(+1)
-                        uint32_t mh_s = __builtin_amdgcn_alignbit(mh, mh_in, 31);  // (mh << 1) | hin(-1)
-                        pv = mh_s | ~(xv | ph_s);
-                        mv = ph_s & xv;
-                    }
-                }
+                for (int u = 0; u < 4; ++u) column(eqs[u], gs + u);
             }
         }
 
+        BP_STAMP(2, false);   // DP steps
         // ---- distance = n + sum over blocks popcount(pv) - popcount(mv) -------------------------
         const uint32_t mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
         int part = __popc(pv & mask) - __popc(mv & mask);
@@ -286,7 +318,19 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
 #pragma unroll
         for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
         wave_lds_fence();
+        BP_STAMP(3, true);   // result + clear
+#ifdef SWH_BP_PROFILE
+        ++my_items;
+#endif
     }
+#ifdef SWH_BP_PROFILE
+    if (lane == 0) {
+        for (int k = 0; k < 4; ++k) atomicAdd(&g_bp_phase[k], phase_acc[k]);
+        atomicAdd(&g_bp_phase[4], __builtin_readcyclecounter() - phase_t0);
+        atomicAdd(&g_bp_phase[5], 1ull);
+        atomicAdd(&g_bp_phase[6], my_items);
+    }
+#endif
 }
 
 template <typename Sym>

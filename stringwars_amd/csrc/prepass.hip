@@ -250,9 +250,134 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
     }
 }
 
-// One pair per lane in tape order; both strings <= 32 bytes. All string loads (8 + 8 dwords) are issued before
-// anything depends on them, so an iteration exposes one memory latency, and 8 KB of LDS per wave leaves 16 waves
-// per CU to hide it. The recurrence is the single-block case of bitparallel.hip (no systolic hand-off).
+// One pair per lane in tape order; both strings <= 32 bytes. The recurrence is the single-block case of
+// bitparallel.hip (no systolic hand-off): the longer string is the pattern (a table update per byte is cheaper than a
+// DP column per byte). Memory is software-pipelined two rounds deep: while round r computes, the strings of round
+// r + 1 (two 128-bit loads per string) and the extents of round r + 2 are in flight, so a round never waits for a
+// full memory latency; 8 KB of LDS per wave leaves 16 waves per CU on top of that.
+// kWide: both tapes hold at least 16 bytes (128-bit loads, bp_window.hpp); compile-time for the reason given there.
+template <typename Off, bool kWide>
+__device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32_t *table, const uint64_t a_total,
+                                                 const uint64_t b_total) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (args.job.pairs + stride - 1) / stride;  // wave-uniform trip count
+    const uint64_t lane_first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    struct Short { bool direct; uint64_t p; uint32_t m, n; ByteWindow pat, txt; };
+    struct Words { uint32_t pw[8], tw[8]; int moved[4]; };
+    auto open_pair = [&](uint64_t round) -> Short {
+        Short sp;
+        sp.p = round * stride + lane_first;
+        PairInfo info{};
+        info.trivial = true;
+        const bool inside = round < rounds && sp.p < args.job.pairs;
+        if (inside) info = pair_info<Off>(args, sp.p, args.gap_open, args.gap_extend, true);
+        sp.direct = inside && short_pair(info);
+        const bool a_is_pattern = info.la >= info.lb;
+        sp.m = sp.direct ? (a_is_pattern ? info.la : info.lb) : 0;
+        sp.n = sp.direct ? (a_is_pattern ? info.lb : info.la) : 0;
+        sp.pat.init((const uint8_t *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? info.a0 : info.b0,
+                    a_is_pattern ? a_total : b_total);
+        sp.txt.init((const uint8_t *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? info.b0 : info.a0,
+                    a_is_pattern ? b_total : a_total);
+        return sp;
+    };
+    auto request = [&](const Short &sp, Words &w) {
+        if constexpr (kWide) {
+            uint32_t half[4];
+            w.moved[0] = sp.pat.fetch16_raw(0, half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w.pw[q] = half[q];
+            w.moved[1] = sp.pat.fetch16_raw(16, half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w.pw[4 + q] = half[q];
+            w.moved[2] = sp.txt.fetch16_raw(0, half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w.tw[q] = half[q];
+            w.moved[3] = sp.txt.fetch16_raw(16, half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w.tw[4 + q] = half[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { w.pw[q] = sp.pat.fetch4(q * 4); w.tw[q] = sp.txt.fetch4(q * 4); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w.moved[q] = 0;
+        }
+    };
+    Short cur = open_pair(0);
+    Words words;
+    request(cur, words);
+    Short next = open_pair(1);
+    for (uint64_t round = 0; round < rounds; ++round) {
+        Words words_next;
+        request(next, words_next);
+        const Short next2 = open_pair(round + 2);
+        if (__any(cur.direct)) {
+            const uint32_t m = cur.m, n = cur.n;
+            uint32_t m_max = m, n_max = n;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                uint32_t om = __shfl_xor(m_max, off), on = __shfl_xor(n_max, off);
+                m_max = om > m_max ? om : m_max;
+                n_max = on > n_max ? on : n_max;
+            }
+            if constexpr (kWide) {   // windows the clamp had to move (first / last strings of a tape): re-read by dword
+                uint32_t half[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    uint32_t *dst = h < 2 ? words.pw + 4 * h : words.tw + 4 * (h - 2);
+                    if (__builtin_expect(words.moved[h] != 0, 0)) {
+                        (h < 2 ? cur.pat : cur.txt).fix16(16 * (h & 1), words.moved[h], half);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[q] = half[q];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if ((uint32_t)q * 4 >= m_max) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if ((uint32_t)(q * 4 + r) < m) {
+                        const uint32_t c = (words.pw[q] >> (8 * r)) & 0xffu, bit = 1u << (q * 4 + r);
+                        atomicOr(&table[(c & 15u) * 64 + lane], bit);
+                        atomicOr(&table[(16 + (c >> 4)) * 64 + lane], bit);
+                    }
+                }
+            }
+            uint32_t pv = 0xFFFFFFFFu, mv = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if ((uint32_t)q * 4 >= n_max) break;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t c = (words.tw[q] >> (8 * u)) & 0xffu;
+                    if ((uint32_t)(q * 4 + u) < n) {
+                        const uint32_t eq = table[(c & 15u) * 64 + lane] & table[(16 + (c >> 4)) * 64 + lane];
+                        const uint32_t xv = eq | mv;
+                        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                        uint32_t ph = mv | ~(xh | pv);
+                        const uint32_t mh = pv & xh;
+                        ph = (ph << 1) | 1u;
+                        pv = (mh << 1) | ~(xv | ph);
+                        mv = ph & xv;
+                    }
+                }
+            }
+            if (cur.direct) {
+                const uint32_t mask = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u);
+                const uint32_t d = n + __popc(pv & mask) - __popc(mv & mask);
+                store_result(args.job, cur.p, (int64_t)clamp_bound(d, args.job.bound));
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) table[k * 64 + lane] = 0;
+        }
+        cur = next;
+        words = words_next;
+        next = next2;
+    }
+}
+
 template <typename Off>
 __global__ __launch_bounds__(256, 4) void k_direct_short(PrepassArgs args) {
     __shared__ uint32_t ltable[4][32 * 64];  // per wave: EqLo[16][64] | EqHi[16][64]
@@ -261,74 +386,8 @@ __global__ __launch_bounds__(256, 4) void k_direct_short(PrepassArgs args) {
     for (int k = 0; k < 32; ++k) table[k * 64 + lane] = 0;
     const uint64_t a_total = (uint64_t)((const Off *)args.job.a.offsets)[args.job.a.count];
     const uint64_t b_total = (uint64_t)((const Off *)args.job.b.offsets)[args.job.b.count];
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t rounds = (args.job.pairs + stride - 1) / stride;  // wave-uniform trip count
-    for (uint64_t round = 0; round < rounds; ++round) {
-        const uint64_t p = round * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        PairInfo info{};
-        info.trivial = true;
-        if (p < args.job.pairs) info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, true);
-        const bool direct = p < args.job.pairs && short_pair(info);
-        if (!__any(direct)) continue;
-        const bool a_is_pattern = info.la <= info.lb;
-        const uint32_t m = direct ? (a_is_pattern ? info.la : info.lb) : 0, n = direct ? (a_is_pattern ? info.lb : info.la) : 0;
-        ByteWindow pat, txt;
-        pat.init((const uint8_t *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? info.a0 : info.b0,
-                 a_is_pattern ? a_total : b_total);
-        txt.init((const uint8_t *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? info.b0 : info.a0,
-                 a_is_pattern ? b_total : a_total);
-        uint32_t m_max = m, n_max = n;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            uint32_t om = __shfl_xor(m_max, off), on = __shfl_xor(n_max, off);
-            m_max = om > m_max ? om : m_max;
-            n_max = on > n_max ? on : n_max;
-        }
-        uint32_t pw[8], tw[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            pw[q] = (uint32_t)q * 4 < m_max ? pat.fetch4(q * 4) : 0;
-            tw[q] = (uint32_t)q * 4 < n_max ? txt.fetch4(q * 4) : 0;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if ((uint32_t)q * 4 >= m_max) break;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((uint32_t)(q * 4 + r) < m) {
-                    const uint32_t c = (pw[q] >> (8 * r)) & 0xffu, bit = 1u << (q * 4 + r);
-                    atomicOr(&table[(c & 15u) * 64 + lane], bit);
-                    atomicOr(&table[(16 + (c >> 4)) * 64 + lane], bit);
-                }
-            }
-        }
-        uint32_t pv = 0xFFFFFFFFu, mv = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if ((uint32_t)q * 4 >= n_max) break;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t c = (tw[q] >> (8 * u)) & 0xffu;
-                if ((uint32_t)(q * 4 + u) < n) {
-                    const uint32_t eq = table[(c & 15u) * 64 + lane] & table[(16 + (c >> 4)) * 64 + lane];
-                    const uint32_t xv = eq | mv;
-                    const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-                    uint32_t ph = mv | ~(xh | pv);
-                    const uint32_t mh = pv & xh;
-                    ph = (ph << 1) | 1u;
-                    pv = (mh << 1) | ~(xv | ph);
-                    mv = ph & xv;
-                }
-            }
-        }
-        if (direct) {
-            const uint32_t mask = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u);
-            const uint32_t d = n + __popc(pv & mask) - __popc(mv & mask);
-            store_result(args.job, p, (int64_t)clamp_bound(d, args.job.bound));
-        }
-#pragma unroll
-        for (int k = 0; k < 32; ++k) table[k * 64 + lane] = 0;
-    }
+    if (a_total >= 16 && b_total >= 16) direct_short_run<Off, true>(args, table, a_total, b_total);
+    else direct_short_run<Off, false>(args, table, a_total, b_total);
 }
 
 void launch_prepass(Scope *scope, const PrepassArgs &args_in) {

@@ -85,8 +85,9 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
 
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
 static size_t utf8_scratch_words(uint64_t bytes) {
-    uint64_t tiles = (bytes + 1023) / 1024;
-    return (size_t)((tiles + 4) + (4 * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4) + (tiles + 4));
+    // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances
+    uint64_t tiles = (bytes + kUtf8Tile - 1) / kUtf8Tile;
+    return (size_t)((tiles + 4) + (kUtf8Subs * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4) + (tiles + 4));
 }
 
 static bool is_device_pointer(const void *p) {

@@ -232,6 +232,9 @@ void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs);
 int wavefront_strip_cap();
 
 // UTF-8 staging: decodes a byte tape into u32 code points + u64 code-point offsets.
+constexpr int kUtf8Pass = 1024, kUtf8Passes = 8;     // a block walks its tile in passes of 256 threads x one dword
+constexpr int kUtf8Tile = kUtf8Pass * kUtf8Passes;   // bytes per block
+constexpr int kUtf8Subs = kUtf8Tile / 256;           // 256-byte sub-tiles per tile
 struct Utf8Args {
     TapeRef in; uint32_t off64;
     uint32_t *symbols;     // out, capacity = total bytes

@@ -429,7 +429,7 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
 
 // ------------------------------------------------------------------------------------------------
 // UTF-8 staging, flat over the tape bytes (independent of how long the strings are):
-//   k_utf8_tile_count : lead bytes (everything but 10xxxxxx) per 1 KB tile and per 256 B sub-tile
+//   k_utf8_tile_count : lead bytes (everything but 10xxxxxx) per 8 KB tile and per 256 B sub-tile
 //   scan              : exclusive prefix of the tile counts = code-point index of each tile
 //   k_utf8_tile_write : every lead byte decodes its sequence to symbols[prefix + rank]; strict validation
 //                       (RFC 3629 / Rust `str`: no overlongs, no surrogates, <= U+10FFFF, no stray
@@ -439,10 +439,14 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
 //                       is what catches sequences straddling two strings.
 // All loads are coalesced dwords; nothing loops over a string.
 // ------------------------------------------------------------------------------------------------
-constexpr int kUtf8Tile = 1024;  // bytes per block (256 threads x 4 bytes)
+// A block walks its tile in passes of 1 KB (256 threads x one dword, coalesced); sub-tiles of 256 B (one wave of one
+// pass) keep the per-string work in k_utf8_string_offsets short. With one pass per block the launch rate of 50K+
+// tiny blocks, not memory, set the pace (0.9 TB/s on the count kernel).
+// (kUtf8Pass, kUtf8Passes, kUtf8Tile, kUtf8Subs: common.hpp)
 
 __device__ __forceinline__ uint32_t load_tape_dword(const uint8_t *data, int64_t pos, int64_t total) {
-    // bytes pos..pos+3, zero where outside [0, total)
+    // bytes pos..pos+3, zero where outside [0, total). (A branch-free clamp-shift-mask form was measured: these
+    // kernels are instruction-bound, and its 64-bit shifts cost more than the branch.)
     if (pos >= 0 && pos + 4 <= total) { uint32_t dw; __builtin_memcpy(&dw, data + pos, 4); return dw; }
     uint32_t dw = 0;
     for (int u = 0; u < 4; ++u) {
@@ -463,19 +467,29 @@ __device__ __forceinline__ uint32_t lead_mask4(uint32_t dw, int valid) {
 
 __global__ __launch_bounds__(256) void k_utf8_tile_count(const uint8_t *data, uint64_t total, uint32_t *tile_counts,
                                                          uint32_t *sub_prefix) {
-    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t wave_sum[kUtf8Passes][4];
     const uint64_t tile = blockIdx.x;
-    const int64_t pos = (int64_t)(tile * kUtf8Tile + threadIdx.x * 4);
-    int valid = (int64_t)total - pos >= 4 ? 4 : ((int64_t)total > pos ? (int)((int64_t)total - pos) : 0);
-    uint32_t dw = valid ? load_tape_dword(data, pos, (int64_t)total) : 0;
-    uint32_t cnt = __popc(lead_mask4(dw, valid));
+    const int64_t tot = (int64_t)total;
+    uint32_t dws[kUtf8Passes];
+    int valids[kUtf8Passes];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = cnt;
+    for (int q = 0; q < kUtf8Passes; ++q) {   // all loads first: one memory latency per block
+        const int64_t pos = (int64_t)(tile * kUtf8Tile + q * kUtf8Pass + threadIdx.x * 4);
+        valids[q] = tot - pos >= 4 ? 4 : (tot > pos ? (int)(tot - pos) : 0);
+        dws[q] = valids[q] ? load_tape_dword(data, pos, tot) : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < kUtf8Passes; ++q) {
+        uint32_t cnt = __popc(lead_mask4(dws[q], valids[q]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if ((threadIdx.x & 63) == 0) wave_sum[q][threadIdx.x >> 6] = cnt;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int w = 0; w < 4; ++w) { sub_prefix[tile * 4 + w] = run; run += wave_sum[w]; }
+        for (int q = 0; q < kUtf8Passes; ++q)
+            for (int w = 0; w < 4; ++w) { sub_prefix[tile * kUtf8Subs + q * 4 + w] = run; run += wave_sum[q][w]; }
         tile_counts[tile] = run;
     }
 }
@@ -487,68 +501,102 @@ __global__ __launch_bounds__(256) void k_utf8_tile_count(const uint8_t *data, ui
 // means every continuation byte is claimed exactly once.
 __global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, uint64_t total, const uint64_t *tile_prefix,
                                                          uint32_t *symbols, uint32_t *invalid, int *balance) {
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t wave_tot[kUtf8Passes][4];
     __shared__ int wave_bal[4];
+    // Code points of a pass are collected in rank order in LDS and leave as full 256-byte rows per wave; written
+    // straight from the decoding lanes (up to four stores each, 16 bytes apart) every cache line was touched by four
+    // store instructions and the kernel ran at a fifth of the memory rate. Two buffers: one barrier per pass.
+    __shared__ uint32_t stage[2][kUtf8Pass];
     const uint64_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t pos = (int64_t)(tile * kUtf8Tile + threadIdx.x * 4);
     const int64_t tot = (int64_t)total;
-    const int valid = tot - pos >= 4 ? 4 : (tot > pos ? (int)(tot - pos) : 0);
-    const uint32_t cur = valid ? load_tape_dword(data, pos, tot) : 0;
-    const bool ascii = (cur & 0x80808080u) == 0;
-    const uint32_t next = (valid && !ascii) ? load_tape_dword(data, pos + 4, tot) : 0;
-    const uint32_t leads = lead_mask4(cur, valid);
-    const uint32_t mine = __popc(leads);
-    uint32_t incl = mine;
+    // all loads first (the word after mine is somebody's `cur`, so it comes out of the cache)
+    uint32_t curs[kUtf8Passes], nexts[kUtf8Passes];
+    int valids[kUtf8Passes];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
+    for (int q = 0; q < kUtf8Passes; ++q) {
+        const int64_t pos = (int64_t)(tile * kUtf8Tile + q * kUtf8Pass + threadIdx.x * 4);
+        valids[q] = tot - pos >= 4 ? 4 : (tot > pos ? (int)(tot - pos) : 0);
+        curs[q] = valids[q] ? load_tape_dword(data, pos, tot) : 0;
+        nexts[q] = valids[q] ? load_tape_dword(data, pos + 4, tot) : 0;
     }
-    if (lane == 63) wave_tot[wave] = incl;
-    // per-thread decode
+    uint32_t incls[kUtf8Passes];
+#pragma unroll
+    for (int q = 0; q < kUtf8Passes; ++q) {
+        uint32_t incl = __popc(lead_mask4(curs[q], valids[q]));
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        incls[q] = incl;
+        if (lane == 63) wave_tot[q][wave] = incl;
+    }
+    __syncthreads();
     int bal = 0;  // expected continuation bytes of my leads minus continuation bytes I hold
     bool bad = false;
-    uint32_t cps[4] = {0, 0, 0, 0};
-    if (ascii) {
+    int64_t bad_pos = 0;
+    uint64_t pass_base = tile_prefix[tile];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cps[u] = (cur >> (8 * u)) & 0xffu;
-    } else {
-        const unsigned long long w64 = (unsigned long long)cur | ((unsigned long long)next << 32);
-        bal = -(valid - (int)mine);
+    for (int q = 0; q < kUtf8Passes; ++q) {
+        const int64_t pos = (int64_t)(tile * kUtf8Tile + q * kUtf8Pass + threadIdx.x * 4);
+        const uint32_t cur = curs[q], next = nexts[q];
+        const int valid = valids[q];
+        const bool ascii = (cur & 0x80808080u) == 0;
+        const uint32_t leads = lead_mask4(cur, valid);
+        const uint32_t mine = __popc(leads);
+        uint32_t cps[4] = {0, 0, 0, 0};
+        bool bad_here = false;
+        if (ascii) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (!(leads & (1u << u))) continue;
-            const uint32_t seq = (uint32_t)(w64 >> (8 * u));
-            const uint32_t c = seq & 0xffu, b1 = (seq >> 8) & 0xffu, b2 = (seq >> 16) & 0xffu, b3 = seq >> 24;
-            uint32_t cp = c;
-            if (c >= 0x80u) {
-                const int need = c >= 0xF0u ? 3 : (c >= 0xE0u ? 2 : 1);
-                bad |= c < 0xC2u || c > 0xF4u;
-                bad |= pos + u + need >= tot;
-                bad |= (b1 & 0xC0u) != 0x80u;
-                cp = need == 1 ? (c & 0x1Fu) : (need == 2 ? (c & 0x0Fu) : (c & 0x07u));
-                cp = (cp << 6) | (b1 & 0x3Fu);
-                if (need >= 2) { bad |= (b2 & 0xC0u) != 0x80u; cp = (cp << 6) | (b2 & 0x3Fu); }
-                if (need == 3) { bad |= (b3 & 0xC0u) != 0x80u; cp = (cp << 6) | (b3 & 0x3Fu); }
-                bad |= need == 2 && (cp < 0x800u || (cp >= 0xD800u && cp <= 0xDFFFu));
-                bad |= need == 3 && (cp < 0x10000u || cp > 0x10FFFFu);
-                bal += need;
+            for (int u = 0; u < 4; ++u) cps[u] = (cur >> (8 * u)) & 0xffu;
+        } else {
+            const unsigned long long w64 = (unsigned long long)cur | ((unsigned long long)next << 32);
+            bal -= valid - (int)mine;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!(leads & (1u << u))) continue;
+                const uint32_t seq = (uint32_t)(w64 >> (8 * u));
+                const uint32_t c = seq & 0xffu, b1 = (seq >> 8) & 0xffu, b2 = (seq >> 16) & 0xffu, b3 = seq >> 24;
+                uint32_t cp = c;
+                if (c >= 0x80u) {
+                    const int need = c >= 0xF0u ? 3 : (c >= 0xE0u ? 2 : 1);
+                    bad_here |= c < 0xC2u || c > 0xF4u;
+                    bad_here |= pos + u + need >= tot;
+                    bad_here |= (b1 & 0xC0u) != 0x80u;
+                    cp = need == 1 ? (c & 0x1Fu) : (need == 2 ? (c & 0x0Fu) : (c & 0x07u));
+                    cp = (cp << 6) | (b1 & 0x3Fu);
+                    if (need >= 2) { bad_here |= (b2 & 0xC0u) != 0x80u; cp = (cp << 6) | (b2 & 0x3Fu); }
+                    if (need == 3) { bad_here |= (b3 & 0xC0u) != 0x80u; cp = (cp << 6) | (b3 & 0x3Fu); }
+                    bad_here |= need == 2 && (cp < 0x800u || (cp >= 0xD800u && cp <= 0xDFFFu));
+                    bad_here |= need == 3 && (cp < 0x10000u || cp > 0x10FFFFu);
+                    bal += need;
+                }
+                cps[u] = cp;
             }
-            cps[u] = cp;
         }
+        if (bad_here && !bad) { bad = true; bad_pos = pos; }
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wave_tot[q][w];
+        uint32_t rank = base + incls[q] - mine;   // within the pass
+        uint32_t *buf = stage[q & 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (leads & (1u << u)) buf[rank++] = cps[u];
+        __syncthreads();
+        const uint32_t pass_total = wave_tot[q][0] + wave_tot[q][1] + wave_tot[q][2] + wave_tot[q][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = k * 256 + threadIdx.x;
+            if (i < pass_total) symbols[pass_base + i] = buf[i];
+        }
+        pass_base += pass_total;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) bal += __shfl_xor(bal, off);
     if (lane == 0) wave_bal[wave] = bal;
+    if (bad) atomicCAS(invalid, 0u, (uint32_t)(bad_pos >> 2) + 1u);
     __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wave_tot[w];
-    uint64_t rank = tile_prefix[tile] + base + incl - mine;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (leads & (1u << u)) symbols[rank++] = cps[u];
-    if (bad) atomicCAS(invalid, 0u, (uint32_t)(pos >> 2) + 1u);
     // per-tile balance (sequences straddling a tile edge make it non-zero per tile, zero over the tape);
     // a single hot atomic here serialised ~100K tiles and cost more than the decode itself
     if (threadIdx.x == 0) balance[tile] = wave_bal[0] + wave_bal[1] + wave_bal[2] + wave_bal[3];
@@ -589,7 +637,7 @@ __global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, cons
         int valid = off - q >= 4 ? 4 : (int)(off - q);
         cnt += __popc(lead_mask4(load_tape_dword(data, q, total), valid));
     }
-    args.offsets[i] = tile_prefix[tile] + sub_prefix[tile * 4 + sub] + cnt;
+    args.offsets[i] = tile_prefix[tile] + sub_prefix[tile * kUtf8Subs + sub] + cnt;
     // a non-empty string must start on a sequence boundary
     if (i < args.in.count && (int64_t)offs[i + 1] > off && (data[off] & 0xC0u) == 0x80u)
         atomicCAS(args.invalid, 0u, (uint32_t)i + 1u);
@@ -654,10 +702,10 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
     hipStream_t stream = scope->stream;
     const uint64_t n = args.in.count, total = args.total_bytes;
     const uint64_t tiles = (total + kUtf8Tile - 1) / kUtf8Tile;
-    // scratch carved from `counts`: tile_counts[tiles+1] | sub_prefix[4*tiles] | tile_prefix u64[tiles+1] | block sums
+    // scratch carved from `counts`: tile_counts[tiles+1] | sub_prefix[kUtf8Subs*tiles] | tile_prefix u64[tiles+1] | block sums
     uint32_t *tile_counts = args.counts;
     uint32_t *sub_prefix = tile_counts + ((tiles + 2) & ~1ull);
-    uint64_t *tile_prefix = (uint64_t *)(sub_prefix + 4 * tiles + 2 - ((4 * tiles) & 1));
+    uint64_t *tile_prefix = (uint64_t *)(sub_prefix + kUtf8Subs * tiles + 2 - ((kUtf8Subs * tiles) & 1));
     unsigned long long *block_sums = (unsigned long long *)(tile_prefix + tiles + 2);
     int *tile_balance = (int *)(block_sums + (tiles + 1023) / 1024 + 4);
     if (tiles) {

@@ -131,6 +131,32 @@ def test_random_levenshtein_short(sw, orc, scope, algorithm, alphabet):
     assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
 
 
+@pytest.mark.parametrize("utf8", [False, True])
+def test_small_tapes_and_strings_at_tape_edges(sw, orc, scope, utf8):
+    """Tapes of 0..80 bytes: the kernels read strings with 4- and 16-byte loads clamped into the tape, so every tape
+    size around those widths, with the first and last strings touching the tape's ends, has to come out right --
+    both through the planned kernels and through the direct kernel for short pairs (taken on the second call, once
+    the scope has seen that the batch is mostly short)."""
+    rng = np.random.default_rng(20260101)
+    cls = sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances
+    alphabet = [chr(c) for c in range(0x61, 0x67)] + (["\u00e9", "\u0416", "\u4e2d", "\U0001f600"] if utf8 else [])
+    for total in list(range(0, 40)) + [47, 48, 49, 63, 64, 65, 80]:
+        for trial in range(3):
+            count = int(rng.integers(1, 5))
+            cuts_a = np.sort(rng.integers(0, total + 1, count - 1)) if count > 1 else np.array([], np.int64)
+            cuts_b = np.sort(rng.integers(0, total + 1, count - 1)) if count > 1 else np.array([], np.int64)
+            la = np.diff(np.concatenate([[0], cuts_a, [total]]))
+            lb = np.diff(np.concatenate([[0], cuts_b, [total]]))
+            items_a = ["".join(rng.choice(alphabet, int(n))) for n in la]
+            items_b = ["".join(rng.choice(alphabet, int(n))) for n in lb]
+            a, b = sw.Strs([x.encode("utf-8") for x in items_a]), sw.Strs([x.encode("utf-8") for x in items_b])
+            engine = cls(capabilities=scope)
+            want = orc.levenshtein_pairs(a, b, utf8=utf8)
+            for call in range(2):
+                got = engine.pairs(a, b, scope)
+                assert got.tolist() == want.tolist(), (total, trial, call, items_a, items_b)
+
+
 @pytest.mark.parametrize("algorithm", ALGORITHMS)
 def test_random_levenshtein_long(sw, orc, scope, algorithm):
     rng = np.random.default_rng(7)

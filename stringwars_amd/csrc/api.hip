@@ -222,7 +222,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         Carver pa{scope->plan_area, 0, 0};
         uint32_t *hist = pa.take<uint32_t>(kKeys);
         uint32_t *cursor = pa.take<uint32_t>(kKeys);
-        PlanPartial *partials = pa.take<PlanPartial>(kMaxPartials);
+        PlanPartial *partials = pa.take<PlanPartial>(2 * kMaxPartials);
+        uint32_t *leftover = pa.take<uint32_t>(4);
         Plan *plan_dev = pa.take<Plan>(1);
 
         // -- UTF-8 staging ----------------------------------------------------------------------------
@@ -274,7 +275,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         pre.local = engine->kind == 2 ? 1 : 0;
         pre.direct_short = bitpar_ok && sym_bytes == 1 && engine->algorithm == swh_algorithm_auto_k && scope->hint_short ? 1 : 0;
         pre.banded = pre.unit_costs && spec.bound <= 63 && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
-        pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.plan = plan_dev;
+        pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.leftover = leftover; pre.plan = plan_dev;
         launch_prepass(scope, pre);
 
         KernelArgs k{};
@@ -385,7 +386,7 @@ static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_
         if (borrow) { scope->stream = (hipStream_t)stream; scope->owns_stream = false; }
         else { SWH_HIP_CHECK(hipStreamCreateWithFlags(&scope->stream, hipStreamNonBlocking)); scope->owns_stream = true; }
         SWH_HIP_CHECK(hipHostMalloc((void **)&scope->plan_host, sizeof(Plan) + 64, hipHostMallocDefault));
-        size_t plan_area_bytes = 2 * ((kKeys * 4 + 255) & ~255) + ((kMaxPartials * sizeof(PlanPartial) + 255) & ~255) +
+        size_t plan_area_bytes = 2 * ((kKeys * 4 + 255) & ~255) + ((2 * kMaxPartials * sizeof(PlanPartial) + 255) & ~255) + 256 +
                                  ((sizeof(Plan) + 255) & ~255);
         SWH_HIP_CHECK(hipMalloc((void **)&scope->plan_area, plan_area_bytes));
         SWH_HIP_CHECK(hipMemset(scope->plan_area, 0, plan_area_bytes));

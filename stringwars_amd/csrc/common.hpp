@@ -103,6 +103,7 @@ struct Plan {
 };
 
 struct PlanPartial { unsigned long long cells, symbols; uint32_t max_la, max_lb, short_pairs, pad; };
+// partials[0, kMaxPartials) belong to k_plan_hist, [kMaxPartials, 2 kMaxPartials) to k_direct_short (see PrepassArgs::leftover)
 constexpr int kMaxPartials = 2048;
 
 // Class numbering --------------------------------------------------------------------------------
@@ -211,7 +212,11 @@ struct PrepassArgs {
     uint32_t *perm;         // out: pair ids sorted by key
     uint32_t *hist;         // scratch: kKeys counters
     uint32_t *cursor;       // scratch: kKeys cursors
-    PlanPartial *partials;  // scratch: kMaxPartials per-block work-unit sums
+    PlanPartial *partials;  // scratch: 2 x kMaxPartials per-block work-unit sums
+    // When k_direct_short runs it visits every pair anyway, so it also finishes the trivial pairs, sums the work
+    // units and counts the pairs it could NOT finish here. Zero left over: k_plan_hist and k_plan_scatter return at
+    // once (nothing to plan); k_plan_scan folds the sums and re-zeroes the counter.
+    uint32_t *leftover;
     Plan *plan;             // out (device)
 };
 void launch_prepass(Scope *scope, const PrepassArgs &args);

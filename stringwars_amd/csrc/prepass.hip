@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
     __shared__ uint32_t lhist[kKeys];
     __shared__ unsigned long long lcells, lsyms;
     __shared__ uint32_t lmaxa, lmaxb, lshorts;
+    // k_direct_short has already finished every pair (and summed the work units): nothing to plan
+    if (args.direct_short && *args.leftover == 0) return;
     for (int i = threadIdx.x; i < kKeys; i += blockDim.x) lhist[i] = 0;
     if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; }
     __syncthreads();
@@ -136,8 +138,9 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
         if (lhist[i]) atomicAdd(&args.hist[i], lhist[i]);
     if (threadIdx.x == 0) {
         // per-block partial sums; k_plan_scan folds them (same-address global atomics from every block
-        // serialise in L2 and used to cost more than the whole histogram)
+        // serialise in L2 and used to cost more than the whole histogram). When k_direct_short ran, the sums are its.
         PlanPartial part{lcells, lsyms, lmaxa, lmaxb, lshorts, 0};
+        if (args.direct_short) part = PlanPartial{0, 0, 0, 0, 0, 0};
         args.partials[blockIdx.x] = part;
     }
 }
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
 // One block of 1024 threads; kKeys = 6144 -> 6 keys per thread. Also folds the per-block partial
 // work-unit sums into the plan and re-zeroes the histogram for the next call (no memsets per call).
 __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cursor, Plan *plan,
-                                                    const PlanPartial *partials, uint32_t npartials) {
+                                                    PlanPartial *partials, uint32_t npartials, uint32_t ndirect,
+                                                    uint32_t *leftover) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t partial[1024];
     __shared__ unsigned long long rcells[1024], rsyms[1024];
@@ -162,8 +166,12 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
     partial[threadIdx.x] = sum;
     unsigned long long c = 0, sy = 0;
     uint32_t ma = 0, mb = 0, sh = 0;
-    for (uint32_t i = threadIdx.x; i < npartials; i += 1024) {
-        PlanPartial pp = partials[i];
+    // k_plan_hist's sums (zero when it returned early: its slots are cleared below for that case) and k_direct_short's
+    const bool planned = ndirect == 0 || *leftover != 0;
+    for (uint32_t i = threadIdx.x; i < npartials + ndirect; i += 1024) {
+        const bool from_hist = i < npartials;
+        if (from_hist && !planned) continue;
+        PlanPartial pp = partials[from_hist ? i : kMaxPartials + (i - npartials)];
         c += pp.cells; sy += pp.symbols; sh += pp.short_pairs;
         ma = pp.max_la > ma ? pp.max_la : ma;
         mb = pp.max_lb > mb ? pp.max_lb : mb;
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
     if (threadIdx.x == 0) {
         plan->cells = rcells[0]; plan->symbols = rsyms[0]; plan->max_la = rmaxa[0]; plan->max_lb = rmaxb[0];
         plan->invalid_utf8 = 0; plan->short_pairs = rshort[0];
+        *leftover = 0;   // every reader of this call's value is upstream of this kernel or has read it above
     }
     for (int off = 1; off < 1024; off <<= 1) {
         uint32_t v = (int)threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
@@ -263,7 +272,7 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (args.job.pairs + stride - 1) / stride;  // wave-uniform trip count
     const uint64_t lane_first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    struct Short { bool direct; uint64_t p; uint32_t m, n; ByteWindow pat, txt; };
+    struct Short { bool inside, direct, trivial; uint64_t p; int64_t trivial_value; uint32_t la, lb, m, n; ByteWindow pat, txt; };
     struct Words { uint32_t pw[8], tw[8]; int moved[4]; };
     auto open_pair = [&](uint64_t round) -> Short {
         Short sp;
@@ -272,6 +281,11 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
         info.trivial = true;
         const bool inside = round < rounds && sp.p < args.job.pairs;
         if (inside) info = pair_info<Off>(args, sp.p, args.gap_open, args.gap_extend, true);
+        sp.inside = inside;
+        sp.trivial = inside && info.trivial;
+        sp.trivial_value = info.trivial_value;
+        sp.la = inside ? info.la : 0;
+        sp.lb = inside ? info.lb : 0;
         sp.direct = inside && short_pair(info);
         const bool a_is_pattern = info.la >= info.lb;
         sp.m = sp.direct ? (a_is_pattern ? info.la : info.lb) : 0;
@@ -304,6 +318,9 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
             for (int q = 0; q < 4; ++q) w.moved[q] = 0;
         }
     };
+    // this kernel sees every pair, so it also finishes the trivial ones and sums the work units (PrepassArgs::leftover)
+    unsigned long long cells = 0, syms = 0;
+    uint32_t maxa = 0, maxb = 0, shorts = 0, left = 0;
     Short cur = open_pair(0);
     Words words;
     request(cur, words);
@@ -312,6 +329,20 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
         Words words_next;
         request(next, words_next);
         const Short next2 = open_pair(round + 2);
+        if (cur.inside) {
+            cells += (unsigned long long)cur.la * cur.lb;
+            syms += (unsigned long long)cur.la + cur.lb;
+            maxa = cur.la > maxa ? cur.la : maxa;
+            maxb = cur.lb > maxb ? cur.lb : maxb;
+            shorts += cur.direct ? 1u : 0u;
+            left += (!cur.trivial && !cur.direct) ? 1u : 0u;
+            if (cur.trivial) {
+                // unit costs: distances are stored positive, cut off at bound + 1 (same as k_plan_hist)
+                int64_t v = cur.trivial_value;
+                if (args.job.negate) v = (int64_t)clamp_bound((uint32_t)(-v), args.job.bound);
+                store_result(args.job, cur.p, v);
+            }
+        }
         if (__any(cur.direct)) {
             const uint32_t m = cur.m, n = cur.n;
             uint32_t m_max = m, n_max = n;
@@ -376,6 +407,22 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
         words = words_next;
         next = next2;
     }
+    // block sums -> this kernel's partial slot; the count of unfinished pairs -> one atomic per block that has any
+    __shared__ unsigned long long lcells, lsyms;
+    __shared__ uint32_t lmaxa, lmaxb, lshorts, lleft;
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; lleft = 0; }
+    __syncthreads();
+    atomicAdd(&lcells, cells);
+    atomicAdd(&lsyms, syms);
+    atomicMax(&lmaxa, maxa);
+    atomicMax(&lmaxb, maxb);
+    atomicAdd(&lshorts, shorts);
+    atomicAdd(&lleft, left);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        args.partials[kMaxPartials + blockIdx.x] = PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, 0};
+        if (lleft) atomicAdd(args.leftover, lleft);
+    }
 }
 
 template <typename Off>
@@ -399,10 +446,12 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     if (max_blocks > kMaxPartials) max_blocks = kMaxPartials;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+    int dblocks = 0;
     if (args.direct_short) {
         StampGuard guard(scope, "direct_short");
-        int dblocks = (int)((pairs + 255) / 256);
+        dblocks = (int)((pairs + 255) / 256);
         if (dblocks > scope->compute_units * 4) dblocks = scope->compute_units * 4;
+        if (dblocks > kMaxPartials) dblocks = kMaxPartials;
         if (args.off64) hipLaunchKernelGGL(k_direct_short<uint64_t>, dim3(dblocks), dim3(256), 0, stream, args);
         else hipLaunchKernelGGL(k_direct_short<uint32_t>, dim3(dblocks), dim3(256), 0, stream, args);
     }
@@ -414,7 +463,7 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     {
         StampGuard guard(scope, "plan_scan");
         hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, stream, args.hist, args.cursor, args.plan,
-                           args.partials, (uint32_t)blocks);
+                           args.partials, (uint32_t)blocks, (uint32_t)dblocks, args.leftover);
     }
     {
         StampGuard guard(scope, "plan_scatter");

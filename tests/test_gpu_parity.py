@@ -438,6 +438,52 @@ def test_pipelined_scope_lanes(sw, orc):
     assert (out.cpu().numpy().astype(np.uint32) == want).all()
 
 
+BAD_UTF8 = [b"\xff", b"\xc0\x80", b"\xc1\xbf", b"\xe0\x80\x80", b"\xe0\x9f\xbf", b"\xed\xa0\x80", b"\xed\xbf\xbf",
+            b"\xf0\x8f\xbf\xbf", b"\xf4\x90\x80\x80", b"\xf5\x80\x80\x80", b"\xf8\x88\x80\x80\x80", b"\xe2\x82", b"\xf0\x9f\x98",
+            b"\xc3", b"\x80", b"\xbf\xbf", b"\xc3\x28", b"\xe2\x28\xa1", b"\xe2\x82\x28", b"\xf0\x28\x8c\xbc", b"\xf0\x90\x28\xbc",
+            b"\xf0\x90\x8c\x28"]
+GOOD_UTF8 = ["", "a", "\u007f", "\u0080", "\u07ff", "\u0800", "\ud7ff", "\ue000", "\uffff", "\U00010000", "\U0010ffff",
+             "na\u00efve \u0416\u4e2d\U0001f600"]
+
+
+def test_utf8_validation_matches_the_oracle(sw, orc, scope):
+    """Strict UTF-8 (RFC 3629): every malformed sequence is rejected wherever it sits -- alone, inside a longer tape,
+    at the very end of the tape, across the decoder's 256 B / 1 KB / 8 KB tile edges, or split over two strings --
+    and the boundary code points of every sequence length decode to the oracle's code points."""
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    good = [g.encode("utf-8") for g in GOOD_UTF8]
+    want = orc.levenshtein_pairs(sw.Strs(good), sw.Strs(list(reversed(good))), utf8=True)
+    assert engine.pairs(good, list(reversed(good)), scope).tolist() == want.tolist()
+    filler = "x\u00e9\u4e2d\U0001f600".encode("utf-8")   # 1 + 2 + 3 + 4 = 10 bytes
+    for bad in BAD_UTF8:
+        with pytest.raises(ValueError):
+            orc.utf8_decode(bad)
+        for lead in (0, 250, 255, 256, 1020, 1023, 1024, 8185, 8190, 8192, 8193):
+            pad = (filler * (lead // len(filler) + 1))[: lead - lead % 1] if lead else b""
+            pad = pad[: len(pad) - 0]
+            # cut the filler on a sequence boundary so that only `bad` is malformed
+            while pad and (pad[-1] & 0xC0) == 0x80 or pad and pad[-1] >= 0xC0:
+                pad = pad[:-1]
+            pad = pad + b"y" * (lead - len(pad))
+            for tail in (b"", b"zz", filler * 30):
+                for side in (0, 1):
+                    strings = [b"ok", pad + bad + tail, b"fine"]
+                    other = [b"ok", b"ok", b"ok"]
+                    with pytest.raises(sw.StringWarsError) as info:
+                        engine.pairs(*((strings, other) if side == 0 else (other, strings)), scope)
+                    assert info.value.status == "invalid_utf8", (bad, lead, tail[:4], side)
+    # a valid sequence cut in two by a string boundary is invalid in both strings
+    euro = "\u20ac".encode("utf-8")
+    with pytest.raises(sw.StringWarsError):
+        engine.pairs([euro[:1], euro[1:]], [b"a", b"b"], scope)
+    with pytest.raises(sw.StringWarsError):
+        engine.pairs([b"a" * 1023 + euro[:2], euro[2:] + b"b"], [b"a", b"b"], scope)
+    # ... while the same bytes inside one string, straddling every tile edge, are fine
+    for lead in (254, 255, 1022, 1023, 8190, 8191):
+        s = b"a" * lead + euro + b"b"
+        assert engine.pairs([s], [b"a" * lead + b"b"], scope).tolist() == [1]
+
+
 def test_edge_cases_and_errors(sw, orc, scope):
     engine = sw.LevenshteinDistances(capabilities=scope)
     assert engine.pairs([], [], scope).size == 0

@@ -548,14 +548,23 @@ __global__ __launch_bounds__(256) void k_utf8_tile_count(const uint8_t *data, ui
 // sum over leads of (length - 1) must equal the number of continuation bytes. Claimed ranges are disjoint
 // (a claimed byte is a continuation byte, so no lead sits inside another lead's range), hence equality
 // means every continuation byte is claimed exactly once.
-__global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, uint64_t total, const uint64_t *tile_prefix,
-                                                         uint32_t *symbols, uint32_t *invalid, int *balance) {
-    __shared__ uint32_t wave_tot[kUtf8Passes][4];
-    __shared__ int wave_bal[4];
-    // Code points of a pass are collected in rank order in LDS and leave as full 256-byte rows per wave; written
-    // straight from the decoding lanes (up to four stores each, 16 bytes apart) every cache line was touched by four
-    // store instructions and the kernel ran at a fifth of the memory rate. Two buffers: one barrier per pass.
-    __shared__ uint32_t stage[2][kUtf8Pass];
+struct Utf8WriteLds {
+    uint32_t wave_tot[kUtf8Passes][4];
+    int wave_bal[4];
+    union {
+        uint32_t stage[2][kUtf8Pass];   // edge tiles: code points of a pass in rank order
+        uint16_t leads[kUtf8Tile];      // interior tiles: byte positions of the tile's lead bytes in rank order
+    };
+    uint32_t raw[kUtf8Tile / 4 + 4];    // interior tiles: the tile's bytes (+ the word after it)
+};
+
+// Generic form (bounds-checked loads, branchy decode): the tiles at the end of the tape.
+__device__ __noinline__ void utf8_tile_write_edge(Utf8WriteLds &lds, const uint8_t *data, uint64_t total,
+                                                   const uint64_t *tile_prefix, uint32_t *symbols, uint32_t *invalid,
+                                                   int *balance) {
+    auto &wave_tot = lds.wave_tot;
+    auto &wave_bal = lds.wave_bal;
+    auto &stage = lds.stage;
     const uint64_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tot = (int64_t)total;
@@ -649,6 +658,110 @@ __global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, ui
     // per-tile balance (sequences straddling a tile edge make it non-zero per tile, zero over the tape);
     // a single hot atomic here serialised ~100K tiles and cost more than the decode itself
     if (threadIdx.x == 0) balance[tile] = wave_bal[0] + wave_bal[1] + wave_bal[2] + wave_bal[3];
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row_shr 1/2/4/8 inside each row of 16, then
+// row_bcast 15 / 31 carry the row totals forward).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// Lead bytes (everything but 10xxxxxx) of four packed bytes as 0x80 flags: !bit7 | bit6.
+__device__ __forceinline__ uint32_t lead_flags4(uint32_t dw) { return (~dw | (dw << 1)) & 0x80808080u; }
+
+// One UTF-8 sequence starting in the low byte of `seq` (its next three bytes above it), without branches:
+// n1 = leading one bits of the first byte (0: ASCII, 2..4: lead of a 2..4 byte sequence), the payload bits of all
+// four bytes are packed as if the sequence were four bytes long and shifted down by the bytes it does not have.
+// `bad` collects: missing continuation bytes, overlong forms, surrogates, > U+10FFFF, lead bytes F8..FF.
+__device__ __forceinline__ uint32_t utf8_decode_one(uint32_t seq, uint32_t &need, bool &bad) {
+    const uint32_t c = seq & 0xffu;
+    const uint32_t n1 = (uint32_t)__builtin_clz(~(seq << 24) | 0x00800000u);   // <= 8
+    need = n1 ? n1 - 1 : 0;                                                        // continuation bytes to follow
+    const uint32_t full = ((c & (0x7fu >> n1)) << 18) | ((seq >> 8 & 0x3fu) << 12) | ((seq >> 16 & 0x3fu) << 6) | (seq >> 24 & 0x3fu);
+    const uint32_t cp = full >> (6 * (3 - (need > 3 ? 3 : need)));
+    const uint32_t cont_wrong = ((seq >> 8 & 0xC0C0C0u) ^ 0x808080u) & ((1u << (8 * (need > 3 ? 3 : need))) - 1u);
+    const uint32_t min_cp = (1u << ((0x100B0700u >> (8 * (need > 3 ? 3 : need))) & 0x1fu)) & ~1u;   // 0, 0x80, 0x800, 0x10000
+    bad = n1 > 4 || cont_wrong != 0 || cp < min_cp || cp > 0x10FFFFu || (cp - 0xD800u) < 0x800u;
+    return cp;
+}
+
+// Validation: every lead byte checks its own sequence (continuation bytes present, no overlong, no
+// surrogate, <= U+10FFFF, inside the tape). Stray continuation bytes are caught by a global balance:
+// sum over leads of (length - 1) must equal the number of continuation bytes. Claimed ranges are disjoint
+// (a claimed byte is a continuation byte, so no lead sits inside another lead's range), hence equality
+// means every continuation byte is claimed exactly once.
+__global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, uint64_t total, const uint64_t *tile_prefix,
+                                                         uint32_t *symbols, uint32_t *invalid, int *balance) {
+    __shared__ Utf8WriteLds lds;
+    const uint64_t tile = blockIdx.x;
+    // interior tiles: every word this block touches (its own and the one after its last) lies inside the tape
+    if ((tile + 1) * kUtf8Tile + 4 > total) {
+        utf8_tile_write_edge(lds, data, total, tile_prefix, symbols, invalid, balance);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t *src = data + tile * kUtf8Tile + threadIdx.x * 4;
+    uint32_t curs[kUtf8Passes];
+#pragma unroll
+    for (int q = 0; q < kUtf8Passes; ++q) __builtin_memcpy(&curs[q], src + q * kUtf8Pass, 4);   // all loads first
+    uint32_t edge = 0;   // the word after the tile: look-ahead of its last sequences
+    if (threadIdx.x == 0) __builtin_memcpy(&edge, data + (tile + 1) * kUtf8Tile, 4);
+    uint32_t incls[kUtf8Passes];
+#pragma unroll
+    for (int q = 0; q < kUtf8Passes; ++q) {
+        incls[q] = wave_inclusive_sum((uint32_t)__popc(lead_flags4(curs[q])));
+        if (lane == 63) lds.wave_tot[q][wave] = incls[q];
+        lds.raw[q * 256 + threadIdx.x] = curs[q];
+    }
+    if (threadIdx.x == 0) lds.raw[kUtf8Tile / 4] = edge;
+    __syncthreads();
+    // Work is handed out per SEQUENCE, not per byte: the byte positions of the tile's lead bytes are listed in rank
+    // order (LDS), then thread i decodes sequences i, i + 256, ... from the tile's bytes (also in LDS) and stores code
+    // points i, i + 256, ... -- coalesced, with no barrier between them, and nothing is decoded for continuation bytes
+    // (two of every four bytes in CJK / Cyrillic text).
+    int bal = 0;  // continuation bytes the sequences I decode expect, minus continuation bytes I hold
+    uint32_t before = 0;   // code points of the passes before q
+#pragma unroll
+    for (int q = 0; q < kUtf8Passes; ++q) {
+        const uint32_t flags = lead_flags4(curs[q]);
+        const uint32_t mine = (uint32_t)__popc(flags);
+        bal -= 4 - (int)mine;
+        uint32_t base = before;
+        for (int w = 0; w < wave; ++w) base += lds.wave_tot[q][w];
+        uint32_t rank = base + incls[q] - mine;   // within the tile
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((flags >> (8 * u + 7)) & 1u) lds.leads[rank++] = (uint16_t)(q * kUtf8Pass + threadIdx.x * 4 + u);
+        before += lds.wave_tot[q][0] + lds.wave_tot[q][1] + lds.wave_tot[q][2] + lds.wave_tot[q][3];
+    }
+    __syncthreads();
+    const uint32_t tile_total = before;
+    uint32_t *out = symbols + tile_prefix[tile];
+    bool bad = false;
+    uint32_t bad_at = 0;
+    for (uint32_t i = threadIdx.x; i < tile_total; i += 256) {
+        const uint32_t at = lds.leads[i];
+        const uint32_t lo = lds.raw[at >> 2], hi = lds.raw[(at >> 2) + 1];
+        const uint32_t seq = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (at & 3u)));
+        uint32_t need;
+        bool bad_here;
+        const uint32_t cp = utf8_decode_one(seq, need, bad_here);
+        bal += (int)need;
+        if (bad_here && !bad) { bad = true; bad_at = at; }
+        out[i] = cp;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bal += __shfl_xor(bal, off);
+    if (lane == 0) lds.wave_bal[wave] = bal;
+    if (bad) atomicCAS(invalid, 0u, (uint32_t)((tile * kUtf8Tile + bad_at) >> 2) + 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) balance[tile] = lds.wave_bal[0] + lds.wave_bal[1] + lds.wave_bal[2] + lds.wave_bal[3];
 }
 
 __global__ __launch_bounds__(256) void k_utf8_balance(const int *tile_balance, uint64_t tiles, int *balance) {

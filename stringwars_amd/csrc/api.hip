@@ -307,6 +307,16 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             return swh_invalid_utf8_k;
         }
 
+        // patterns of more than 64 blocks: multi-pass bit-parallel kernel, carries between passes in scratch
+        if (bitpar_ok && plan.class_count[kClassBpLong]) {
+            const uint64_t stride = bp_long_carry_words(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb);
+            ensure(scope->boundary, scope->boundary_bytes, kBpLongMaxWaves * stride * sizeof(uint32_t));
+            KernelArgs kl = k;
+            kl.boundary = (int32_t *)scope->boundary;
+            kl.boundary_stride = stride;
+            launch_bitparallel_long(scope, kl, plan);
+        }
+
         // wavefront classes (all of them when the plan is wavefront-only)
         bool any_wf = false, multi = false;
         for (int c = kClassWf16; c <= kClassWfMulti; ++c) {

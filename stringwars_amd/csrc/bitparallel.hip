@@ -348,6 +348,209 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Patterns of more than 64 blocks (> 2048 symbols): ONE pair per wave, the 64 lanes take 64 consecutive blocks and the
+// text is walked once per pass of 64 blocks. The horizontal deltas leaving a pass's last block (one +1 and one -1
+// bit per text column) are parked in a per-wave carry array and fed to the next pass's first block in place of the
+// DP boundary. 32 columns per word, shifted in from the top by lane 63 and shifted out from the bottom by lane 0.
+// ------------------------------------------------------------------------------------------------------------
+template <typename Sym>
+__global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel_long(KernelArgs args) {
+    constexpr int kBpWaves = BpTraits<Sym>::kWaves, kBpTableWords = bp_table_words<Sym>();
+    constexpr bool kBytes = sizeof(Sym) == 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    uint32_t *table = (uint32_t *)smem + (size_t)wave_in_block * kBpTableWords;  // [entries][64 lanes]
+#pragma unroll
+    for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
+    const uint32_t cstart = args.plan->class_start[kClassBpLong], ccount = args.plan->class_count[kClassBpLong];
+    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
+                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
+    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
+                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
+    const uint32_t waves_total = gridDim.x * kBpWaves;
+    const uint32_t wave_id = blockIdx.x * kBpWaves + wave_in_block;
+    // carry words of this wave: [parity of the producing pass][+1 bits | -1 bits][words]
+    const uint32_t cwords = (uint32_t)(args.boundary_stride / 4);
+    uint32_t *carry = (uint32_t *)args.boundary + (uint64_t)wave_id * args.boundary_stride;
+
+    // lanes other than 0 take their horizontal input from the lane below; lane 0 from the boundary / the carry words
+    uint32_t keep_mask = lane == 0 ? 0u : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(keep_mask));
+
+    for (uint32_t w = wave_id; w < ccount; w += waves_total) {
+        const uint64_t p = args.perm[cstart + (ccount - 1 - w)];   // longest texts first
+        uint64_t a0, b0;
+        uint32_t la, lb;
+        if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
+        else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
+        const bool a_is_pattern = bp_pattern_is_a(la, lb);
+        const uint32_t m = a_is_pattern ? la : lb, n = a_is_pattern ? lb : la;
+        using Window = typename std::conditional<kBytes, ByteWindow, SymWindow32>::type;
+        Window pat, txt;
+        pat.init((const Sym *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? a0 : b0,
+                 a_is_pattern ? a_total : b_total);
+        txt.init((const Sym *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? b0 : a0,
+                 a_is_pattern ? b_total : a_total);
+        const uint32_t blocks_total = (m + 31) >> 5, passes = (blocks_total + 63) >> 6;
+        int part = 0;   // my blocks' share of the vertical deltas in the last column
+
+        for (uint32_t pass = 0; pass < passes; ++pass) {
+            const uint32_t blocks_here = blocks_total - pass * 64 < 64 ? blocks_total - pass * 64 : 64;
+            const bool my_block = (uint32_t)lane < blocks_here;
+            const uint32_t row0 = (pass * 64 + (uint32_t)lane) * 32;
+            const uint32_t brows = my_block ? (m - row0 < 32 ? m - row0 : 32) : 0;
+            const bool record = pass + 1 < passes;   // a full pass of 64 blocks: lane 63 leaves the carries
+            const uint32_t *cin_ph = carry + (size_t)((pass + 1) & 1) * 2 * cwords, *cin_mh = cin_ph + cwords;
+            uint32_t *cout_ph = carry + (size_t)(pass & 1) * 2 * cwords, *cout_mh = cout_ph + cwords;
+
+            constexpr int kTextRegs = kBytes ? 4 : 16;
+            uint32_t tnxt[kTextRegs];
+            int tshift[kBytes ? 4 : 1];
+            auto fetch_text = [&](int first) {
+                if constexpr (kBytes) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4_raw(first + q * 4, tshift[q]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) tnxt[q] = txt.fetch(first + q);
+                }
+            };
+            fetch_text(0 - lane);
+            // ---- match tables of my block ------------------------------------------------------------------
+            if constexpr (kBytes) {
+                uint32_t praw[8];
+                int pshift[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) praw[q] = pat.fetch4_raw((int)row0 + q * 4, pshift[q]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (brows > (uint32_t)q * 4) {
+                        const uint32_t dw = ByteWindow::realign(praw[q], pshift[q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if ((uint32_t)(q * 4 + r) < brows) bp_table_insert<Sym>(table, lane, (dw >> (8 * r)) & 0xffu, 1u << (q * 4 + r));
+                    }
+                }
+            } else {
+#pragma unroll 4
+                for (int q = 0; q < 32; ++q)
+                    if ((uint32_t)q < brows) bp_table_insert<Sym>(table, lane, pat.fetch((int)row0 + q), 1u << q);
+            }
+            const uint32_t n_eff = n + blocks_here - 1;
+            const uint32_t steps = (n_eff + 15) & ~15u;
+            uint32_t cw_ph = 0, cw_mh = 0, cw_ph_next = 0, cw_mh_next = 0;   // carries entering lane 0, 32 columns per word
+            if (pass) {
+                cw_ph_next = __hip_atomic_load(cin_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cw_mh_next = __hip_atomic_load(cin_mh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            uint32_t ow_ph = 0, ow_mh = 0;   // carries leaving lane 63
+            uint32_t pv = 0xFFFFFFFFu, mv = 0, ph = 0, mh = 0;
+            for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
+                uint32_t tcur[kTextRegs];
+#pragma unroll
+                for (int q = 0; q < kTextRegs; ++q) {
+                    if constexpr (kBytes) tcur[q] = ByteWindow::realign(tnxt[q], tshift[q]);
+                    else tcur[q] = tnxt[q];
+                }
+                fetch_text((int)s0 + 16 - lane);
+                if (pass && (s0 & 31u) == 0) {   // lane 0 is at column s0: the word for columns s0 .. s0 + 31
+                    cw_ph = cw_ph_next;
+                    cw_mh = cw_mh_next;
+                    const uint32_t nxt = (s0 >> 5) + 1 < cwords ? (s0 >> 5) + 1 : cwords - 1;
+                    cw_ph_next = __hip_atomic_load(cin_ph + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cw_mh_next = __hip_atomic_load(cin_mh + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t gs = s0 + q * 4;
+                    if (gs >= n_eff) break;  // wave-uniform
+                    uint32_t eqs[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uint32_t c;
+                        if constexpr (kBytes) c = (tcur[q] >> (8 * u)) & 0xffu;
+                        else c = tcur[q * 4 + u];
+                        eqs[u] = bp_table_lookup<Sym>(table, lane, c);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t s = gs + u;
+                        // what enters block 64 * pass in column s: the DP boundary (+1) or the previous pass's carries
+                        uint32_t in_ph = 0x80000000u, in_mh = 0;
+                        if (pass) {   // uniform
+                            in_ph = cw_ph << 31; in_mh = cw_mh << 31;
+                            cw_ph >>= 1; cw_mh >>= 1;
+                        }
+                        uint32_t ph_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ph, 0x138, 0xf, 0xf, true);
+                        uint32_t mh_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x138, 0xf, 0xf, true);
+                        ph_in = (uint32_t)__builtin_amdgcn_bitop3_b32((int)ph_in, (int)keep_mask, (int)in_ph, 0xE2);  // (a & b) | (c & ~b)
+                        mh_in = (uint32_t)__builtin_amdgcn_bitop3_b32((int)mh_in, (int)keep_mask, (int)in_mh, 0xE2);
+                        if (my_block && s - (uint32_t)lane < n) {
+                            uint32_t eq = eqs[u];
+                            uint32_t xv = eq | mv;
+                            eq |= mh_in >> 31;
+                            uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                            ph = mv | ~(xh | pv);
+                            mh = pv & xh;
+                            uint32_t ph_s = __builtin_amdgcn_alignbit(ph, ph_in, 31);
+                            uint32_t mh_s = __builtin_amdgcn_alignbit(mh, mh_in, 31);
+                            pv = mh_s | ~(xv | ph_s);
+                            mv = ph_s & xv;
+                            if (record) {   // uniform; only lane 63's words are stored
+                                ow_ph = (ow_ph >> 1) | (ph & 0x80000000u);
+                                ow_mh = (ow_mh >> 1) | (mh & 0x80000000u);
+                            }
+                        }
+                        // lane 63 has just finished column s - 63: a word is complete every 32 columns
+                        if (record && s >= 63 && ((s - 63) & 31u) == 31u && s - 63 < n && lane == 63) {
+                            cout_ph[(s - 63) >> 5] = ow_ph;
+                            cout_mh[(s - 63) >> 5] = ow_mh;
+                        }
+                    }
+                }
+            }
+            if (record && (n & 31u) && lane == 63) {   // the last, partial word: bits sit at the top
+                cout_ph[n >> 5] = ow_ph >> (32 - (n & 31u));
+                cout_mh[n >> 5] = ow_mh >> (32 - (n & 31u));
+            }
+            const uint32_t mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
+            part += __popc(pv & mask) - __popc(mv & mask);
+#pragma unroll
+            for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
+            __builtin_amdgcn_s_waitcnt(0);   // carries are in memory before the next pass asks for them
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) store_result(args.job, p, (int64_t)clamp_bound(n + (uint32_t)part, args.job.bound));
+    }
+}
+
+void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_host) {
+    const uint32_t count = plan_host.class_count[kClassBpLong];
+    if (!count) return;
+    const bool bytes = args.sym_bytes == 1;
+    const int waves = bytes ? BpTraits<uint8_t>::kWaves : BpTraits<uint32_t>::kWaves;
+    const size_t lds = bytes ? bp_lds_bytes<uint8_t>() : bp_lds_bytes<uint32_t>();
+    uint32_t blocks = (count + waves - 1) / waves;
+    const uint32_t max_blocks = (uint32_t)scope->compute_units * (bytes ? 4 : 3);
+    if (blocks > max_blocks) blocks = max_blocks;
+    // args.boundary / boundary_stride: the carry words, sized by the caller (bp_long_carry_words, <= 4096 waves)
+    StampGuard guard(scope, bytes ? "bitparallel_long" : "bitparallel_long_u32");
+    if (bytes) {
+        static bool attr_set = false;
+        if (!attr_set) { SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_bitparallel_long<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        hipLaunchKernelGGL(k_bitparallel_long<uint8_t>, dim3(blocks), dim3(waves * 64), lds, scope->stream, args);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) { SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_bitparallel_long<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        hipLaunchKernelGGL(k_bitparallel_long<uint32_t>, dim3(blocks), dim3(waves * 64), lds, scope->stream, args);
+    }
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
 template <typename Sym>
 static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     // The work list lives in the device plan; the host only bounds the grid (an item holds >= 1 pair).

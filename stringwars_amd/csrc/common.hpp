@@ -120,6 +120,7 @@ constexpr int kClassWf64 = 73;
 constexpr int kNumWideW = 12;
 constexpr int kClassWfMulti = kClassWf64 + kNumWideW;
 constexpr int kClassBanded = kClassWfMulti + 1;  // bounded unit-cost pairs on the sliding 64-bit band (banded.hip)
+constexpr int kClassBpLong = kClassBanded + 1;   // bit-parallel, both strings > 2048 symbols: one pair per wave, 64 blocks per pass
 __host__ __device__ constexpr int wide_w(int i) {
     constexpr int w[kNumWideW] = {3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 80, 96};
     return w[i];
@@ -232,6 +233,12 @@ struct KernelArgs {
     uint64_t boundary_stride;  // int32 elements per group slot
 };
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs);
+// pairs of class kClassBpLong (needs the host plan: carry scratch is sized by the longest text)
+void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_host);
+// u32 carry words per wave of k_bitparallel_long: 2 pass parities x (+1 | -1 deltas) x one bit per text column, plus
+// slack for the prefetch of the word after the last; the kernel never has more than 4096 waves
+inline uint64_t bp_long_carry_words(uint64_t longest_text) { return 4 * (longest_text / 32 + 4); }
+constexpr uint64_t kBpLongMaxWaves = 4096;
 void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan_host);
 void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs);
 int wavefront_strip_cap();

@@ -168,6 +168,46 @@ def test_random_levenshtein_long(sw, orc, scope, algorithm):
     assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
 
 
+@pytest.mark.parametrize("utf8", [False, True])
+def test_patterns_longer_than_64_blocks(sw, orc, scope, utf8):
+    """Both strings > 2048 symbols: the bit-parallel kernel walks the text once per pass of 64 blocks and hands the
+    horizontal deltas from pass to pass (2 to 5 passes here, with partial last passes, block-aligned and unaligned
+    lengths, texts shorter and longer than the carry-word granularity, mixed with ordinary pairs)."""
+    rng = np.random.default_rng(77)
+    lengths = [(2049, 2049), (2048 + 32, 2100), (4096, 4096), (4097, 5000), (3000, 9000), (6143, 6145), (8200, 2300),
+               (2050, 2080), (10, 5000), (5000, 10), (2500, 2500), (70, 90), (0, 3000), (4095, 4095)]
+    alphabet = np.array([ord(c) for c in "ACGT"], np.uint32) if not utf8 else np.array([0x41, 0xE9, 0x416, 0x4E2D, 0x1F600], np.uint32)
+    items_a, items_b = [], []
+    for la, lb in lengths:
+        a = alphabet[rng.integers(0, len(alphabet), la)]
+        if la and lb and rng.random() < 0.7:     # related strings: a few hundred edits
+            b = list(a)
+            for _ in range(int(rng.integers(1, 300))):
+                op, pos = int(rng.integers(0, 3)), int(rng.integers(0, max(len(b), 1)))
+                if op == 0 and b:
+                    b[pos] = int(alphabet[rng.integers(0, len(alphabet))])
+                elif op == 1:
+                    b.insert(pos, int(alphabet[rng.integers(0, len(alphabet))]))
+                elif len(b) > 1:
+                    del b[pos]
+            b = np.array(b[:max(lb, 1)] if len(b) > lb else b, np.uint32)
+        else:
+            b = alphabet[rng.integers(0, len(alphabet), lb)]
+        enc = (lambda x: "".join(map(chr, x)).encode("utf-8")) if utf8 else (lambda x: bytes(x.astype(np.uint8)))
+        items_a.append(enc(a))
+        items_b.append(enc(b))
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    cls = sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances
+    want = orc.levenshtein_pairs(a, b, utf8=utf8, algo="hyyro" if not utf8 else "wf")
+    for algorithm in ("auto", "bitparallel"):
+        engine = cls(capabilities=scope, algorithm=algorithm)
+        got = engine.pairs(a, b, scope)
+        assert got.tolist() == want.tolist(), (algorithm, got.tolist(), want.tolist())
+        timing_names = scope.last_timing()["dominant_name"] if hasattr(scope, "last_timing") else ""
+        got_bounded = engine.pairs(a, b, scope, bound=100)
+        assert got_bounded.tolist() == np.minimum(want, 101).tolist(), algorithm
+
+
 @pytest.mark.parametrize("algorithm", ["wavefront", "bitparallel"])
 def test_very_long_pair(sw, orc, scope, algorithm):
     """Beyond 64 blocks (bit-parallel hands over to the wavefront) and beyond one wavefront pass (6144 columns)."""

@@ -315,7 +315,7 @@ class LevenshteinDistances(_Engine):
         return self._pairs(fns[0], fns[1], a, b, scope, out, np.uint32, extra=(C.c_uint32(bound_value),))
 
     def __del__(self):
-        if getattr(self, "_handle", None):
+        if getattr(self, "_handle", None) and getattr(N, "lib", None) is not None:   # module globals go first at exit
             N.lib.swh_levenshtein_free(self._handle)
             self._handle = None
 
@@ -366,7 +366,7 @@ class NeedlemanWunschScores(_Engine):
                            a, b, scope, out, np.int32)
 
     def __del__(self):
-        if getattr(self, "_handle", None):
+        if getattr(self, "_handle", None) and getattr(N, "lib", None) is not None:   # module globals go first at exit
             getattr(N.lib, self._prefix + "_free")(self._handle)
             self._handle = None
 

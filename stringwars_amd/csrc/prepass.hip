@@ -131,11 +131,24 @@ __global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
         }
         atomicAdd(&lhist[key], 1u);
     }
-    atomicAdd(&lcells, cells);
-    atomicAdd(&lsyms, syms);
-    atomicMax(&lmaxa, maxa);
-    atomicMax(&lmaxb, maxb);
-    atomicAdd(&lshorts, shorts);
+    // wave-reduce first: 256 lanes adding to ONE LDS word serialise completely (five such atomics per thread were
+    // half of this kernel's run time)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cells += __shfl_xor(cells, off);
+        syms += __shfl_xor(syms, off);
+        shorts += __shfl_xor(shorts, off);
+        const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+        maxa = oa > maxa ? oa : maxa;
+        maxb = ob > maxb ? ob : maxb;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&lcells, cells);
+        atomicAdd(&lsyms, syms);
+        atomicMax(&lmaxa, maxa);
+        atomicMax(&lmaxb, maxb);
+        atomicAdd(&lshorts, shorts);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < kKeys; i += blockDim.x)
         if (lhist[i]) atomicAdd(&args.hist[i], lhist[i]);
@@ -415,12 +428,24 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
     __shared__ uint32_t lmaxa, lmaxb, lshorts, lleft;
     if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; lleft = 0; }
     __syncthreads();
-    atomicAdd(&lcells, cells);
-    atomicAdd(&lsyms, syms);
-    atomicMax(&lmaxa, maxa);
-    atomicMax(&lmaxb, maxb);
-    atomicAdd(&lshorts, shorts);
-    atomicAdd(&lleft, left);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {   // wave-reduce first (see k_plan_hist)
+        cells += __shfl_xor(cells, off);
+        syms += __shfl_xor(syms, off);
+        shorts += __shfl_xor(shorts, off);
+        left += __shfl_xor(left, off);
+        const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+        maxa = oa > maxa ? oa : maxa;
+        maxb = ob > maxb ? ob : maxb;
+    }
+    if (lane == 0) {
+        atomicAdd(&lcells, cells);
+        atomicAdd(&lsyms, syms);
+        atomicMax(&lmaxa, maxa);
+        atomicMax(&lmaxb, maxb);
+        atomicAdd(&lshorts, shorts);
+        atomicAdd(&lleft, left);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         args.partials[kMaxPartials + blockIdx.x] = PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, 0};

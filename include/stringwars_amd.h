@@ -88,6 +88,14 @@ typedef struct swh_timing_t {
 } swh_timing_t;
 swh_status_t swh_scope_set_profiling(swh_scope_t scope, int enabled);
 swh_status_t swh_scope_last_timing(swh_scope_t scope, swh_timing_t *timing);
+/* Sums over every engine call since profiling was last switched on -- also the asynchronous and pipelined ones, whose
+ * events are read when their lane is next used or the scope is synchronized. bench.py's roofline uses the mean of
+ * `dominant_ms` over a pipelined run, i.e. kernel durations under the same conditions rocprofv3 sees them. */
+typedef struct swh_timing_totals_t {
+    double total_ms, dominant_ms, compute_ms;   /* sums of the per-call figures of swh_timing_t */
+    uint64_t calls;
+} swh_timing_totals_t;
+swh_status_t swh_scope_timing_totals(swh_scope_t scope, swh_timing_totals_t *totals);
 
 /* ---- Memory: `UnifiedAlloc` / `UnifiedMat` parity (bench.rs:292-295, :466-468). ------------ */
 /* Host-visible, device-readable allocation (pinned + mapped). */

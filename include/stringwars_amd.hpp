@@ -83,6 +83,7 @@ public:
     size_t compute_units() const { size_t n = 0; swh_scope_compute_units(handle_, &n); return n; }
     void set_profiling(bool on) const { swh_scope_set_profiling(handle_, on); }
     swh_timing_t last_timing() const { swh_timing_t t{}; swh_scope_last_timing(handle_, &t); return t; }
+    swh_timing_totals_t timing_totals() const { swh_timing_totals_t t{}; swh_scope_timing_totals(handle_, &t); return t; }
 };
 
 class LevenshteinDistances {

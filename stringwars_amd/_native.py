@@ -66,6 +66,11 @@ class Timing(C.Structure):
     ]
 
 
+class TimingTotals(C.Structure):
+    """``swh_timing_totals_t``: sums over the profiled calls (synchronous, asynchronous and pipelined)."""
+    _fields_ = [("total_ms", C.c_double), ("dominant_ms", C.c_double), ("compute_ms", C.c_double), ("calls", C.c_uint64)]
+
+
 class Synth(C.Structure):
     _fields_ = [
         ("data_a", C.c_void_p), ("offsets_a", C.c_void_p), ("data_b", C.c_void_p), ("offsets_b", C.c_void_p),
@@ -89,6 +94,7 @@ SIGNATURES = {
     "swh_scope_join": (C.c_int, [_P, _ERR]),
     "swh_scope_set_profiling": (C.c_int, [_P, C.c_int]),
     "swh_scope_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
+    "swh_scope_timing_totals": (C.c_int, [_P, C.POINTER(TimingTotals)]),
     "swh_unified_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), _ERR]),
     "swh_unified_free": (C.c_int, [_P, _P]),
     "swh_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), _ERR]),

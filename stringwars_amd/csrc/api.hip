@@ -63,6 +63,20 @@ static void collect_timing(Scope *scope) {
     }
 }
 
+// Reads the events of the scope's last call once they are complete and adds the call to the running totals.
+static void harvest_timing(Scope *scope) {
+    if (!scope->profiling || !scope->stamps_pending || !scope->stamps_used) { scope->stamps_pending = false; return; }
+    (void)hipEventSynchronize(scope->stamps[scope->stamps_used - 1].stop);
+    const uint64_t cells = scope->last_timing.cells, bytes = scope->last_timing.bytes;
+    collect_timing(scope);
+    scope->last_timing.cells = cells; scope->last_timing.bytes = bytes;
+    scope->totals.total_ms += scope->last_timing.total_ms;
+    scope->totals.dominant_ms += scope->last_timing.dominant_ms;
+    scope->totals.compute_ms += scope->last_timing.compute_ms;
+    scope->totals.calls += 1;
+    scope->stamps_pending = false;
+}
+
 // ---- scratch -------------------------------------------------------------------------------------
 struct Carver {
     char *base; size_t used, cap;
@@ -142,6 +156,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         return fail(error, swh_invalid_argument_k, "pairwise call needs tapes of equal count");
     const uint64_t pairs = spec.cross ? (uint64_t)spec.a.count * spec.b.count : spec.a.count;
     if (pairs >= 0xFFFFFFF0ull) return fail(error, swh_unsupported_length_k, "more than 2^32 pairs in one call");
+    harvest_timing(scope);   // an earlier asynchronous call on this scope / lane: its events are complete by now
     scope->stamps_used = 0;
     scope->last_timing = swh_timing_t{};
     if (pairs == 0) return swh_success_k;
@@ -351,9 +366,10 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         }
         scope->last_timing.cells = plan.cells;
         scope->last_timing.bytes = (need_sizes ? a_bytes + b_bytes : plan.symbols) + pairs * (2 * ow + elem);
+        scope->stamps_pending = scope->profiling;
         if (!scope->async || !dev_out) {
             SWH_HIP_CHECK(hipStreamSynchronize(stream));
-            if (scope->profiling) collect_timing(scope);
+            harvest_timing(scope);
         }
         return swh_success_k;
     } catch (const HipFailure &f) {
@@ -456,10 +472,12 @@ swh_status_t swh_scope_synchronize(swh_scope_t handle, const char **error) {
         if (lane) {
             hipError_t lerr = hipStreamSynchronize(lane->stream);
             if (lerr != hipSuccess) return fail_hip(error, HipFailure{lerr, "hipStreamSynchronize (lane)"});
+            harvest_timing(lane);
         }
     hipError_t err = hipStreamSynchronize(scope->stream);
     if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipStreamSynchronize"});
-    if (scope->profiling) collect_timing(scope);
+    harvest_timing(scope);
+    if (scope->pipelined && scope->last_lane) scope->last_timing = scope->last_lane->last_timing;
     return swh_success_k;
 }
 swh_status_t swh_scope_set_pipelined(swh_scope_t handle, int enabled, const char **error) {
@@ -475,6 +493,7 @@ swh_status_t swh_scope_set_pipelined(swh_scope_t handle, int enabled, const char
             if (status != swh_success_k) return status;
             lane = (Scope *)created;
             lane->async = true;
+            lane->profiling = scope->profiling;
             if (hipEventCreateWithFlags(&lane->lane_done, hipEventDisableTiming) != hipSuccess)
                 return fail(error, swh_device_error_k, "hipEventCreate failed for a pipeline lane");
         }
@@ -493,7 +512,25 @@ swh_status_t swh_scope_join(swh_scope_t handle, const char **error) {
 }
 swh_status_t swh_scope_set_profiling(swh_scope_t handle, int enabled) {
     if (!handle) return swh_invalid_argument_k;
-    ((Scope *)handle)->profiling = enabled != 0;
+    Scope *scope = (Scope *)handle;
+    Scope *all[3] = {scope, scope->lanes[0], scope->lanes[1]};
+    for (Scope *s : all) {
+        if (!s) continue;
+        if (enabled && !s->profiling) { s->totals = swh_timing_totals_t{}; s->stamps_pending = false; }
+        s->profiling = enabled != 0;
+    }
+    return swh_success_k;
+}
+swh_status_t swh_scope_timing_totals(swh_scope_t handle, swh_timing_totals_t *totals) {
+    if (!handle || !totals) return swh_invalid_argument_k;
+    Scope *scope = (Scope *)handle;
+    *totals = swh_timing_totals_t{};
+    Scope *all[3] = {scope, scope->lanes[0], scope->lanes[1]};
+    for (Scope *s : all) {
+        if (!s) continue;
+        totals->total_ms += s->totals.total_ms; totals->dominant_ms += s->totals.dominant_ms;
+        totals->compute_ms += s->totals.compute_ms; totals->calls += s->totals.calls;
+    }
     return swh_success_k;
 }
 swh_status_t swh_scope_last_timing(swh_scope_t handle, swh_timing_t *timing) {

@@ -177,6 +177,8 @@ struct Scope {
     Scope *last_lane = nullptr;       // (on the parent) lane that took the latest call
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
+    bool stamps_pending = false;       // recorded by an asynchronous call, not read yet (api.hip: harvest_timing)
+    swh_timing_totals_t totals{};      // sums since profiling was switched on
     swh_timing_t last_timing{};
     std::string error;
 };

@@ -106,6 +106,15 @@ class DeviceScope:
             "bytes": int(timing.bytes), "kernels": int(timing.kernels),
         }
 
+
+    def timing_totals(self) -> dict:
+        """Sums of ``last_timing``'s durations over every call since profiling was switched on, including
+        asynchronous / pipelined calls (``swh_scope_timing_totals``)."""
+        totals = N.TimingTotals()
+        N.lib.swh_scope_timing_totals(self._handle, C.byref(totals))
+        return {"total_ms": totals.total_ms, "dominant_ms": totals.dominant_ms, "compute_ms": totals.compute_ms,
+                "calls": int(totals.calls)}
+
     def close(self) -> None:
         if getattr(self, "_handle", None) is not None and self._handle:
             N.lib.swh_scope_free(self._handle)

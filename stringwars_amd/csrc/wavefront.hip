@@ -109,7 +109,9 @@ __device__ __forceinline__ void store_score(const Job &job, uint64_t p, int scor
     else store_result(job, p, (int64_t)score);
 }
 
-template <typename Sym, int G, int W, int MODEL>
+// PQ (class models only): cost-row dword pairs that can hold a class, ceil(classes / 8) -- one v_perm per pair and
+// group of four columns. Up to eight classes need one, 20 amino acids + "other" three, the full 32 classes four.
+template <typename Sym, int G, int W, int MODEL, int PQ = 4>
 __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls) {
     constexpr bool kClass = MODEL == kClassLinear || MODEL == kClassAffine;
     constexpr bool kMatrix = MODEL != kUniformLinear && !kClass;   // per-cell LDS gather from the 256x256 table
@@ -216,13 +218,13 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
             uint32_t bs[kClass ? 1 : kColRegs];
             // class model: per group of four columns, four v_perm selectors (one per pair of cost-row dwords): byte
             // i of selector p is (class_i & 7) when class_i lives in dwords 2p..2p+1 of the row, else 0x0C (zero)
-            [[maybe_unused]] uint32_t sel[kClass ? W : 1];
+            [[maybe_unused]] uint32_t sel[kClass ? (W / 4) * PQ : 1];
             int H[W], F[kAffine ? W : 1];
 #pragma unroll
             for (int k = 0; k < (kClass ? 1 : kColRegs); ++k) bs[k] = 0;
             if constexpr (kClass) {
 #pragma unroll
-                for (int k = 0; k < W; ++k) sel[k] = 0;
+                for (int k = 0; k < (W / 4) * PQ; ++k) sel[k] = 0;
             }
 #pragma unroll
             for (int k = 0; k < W; ++k) {
@@ -231,8 +233,8 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 if constexpr (kClass) {
                     const uint32_t cls_k = lclass_of[sym_k & 0xffu];
 #pragma unroll
-                    for (int pq = 0; pq < 4; ++pq)
-                        sel[(k & ~3) + pq] |= ((cls_k >> 3) == (uint32_t)pq ? (cls_k & 7u) : 0x0Cu) << (8 * (k & 3));
+                    for (int pq = 0; pq < PQ; ++pq)
+                        sel[(k >> 2) * PQ + pq] |= ((cls_k >> 3) == (uint32_t)pq ? (cls_k & 7u) : 0x0Cu) << (8 * (k & 3));
                 } else if constexpr (kPackCols) bs[k >> 2] |= sym_k << (8 * (k & 3));
                 else bs[k] = sym_k;
                 H[k] = (kLocal || kSkew) ? 0 : (kSkewAffine ? open - ext : open + (int)j * ext);  // row 0: H[0][j+1] = open + j*ext
@@ -318,13 +320,16 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                             // one 32-byte cost row per step (the row symbol's class), then bytes are picked in
                             // registers: no per-cell LDS traffic at all
                             const uint32_t rc = lclass_of[sym & 0xffu];
-                            const uint4 r_lo = *(const uint4 *)(smem + rc * 32), r_hi = *(const uint4 *)(smem + rc * 32 + 16);
+                            const uint4 r_lo = *(const uint4 *)(smem + rc * 32);
+                            uint4 r_hi{0, 0, 0, 0};
+                            if constexpr (PQ > 2) r_hi = *(const uint4 *)(smem + rc * 32 + 16);
 #pragma unroll
                             for (int g4 = 0; g4 < W; g4 += 4) {
-                                const uint32_t c4 = __builtin_amdgcn_perm(r_lo.y, r_lo.x, sel[g4 + 0]) |
-                                                    __builtin_amdgcn_perm(r_lo.w, r_lo.z, sel[g4 + 1]) |
-                                                    __builtin_amdgcn_perm(r_hi.y, r_hi.x, sel[g4 + 2]) |
-                                                    __builtin_amdgcn_perm(r_hi.w, r_hi.z, sel[g4 + 3]);
+                                const uint32_t *sg = sel + (g4 >> 2) * PQ;
+                                uint32_t c4 = __builtin_amdgcn_perm(r_lo.y, r_lo.x, sg[0]);
+                                if constexpr (PQ > 1) c4 |= __builtin_amdgcn_perm(r_lo.w, r_lo.z, sg[PQ > 1 ? 1 : 0]);
+                                if constexpr (PQ > 2) c4 |= __builtin_amdgcn_perm(r_hi.y, r_hi.x, sg[PQ > 2 ? 2 : 0]);
+                                if constexpr (PQ > 3) c4 |= __builtin_amdgcn_perm(r_hi.w, r_hi.z, sg[PQ > 3 ? 3 : 0]);
 #pragma unroll
                                 for (int i4 = 0; i4 < 4; ++i4) cell(g4 + i4, (int)(int8_t)(c4 >> (8 * i4)));
                             }
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
 // ------------------------------------------------------------------------------------------------
 // Host dispatch
 // ------------------------------------------------------------------------------------------------
-template <typename Sym, int G, int W, int MODEL>
+template <typename Sym, int G, int W, int MODEL, int PQ = 4>
 static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint32_t count, const char *name) {
     constexpr int kGroups = 64 / G;
     uint32_t chunks = (count + kGroups - 1) / kGroups;
@@ -413,13 +418,13 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
     if (lds > 65536) {
         static bool attr_set = false;  // one flag per instantiation
         if (!attr_set) {
-            SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_wavefront<Sym, G, W, MODEL>,
+            SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_wavefront<Sym, G, W, MODEL, PQ>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
     }
     StampGuard guard(scope, name);
-    hipLaunchKernelGGL((k_wavefront<Sym, G, W, MODEL>), dim3(blocks), dim3(256), lds, scope->stream, args, cls);
+    hipLaunchKernelGGL((k_wavefront<Sym, G, W, MODEL, PQ>), dim3(blocks), dim3(256), lds, scope->stream, args, cls);
 }
 
 // Tuning knob (STRINGWARS_AMD_WF_CAP=<columns per lane>): strips wider than the cap run as several passes of 32
@@ -464,38 +469,38 @@ static void launch_model(Scope *scope, const KernelArgs &args, const Plan &plan)
 }
 
 // Class-table models handle columns four at a time: strips are rounded up to a multiple of four columns.
-template <int MODEL>
+template <int MODEL, int PQ>
 static void launch_class_model(Scope *scope, const KernelArgs &args, const Plan &plan) {
     for (int wc = 1; wc <= 8; ++wc) {
         const uint32_t cls = kClassWf16 + wc - 1, count = plan.class_count[cls];
         if (!count) continue;
-        if (wc <= 4) launch_one<uint8_t, 16, 4, MODEL>(scope, args, cls, count, "wavefront_class_g16_w4");
-        else launch_one<uint8_t, 16, 8, MODEL>(scope, args, cls, count, "wavefront_class_g16_w8");
+        if (wc <= 4) launch_one<uint8_t, 16, 4, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g16_w4");
+        else launch_one<uint8_t, 16, 8, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g16_w8");
     }
     for (int idx = 0; idx < kNumWideW; ++idx) {
         const uint32_t cls = kClassWf64 + idx, count = plan.class_count[cls];
         if (!count) continue;
         const int w = wide_w(idx);
-        if (w <= 4) launch_one<uint8_t, 64, 4, MODEL>(scope, args, cls, count, "wavefront_class_g64_w4");
-        else if (w <= 8) launch_one<uint8_t, 64, 8, MODEL>(scope, args, cls, count, "wavefront_class_g64_w8");
-        else if (w <= 12) launch_one<uint8_t, 64, 12, MODEL>(scope, args, cls, count, "wavefront_class_g64_w12");
-        else if (w <= 16) launch_one<uint8_t, 64, 16, MODEL>(scope, args, cls, count, "wavefront_class_g64_w16");
-        else if (w <= 24) launch_one<uint8_t, 64, 24, MODEL>(scope, args, cls, count, "wavefront_class_g64_w24");
-        else if (w <= 32) launch_one<uint8_t, 64, 32, MODEL>(scope, args, cls, count, "wavefront_class_g64_w32");
-        else if (w <= 48) launch_one<uint8_t, 64, 48, MODEL>(scope, args, cls, count, "wavefront_class_g64_w48");
-        else if (w <= 64) launch_one<uint8_t, 64, 64, MODEL>(scope, args, cls, count, "wavefront_class_g64_w64");
+        if (w <= 4) launch_one<uint8_t, 64, 4, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w4");
+        else if (w <= 8) launch_one<uint8_t, 64, 8, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w8");
+        else if (w <= 12) launch_one<uint8_t, 64, 12, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w12");
+        else if (w <= 16) launch_one<uint8_t, 64, 16, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w16");
+        else if (w <= 24) launch_one<uint8_t, 64, 24, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w24");
+        else if (w <= 32) launch_one<uint8_t, 64, 32, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w32");
+        else if (w <= 48) launch_one<uint8_t, 64, 48, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w48");
+        else if (w <= 64) launch_one<uint8_t, 64, 64, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w64");
         else if constexpr (MODEL == kClassLinear) {
-            if (w <= 80) launch_one<uint8_t, 64, 80, MODEL>(scope, args, cls, count, "wavefront_class_g64_w80");
-            else launch_one<uint8_t, 64, 96, MODEL>(scope, args, cls, count, "wavefront_class_g64_w96");
+            if (w <= 80) launch_one<uint8_t, 64, 80, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w80");
+            else launch_one<uint8_t, 64, 96, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w96");
         } else {
             // Gotoh keeps H, F and the selectors per column (3 registers): two exact half-width passes beat one
             // pass that spills or a wider pass whose second half idles
-            if (w <= 80) launch_one<uint8_t, 64, 40, MODEL>(scope, args, cls, count, "wavefront_class_g64_w40_x2");
-            else launch_one<uint8_t, 64, 48, MODEL>(scope, args, cls, count, "wavefront_class_g64_w48_x2");
+            if (w <= 80) launch_one<uint8_t, 64, 40, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w40_x2");
+            else launch_one<uint8_t, 64, 48, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w48_x2");
         }
     }
     if (plan.class_count[kClassWfMulti])
-        launch_one<uint8_t, 64, 32, MODEL>(scope, args, kClassWfMulti, plan.class_count[kClassWfMulti],
+        launch_one<uint8_t, 64, 32, MODEL, PQ>(scope, args, kClassWfMulti, plan.class_count[kClassWfMulti],
                                            "wavefront_class_g64_w32_multipass");
 }
 
@@ -506,8 +511,17 @@ void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan) {
     } else if (!matrix) {
         launch_model<uint8_t, kUniformLinear>(scope, args, plan);
     } else if (args.scoring.class_table && !args.local) {
-        if (!args.affine) launch_class_model<kClassLinear>(scope, args, plan);
-        else launch_class_model<kClassAffine>(scope, args, plan);
+        // one v_perm per group of four columns and per 8 classes the matrix distinguishes
+        const uint32_t classes = args.scoring.classes ? args.scoring.classes : 32;
+        if (!args.affine) {
+            if (classes <= 8) launch_class_model<kClassLinear, 1>(scope, args, plan);
+            else if (classes <= 24) launch_class_model<kClassLinear, 3>(scope, args, plan);
+            else launch_class_model<kClassLinear, 4>(scope, args, plan);
+        } else {
+            if (classes <= 8) launch_class_model<kClassAffine, 1>(scope, args, plan);
+            else if (classes <= 24) launch_class_model<kClassAffine, 3>(scope, args, plan);
+            else launch_class_model<kClassAffine, 4>(scope, args, plan);
+        }
     } else if (args.local) {
         if (!args.affine) launch_model<uint8_t, kMatrixLinearLocal>(scope, args, plan);
         else launch_model<uint8_t, kMatrixAffineLocal>(scope, args, plan);

@@ -30,10 +30,6 @@ struct ByteWindow {
         shift = 8 * bp_med3i(idx - c, -3, 3) + 24;
         return dw;
     }
-    // the shift fetch4_raw(idx, .) reported, recomputed where only the raw word was kept
-    __device__ __forceinline__ int shift_of(int idx) const {
-        return 8 * bp_med3i(idx - bp_med3i(idx, lo, hi), -3, 3) + 24;
-    }
     static __device__ __forceinline__ uint32_t realign(uint32_t dw, int shift) {
         return (uint32_t)((((uint64_t)dw) << 24) >> (uint32_t)shift);
     }

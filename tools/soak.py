@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Randomized parity soak on the GPU: batches with mixed length regimes, alphabets, bounds and engines, every result
+compared with the CPU oracle (test infrastructure) bit for bit. Not part of the pytest suite (minutes, not seconds).
+
+    python tools/soak.py --seconds 240 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import stringwars_amd as sw  # noqa: E402
+import oracle  # noqa: E402
+
+REGIMES = [(0, 8), (0, 40), (20, 140), (100, 700), (500, 2100), (1900, 2300), (2000, 5000), (0, 5000)]
+ALPHABETS = {"acgt": [ord(c) for c in "ACGT"], "lower": list(range(97, 123)), "byte": list(range(256)),
+             "binary": [48, 49], "ascii": list(range(32, 127))}
+SCRIPTS = [0x41, 0x62, 0xE9, 0x416, 0x434, 0x4E2D, 0x6587, 0x1F600, 0x20AC, 0x7F, 0x80, 0x7FF, 0x800, 0xFFFF, 0x10000]
+
+
+def random_batch(rng, utf8):
+    regime = REGIMES[int(rng.integers(0, len(REGIMES)))]
+    mixed = rng.random() < 0.3
+    budget = 1.5e9
+    alphabet = np.array(SCRIPTS if utf8 else ALPHABETS[str(rng.choice(list(ALPHABETS)))], np.uint32)
+    items_a, items_b, cells = [], [], 0
+    while cells < budget and len(items_a) < 20000:
+        lo, hi = REGIMES[int(rng.integers(0, len(REGIMES)))] if mixed else regime
+        la, lb = int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))
+        a = alphabet[rng.integers(0, len(alphabet), la)]
+        if rng.random() < 0.6 and la:
+            b = list(a)
+            for _ in range(int(rng.integers(0, max(2, la // 8)))):
+                op, pos = int(rng.integers(0, 3)), int(rng.integers(0, max(len(b), 1)))
+                if op == 0 and b:
+                    b[pos] = int(alphabet[rng.integers(0, len(alphabet))])
+                elif op == 1:
+                    b.insert(pos, int(alphabet[rng.integers(0, len(alphabet))]))
+                elif len(b) > 1:
+                    del b[pos]
+            b = np.array(b, np.uint32)
+        else:
+            b = alphabet[rng.integers(0, len(alphabet), lb)]
+        enc = (lambda x: "".join(map(chr, x)).encode("utf-8")) if utf8 else (lambda x: bytes(x.astype(np.uint8)))
+        items_a.append(enc(a))
+        items_b.append(enc(b))
+        cells += max(len(a), 1) * max(len(b), 1)
+    return sw.Strs(items_a), sw.Strs(items_b)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    scope = sw.DeviceScope(gpu_device=0)
+    t0, rounds, pairs_total = time.time(), 0, 0
+    while time.time() - t0 < args.seconds:
+        kind = str(rng.choice(["lev", "lev", "lev_utf8", "nw", "sw"]))
+        if kind in ("lev", "lev_utf8"):
+            utf8 = kind == "lev_utf8"
+            a, b = random_batch(rng, utf8)
+            bound = None if rng.random() < 0.5 else int(rng.integers(0, 80))
+            algorithm = str(rng.choice(["auto", "auto", "bitparallel", "wavefront"]))
+            if algorithm == "wavefront" and oracle.cells(a, b, utf8=utf8) > 3e8:
+                algorithm = "auto"
+            cls = sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances
+            engine = cls(capabilities=scope, algorithm=algorithm)
+            want = oracle.levenshtein_pairs(a, b, utf8=utf8, algo="wf" if utf8 else "hyyro", bound=bound)
+            for _ in range(2):   # the second call may take the direct-short path
+                got = engine.pairs(a, b, scope, bound=bound)
+                bad = np.nonzero(got != want)[0]
+                assert bad.size == 0, (kind, algorithm, bound, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+        else:
+            classes = int(rng.choice([2, 4, 8, 9, 21, 24, 25, 32, 256]))
+            alphabet = np.arange(classes if classes < 256 else 256, dtype=np.uint32) + (65 if classes <= 32 else 0)
+            matrix = rng.integers(-6, 7, (256, 256)).astype(np.int8)
+            matrix = np.minimum(matrix, matrix.T)   # symmetric
+            if classes <= 32:   # bytes outside the alphabet share one class
+                other = np.setdiff1d(np.arange(256), alphabet.astype(np.int64))
+                matrix[other, :] = matrix[other[0], :][None, :]
+                matrix[:, other] = matrix[:, other[0]][:, None]
+                matrix[np.ix_(other, other)] = matrix[other[0], other[0]]
+            gaps = [(-4, -4), (-11, -1), (-2, -2), (-5, -1), (-1, -1)][int(rng.integers(0, 5))]
+            items_a, items_b, cells = [], [], 0
+            lo, hi = [(0, 40), (20, 300), (200, 1500), (1000, 5000)][int(rng.integers(0, 4))]
+            while cells < 1.5e8 and len(items_a) < 4000:
+                la, lb = int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))
+                items_a.append(bytes(alphabet[rng.integers(0, len(alphabet), la)].astype(np.uint8)))
+                items_b.append(bytes(alphabet[rng.integers(0, len(alphabet), lb)].astype(np.uint8)))
+                cells += max(la, 1) * max(lb, 1)
+            a, b = sw.Strs(items_a), sw.Strs(items_b)
+            cls = sw.NeedlemanWunschScores if kind == "nw" else sw.SmithWatermanScores
+            engine = cls(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope)
+            got = engine.pairs(a, b, scope)
+            want = np.array([oracle.nw_score(x, y, matrix, gaps[0], gaps[1], local=(kind == "sw")) for x, y in zip(items_a, items_b)])
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (kind, classes, gaps, bad[:5], got[bad[:5]], want[bad[:5]])
+        rounds += 1
+        pairs_total += len(a)
+    print(f"soak ok: {rounds} batches, {pairs_total} pairs, {time.time() - t0:.0f} s, seed {args.seed}")
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,8 @@ constexpr int kBandPitch = kBandChunk + 1;          // u64 per pair row in LDS
 constexpr int kBandWaves = 4;
 constexpr int kBandParamWords = 8;
 constexpr int kBandStage = 96;                      // u32 window symbols staged per half-wave (32 + WBITS max)
-constexpr size_t kBandLdsPerWave = (size_t)64 * kBandPitch * 8 + 64 * kBandParamWords * 4 + 2 * kBandStage * 4;
+// P = pairs per wave item (64, or 32 when the batch is too small to give every SIMD a few waves at 64)
+constexpr size_t band_lds_per_wave(int P) { return (size_t)P * kBandPitch * 8 + (size_t)P * kBandParamWords * 4 + 2 * kBandStage * 4; }
 
 struct BandPair {            // per-pair parameters parked in LDS for phase 1 (uniform reads)
     uint32_t pat_lo, pat_hi; // pattern pointer
@@ -46,26 +47,30 @@ __device__ __forceinline__ uint32_t band_load_sym(const Sym *base, int idx, int 
 }
 
 // WBITS = number of live window bits (a multiple of 4, >= k + 1): bits [64 - WBITS, 63].
-template <typename Sym, int WBITS>
+// P = pairs per item. The recurrence is a serial chain per pair and one wave issues a dependent instruction only every
+// ~8.5 cycles, so a batch of 100 K pairs (1564 items of 64 = 1.5 waves per SIMD) ran at 11 SIMD-cycles per instruction.
+// Items of 32 pairs leave half of phase 2's lanes idle (+30 % instructions) but double the resident waves.
+template <typename Sym, int WBITS, int P>
 __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
+    constexpr size_t kBandLdsPerWave = band_lds_per_wave(P);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     char *wave_lds = smem + (size_t)wave_in_block * kBandLdsPerWave;
-    unsigned long long *eqbuf = (unsigned long long *)wave_lds;                   // [64][kBandPitch]
-    BandPair *params = (BandPair *)(wave_lds + (size_t)64 * kBandPitch * 8);      // [64]
-    uint32_t *stage = (uint32_t *)(wave_lds + (size_t)64 * kBandPitch * 8 + 64 * kBandParamWords * 4);  // [2][kBandStage]
+    unsigned long long *eqbuf = (unsigned long long *)wave_lds;                   // [P][kBandPitch]
+    BandPair *params = (BandPair *)(wave_lds + (size_t)P * kBandPitch * 8);       // [P]
+    uint32_t *stage = (uint32_t *)(wave_lds + (size_t)P * kBandPitch * 8 + (size_t)P * kBandParamWords * 4);  // [2][kBandStage]
 
     const uint32_t cstart = args.plan->class_start[cls], ccount = args.plan->class_count[cls];
-    const uint32_t chunks = (ccount + 63) / 64;
+    const uint32_t chunks = (ccount + P - 1) / P;
     const uint32_t waves_total = gridDim.x * kBandWaves;
     const uint32_t wave_id = blockIdx.x * kBandWaves + wave_in_block;
     const uint32_t k = args.job.bound;
 
     for (uint32_t item_rev = wave_id; item_rev < chunks; item_rev += waves_total) {
         const uint32_t item = chunks - 1 - item_rev;  // longest texts first
-        const uint32_t pidx = item * 64 + lane;
-        const bool have = pidx < ccount;
+        const uint32_t pidx = item * P + lane;
+        const bool have = lane < P && pidx < ccount;
         uint64_t p = 0, a0 = 0, b0 = 0;
         uint32_t la = 0, lb = 0;
         if (have) {
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
             bp.pat_lo = (uint32_t)(uintptr_t)pat; bp.pat_hi = (uint32_t)((uintptr_t)pat >> 32);
             bp.txt_lo = (uint32_t)(uintptr_t)txt; bp.txt_hi = (uint32_t)((uintptr_t)txt >> 32);
             bp.len1 = len1; bp.len2 = have ? len2 : 0; bp.start0 = start0; bp.pad = 0;
-            params[lane] = bp;
+            if (lane < P) params[lane] = bp;
         }
         wave_lds_fence();  // params are read by other lanes in phase 1
         uint32_t n_max = have ? len2 : 0;
@@ -132,13 +137,13 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
             };
             issue_loads(half);
 #pragma unroll 1
-            for (int pp = 0; pp < 32; ++pp) {
+            for (int pp = 0; pp < P / 2; ++pp) {
                 const int q = pp * 2 + half;               // pair slot served by my half of the wave
                 const uint32_t tsym = nxt_tsym;
 #pragma unroll
                 for (int r = 0; r < kStageLoads; ++r)
                     if (col + 32 * r < 32 + WBITS) win[col + 32 * r] = nxt_sym[r];
-                if (pp + 1 < 32) issue_loads(q + 2);
+                if (pp + 1 < P / 2) issue_loads(q + 2);
                 wave_lds_fence();  // every lane reads symbols its neighbours staged
                 // hits: window symbol j <-> band bit 64 - WBITS + j. Built as kSegs independent accumulators
                 // (seg = seg * 2 + (symbol == text symbol), one compare + one add-with-carry per symbol, most
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
             for (int c = 0; c < kBandChunk; ++c) {
                 const uint32_t i = i0 + (uint32_t)c;
                 if (have && i < len2) {
-                    const unsigned long long eq = eqbuf[lane * kBandPitch + c];
+                    const unsigned long long eq = eqbuf[(lane < P ? lane : 0) * kBandPitch + c];
                     const uint32_t eq_lo = (uint32_t)eq, eq_hi = (uint32_t)(eq >> 32);
                     // D0 = (((Eq & VP) + VP) ^ VP) | Eq | VN   (64-bit add with carry)
                     uint32_t x_lo = eq_lo & vp_lo, x_hi = eq_hi & vp_hi;
@@ -216,21 +221,29 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
     }
 }
 
-template <typename Sym, int WBITS>
-static void launch_banded_one(Scope *scope, const KernelArgs &args, uint64_t pairs) {
-    const size_t lds = kBandWaves * kBandLdsPerWave;
-    uint64_t items = (pairs + 63) / 64;
+template <typename Sym, int WBITS, int P>
+static void launch_banded_items(Scope *scope, const KernelArgs &args, uint64_t pairs) {
+    const size_t lds = kBandWaves * band_lds_per_wave(P);
+    uint64_t items = (pairs + P - 1) / P;
     uint64_t blocks64 = (items + kBandWaves - 1) / kBandWaves;
-    uint32_t max_blocks = (uint32_t)scope->compute_units * 2;  // 77 KB per block -> two blocks per CU
+    uint32_t max_blocks = (uint32_t)scope->compute_units * (uint32_t)(160 * 1024 / lds);   // 77 KB (P = 64) / 41 KB per block
     uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
     if (!blocks) return;
     static bool attr_set = false;  // one per instantiation
     if (!attr_set) {
-        SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_banded<Sym, WBITS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_banded<Sym, WBITS, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     StampGuard guard(scope, "banded");
-    hipLaunchKernelGGL((k_banded<Sym, WBITS>), dim3(blocks), dim3(256), lds, scope->stream, args, (uint32_t)kClassBanded);
+    hipLaunchKernelGGL((k_banded<Sym, WBITS, P>), dim3(blocks), dim3(256), lds, scope->stream, args, (uint32_t)kClassBanded);
+}
+
+template <typename Sym, int WBITS>
+static void launch_banded_one(Scope *scope, const KernelArgs &args, uint64_t pairs) {
+    // `pairs` bounds the banded class from above (its size is only known on the device at this point): below eight
+    // 64-pair items per CU the half-size items win
+    if (pairs < (uint64_t)64 * 8 * scope->compute_units) launch_banded_items<Sym, WBITS, 32>(scope, args, pairs);
+    else launch_banded_items<Sym, WBITS, 64>(scope, args, pairs);
 }
 
 void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs) {

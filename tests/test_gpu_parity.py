@@ -280,6 +280,20 @@ def test_banded_window_kernel(sw, orc, scope, utf8):
         assert (engine.pairs(b, a, scope, bound=k) == want).all(), k
 
 
+def test_banded_window_kernel_large_batch(sw, orc, scope):
+    """Above ~131 K pairs the banded kernel switches from 32-pair to 64-pair wave items: same results."""
+    rng = np.random.default_rng(4242)
+    items_a, items_b = random_pairs(rng, 140_000, list(range(90, 131)), 26, related=0.8)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    for bound in (8, 20):
+        got = engine.pairs(a, b, scope, bound=bound)
+        want = orc.levenshtein_pairs(a, b, algo="hyyro", bound=bound)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (bound, bad[:5], got[bad[:5]], want[bad[:5]])
+    assert scope.last_timing()["cells"] > 0
+
+
 def test_high_bytes_take_the_8bit_table(sw, orc, scope):
     """Bytes >= 0x80 overflow the 7-bit match table and are deferred to the 8-bit kernel."""
     rng = np.random.default_rng(5)

@@ -266,8 +266,27 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 invalid_dev = flag_slot;
                 SWH_HIP_CHECK(hipMemsetAsync(invalid_dev, 0, 16, stream));
             }
-            decode(ta, a_bytes, da);
-            if (same_tape) db = da; else decode(tb, b_bytes, db);
+            if (same_tape) {
+                decode(ta, a_bytes, da);
+                db = da;
+            } else {
+                // The two tapes decode side by side: the staging kernels are barrier- and latency-bound (half the issue
+                // slots idle), so the second tape's run on the side stream, forked after the inputs are in place.
+                struct StreamSwap {   // launch_utf8_decode and its event stamps follow scope->stream
+                    Scope *s; hipStream_t keep;
+                    StreamSwap(Scope *sc_, hipStream_t to) : s(sc_), keep(sc_->stream) { s->stream = to; }
+                    ~StreamSwap() { s->stream = keep; }
+                };
+                SWH_HIP_CHECK(hipEventRecord(scope->fork_ev, stream));
+                SWH_HIP_CHECK(hipStreamWaitEvent(scope->side_stream, scope->fork_ev, 0));
+                {
+                    StreamSwap swap(scope, scope->side_stream);
+                    decode(tb, b_bytes, db);
+                }
+                SWH_HIP_CHECK(hipEventRecord(scope->join_ev, scope->side_stream));
+                decode(ta, a_bytes, da);
+                SWH_HIP_CHECK(hipStreamWaitEvent(stream, scope->join_ev, 0));
+            }
             ta = da; tb = db;
             sym_bytes = 4; off64 = 1;
         }
@@ -418,6 +437,8 @@ static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_
         SWH_HIP_CHECK(hipMemset(scope->plan_area, 0, plan_area_bytes));
         SWH_HIP_CHECK(hipStreamCreateWithFlags(&scope->side_stream, hipStreamNonBlocking));
         SWH_HIP_CHECK(hipEventCreateWithFlags(&scope->plan_ready, hipEventDisableTiming));
+        SWH_HIP_CHECK(hipEventCreateWithFlags(&scope->fork_ev, hipEventDisableTiming));
+        SWH_HIP_CHECK(hipEventCreateWithFlags(&scope->join_ev, hipEventDisableTiming));
         *out = (swh_scope_t)scope;
         return swh_success_k;
     } catch (const HipFailure &f) {
@@ -450,6 +471,8 @@ swh_status_t swh_scope_free(swh_scope_t handle) {
     if (scope->plan_host) (void)hipHostFree(scope->plan_host);
     if (scope->plan_area) (void)hipFree(scope->plan_area);
     if (scope->side_stream) (void)hipStreamDestroy(scope->side_stream);
+    if (scope->fork_ev) (void)hipEventDestroy(scope->fork_ev);
+    if (scope->join_ev) (void)hipEventDestroy(scope->join_ev);
     if (scope->plan_ready) (void)hipEventDestroy(scope->plan_ready);
     if (scope->owns_stream) (void)hipStreamDestroy(scope->stream);
     delete scope;

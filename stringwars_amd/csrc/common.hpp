@@ -167,6 +167,7 @@ struct Scope {
     char *plan_area = nullptr;  // device: hist | cursor | partials | plan, zeroed once (the scan kernel re-zeroes hist)
     hipStream_t side_stream = nullptr;  // plan read-back overlaps the first DP kernel
     hipEvent_t plan_ready = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;   // second tape's UTF-8 decode runs on side_stream beside the first's
     bool hint_short = true;     // the previous call saw short pairs: enqueue k_direct_short (first call: assume yes)
     // Pipelined mode: calls alternate between `lanes` (internal scopes with their own stream, scratch and plan
     // buffers), so the planning pre-pass of call i+1 overlaps the DP kernel of call i. Results are ordered for the

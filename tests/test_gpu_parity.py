@@ -206,6 +206,17 @@ def test_patterns_longer_than_64_blocks(sw, orc, scope, utf8):
         timing_names = scope.last_timing()["dominant_name"] if hasattr(scope, "last_timing") else ""
         got_bounded = engine.pairs(a, b, scope, bound=100)
         assert got_bounded.tolist() == np.minimum(want, 101).tolist(), algorithm
+    # 32-bit offsets, device-resident tapes, and the same strings as a cross-product (rows x columns) job
+    engine = cls(capabilities=scope)
+    a32, b32 = a.with_offsets(np.uint32), b.with_offsets(np.uint32)
+    assert engine.pairs(a32, b32, scope).tolist() == want.tolist()
+    assert engine.pairs(a32.to_device(scope), b32.to_device(scope), scope).tolist() == want.tolist()
+    rows, cols = a.subview(0, 5), b.subview(0, 4)
+    matrix = engine(rows, cols, scope)
+    for i in range(5):
+        for j in range(4):
+            one = orc.levenshtein_pairs(a.subview(i, i + 1), b.subview(j, j + 1), utf8=utf8, algo="wf")
+            assert int(matrix[i, j]) == int(one[0]), (i, j)
 
 
 @pytest.mark.parametrize("algorithm", ["wavefront", "bitparallel"])

@@ -175,7 +175,8 @@ def test_patterns_longer_than_64_blocks(sw, orc, scope, utf8):
     lengths, texts shorter and longer than the carry-word granularity, mixed with ordinary pairs)."""
     rng = np.random.default_rng(77)
     lengths = [(2049, 2049), (2048 + 32, 2100), (4096, 4096), (4097, 5000), (3000, 9000), (6143, 6145), (8200, 2300),
-               (2050, 2080), (10, 5000), (5000, 10), (2500, 2500), (70, 90), (0, 3000), (4095, 4095)]
+               (2050, 2080), (10, 5000), (5000, 10), (2500, 2500), (70, 90), (0, 3000), (4095, 4095),
+               (20_000, 24_000) if utf8 else (50_000, 60_000)]   # tens of passes, carry words far beyond one cache line
     alphabet = np.array([ord(c) for c in "ACGT"], np.uint32) if not utf8 else np.array([0x41, 0xE9, 0x416, 0x4E2D, 0x1F600], np.uint32)
     items_a, items_b = [], []
     for la, lb in lengths:

@@ -90,8 +90,12 @@ __device__ __forceinline__ PairInfo pair_info(const PrepassArgs &args, uint64_t 
     return info;
 }
 
+// Sixteen waves share one 24.6 KB counter array, so a CU holds enough waves to cover the serial key computation
+// (~120 dependent instructions per pair) and the per-block clear / flush of 6144 counters is spread over four times
+// the threads (with 256-thread blocks: 2 waves per SIMD, 14 us per 1 M pairs).
+constexpr int kPlanThreads = 1024;
 template <typename Off>
-__global__ __launch_bounds__(256) void k_plan_hist(PrepassArgs args) {
+__global__ __launch_bounds__(kPlanThreads) void k_plan_hist(PrepassArgs args) {
     // The planning kernels of one pipeline lane run in the shadow of the other lane's bit-parallel kernel, which owns
     // most wave slots and LDS; issue priority lets these short kernels through instead of trickling behind it.
     __builtin_amdgcn_s_setprio(3);
@@ -233,14 +237,14 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
     }
 }
 
-constexpr int kScatterTile = 2048;  // pairs per block iteration (8 per thread)
+constexpr int kScatterTile = 2048;  // pairs per block iteration (2 per thread)
 template <typename Off>
-__global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
+__global__ __launch_bounds__(kPlanThreads) void k_plan_scatter(PrepassArgs args) {
     __builtin_amdgcn_s_setprio(3);
     // One counter array, reused as the keys' output bases: 24.6 KB, so that a block of this kernel still fits next to
     // the four resident bit-parallel blocks of the scope's other pipeline lane (136 KB of a CU's 160 KB).
     __shared__ uint32_t lcount[kKeys];
-    constexpr int kPerThread = kScatterTile / 256;
+    constexpr int kPerThread = kScatterTile / kPlanThreads;
     // nothing left to sort when every pair was finished by the planning pass or the direct kernel
     if (args.plan->class_count[kClassTrivial] == args.plan->class_start[kMaxClasses]) return;
     uint64_t tiles = (args.job.pairs + kScatterTile - 1) / kScatterTile;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
         uint32_t keys[kPerThread], ranks[kPerThread];
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
-            uint64_t p = tile * kScatterTile + (uint64_t)k * 256 + threadIdx.x;
+            uint64_t p = tile * kScatterTile + (uint64_t)k * kPlanThreads + threadIdx.x;
             keys[k] = 0xFFFFFFFFu;
             if (p < args.job.pairs) {
                 PairInfo info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, args.unit_costs != 0);
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void k_plan_scatter(PrepassArgs args) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
-            uint64_t p = tile * kScatterTile + (uint64_t)k * 256 + threadIdx.x;
+            uint64_t p = tile * kScatterTile + (uint64_t)k * kPlanThreads + threadIdx.x;
             if (keys[k] != 0xFFFFFFFFu) args.perm[lcount[keys[k]] + ranks[k]] = (uint32_t)p;
         }
         __syncthreads();
@@ -469,7 +473,7 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     PrepassArgs args = args_in;
     hipStream_t stream = scope->stream;
     uint64_t pairs = args.job.pairs;
-    int blocks = (int)((pairs + 256 * 8 - 1) / (256 * 8));
+    int blocks = (int)((pairs + kPlanThreads * 2 - 1) / (kPlanThreads * 2));
     int max_blocks = scope->compute_units * 4;
     if (max_blocks > kMaxPartials) max_blocks = kMaxPartials;
     if (blocks > max_blocks) blocks = max_blocks;
@@ -485,8 +489,8 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     }
     {
         StampGuard guard(scope, "plan_hist");
-        if (args.off64) hipLaunchKernelGGL(k_plan_hist<uint64_t>, dim3(blocks), dim3(256), 0, stream, args);
-        else hipLaunchKernelGGL(k_plan_hist<uint32_t>, dim3(blocks), dim3(256), 0, stream, args);
+        if (args.off64) hipLaunchKernelGGL(k_plan_hist<uint64_t>, dim3(blocks), dim3(kPlanThreads), 0, stream, args);
+        else hipLaunchKernelGGL(k_plan_hist<uint32_t>, dim3(blocks), dim3(kPlanThreads), 0, stream, args);
     }
     {
         StampGuard guard(scope, "plan_scan");
@@ -498,8 +502,8 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
         uint64_t tiles = (pairs + kScatterTile - 1) / kScatterTile;
         int sblocks = (int)(tiles < (uint64_t)scope->compute_units * 4 ? tiles : (uint64_t)scope->compute_units * 4);
         if (sblocks < 1) sblocks = 1;
-        if (args.off64) hipLaunchKernelGGL(k_plan_scatter<uint64_t>, dim3(sblocks), dim3(256), 0, stream, args);
-        else hipLaunchKernelGGL(k_plan_scatter<uint32_t>, dim3(sblocks), dim3(256), 0, stream, args);
+        if (args.off64) hipLaunchKernelGGL(k_plan_scatter<uint64_t>, dim3(sblocks), dim3(kPlanThreads), 0, stream, args);
+        else hipLaunchKernelGGL(k_plan_scatter<uint32_t>, dim3(sblocks), dim3(kPlanThreads), 0, stream, args);
     }
     SWH_HIP_CHECK(hipGetLastError());
 }

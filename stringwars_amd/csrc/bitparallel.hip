@@ -400,6 +400,8 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     uint32_t *table = (uint32_t *)smem + (size_t)wave_in_block * kBpTableWords;  // [entries][64 lanes]
+    [[maybe_unused]] NibbleTables nib;
+    if constexpr (kBytes) nib.init(table, lane);
 #pragma unroll
     for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
     const uint32_t cstart = args.plan->class_start[kClassBpLong], ccount = args.plan->class_count[kClassBpLong];
@@ -462,13 +464,15 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                 int pshift[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) praw[q] = pat.fetch4_raw((int)row0 + q * 4, pshift[q]);
+                const uint32_t row_mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (brows > (uint32_t)q * 4) {
                         const uint32_t dw = ByteWindow::realign(praw[q], pshift[q]);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if ((uint32_t)(q * 4 + r) < brows) bp_table_insert<Sym>(table, lane, (dw >> (8 * r)) & 0xffu, 1u << (q * 4 + r));
+                        nib.template insert<0>(dw, row_mask & (1u << (q * 4 + 0)));
+                        nib.template insert<1>(dw, row_mask & (1u << (q * 4 + 1)));
+                        nib.template insert<2>(dw, row_mask & (1u << (q * 4 + 2)));
+                        nib.template insert<3>(dw, row_mask & (1u << (q * 4 + 3)));
                     }
                 }
             } else {
@@ -505,12 +509,14 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                     const uint32_t gs = s0 + q * 4;
                     if (gs >= n_eff) break;  // wave-uniform
                     uint32_t eqs[4];
+                    if constexpr (kBytes) {
+                        eqs[0] = nib.template lookup<0>(tcur[q]);
+                        eqs[1] = nib.template lookup<1>(tcur[q]);
+                        eqs[2] = nib.template lookup<2>(tcur[q]);
+                        eqs[3] = nib.template lookup<3>(tcur[q]);
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        uint32_t c;
-                        if constexpr (kBytes) c = (tcur[q] >> (8 * u)) & 0xffu;
-                        else c = tcur[q * 4 + u];
-                        eqs[u] = bp_table_lookup<Sym>(table, lane, c);
+                        for (int u = 0; u < 4; ++u) eqs[u] = bp_table_lookup<Sym>(table, lane, tcur[q * 4 + u]);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {

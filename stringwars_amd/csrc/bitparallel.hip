@@ -81,37 +81,6 @@ __device__ __forceinline__ uint32_t bp_table_lookup(const uint32_t *table, int l
     }
 }
 
-// Byte alphabet, address arithmetic done by hand: the LDS byte address of EqLo[v][lane] is tbase + (v << 8) and of
-// EqHi[v][lane] tbase + 4096 + (v << 8), where tbase (the wave's table + 4 * lane) has zeros in bits 8..11 -- the
-// per-wave tables are 8 KB apart and the dynamic LDS of these kernels starts at 0. So a nibble that has been shifted
-// to bits 8..11 goes in with ONE v_bitop3 ((x & 0xF00) | tbase; 2.8 cycles, against shift + and + add at 4.4 each
-// the compiler emits for the indexed form), and the +4096 rides in the ds instruction's offset field.
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-struct NibbleTables {
-    uint32_t tbase, mask;
-    __device__ __forceinline__ void init(uint32_t *table, int lane) {
-        tbase = (uint32_t)(uintptr_t)(lds_u32 *)(table + lane);
-        mask = 0xF00u;
-        asm volatile("" : "+v"(mask));   // keep it in a register: three distinct registers is the fast form of v_bitop3
-    }
-    // x holds the symbol in byte U
-    template <int U> __device__ __forceinline__ uint32_t lo_addr(uint32_t x) const {
-        const uint32_t s = U == 0 ? x << 8 : (U == 1 ? x : x >> (8 * U - 8));
-        return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask, (int)tbase, 0xEA);
-    }
-    template <int U> __device__ __forceinline__ uint32_t hi_addr(uint32_t x) const {
-        const uint32_t s = U == 0 ? x << 4 : x >> (8 * U - 4);
-        return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask, (int)tbase, 0xEA);
-    }
-    template <int U> __device__ __forceinline__ uint32_t lookup(uint32_t x) const {
-        return *(const lds_u32 *)(uintptr_t)lo_addr<U>(x) & *(const lds_u32 *)(uintptr_t)(hi_addr<U>(x) + 4096);
-    }
-    template <int U> __device__ __forceinline__ void insert(uint32_t x, uint32_t bit) const {
-        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)lo_addr<U>(x), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(hi_addr<U>(x) + 4096), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-};
-
 #ifdef SWH_BP_PROFILE
 // Diagnostic build only (make EXTRA=-DSWH_BP_PROFILE): summed wave cycles per phase of k_bitparallel.
 __device__ unsigned long long g_bp_phase[10];

@@ -289,6 +289,8 @@ template <typename Off, bool kWide>
 __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32_t *table, const uint64_t a_total,
                                                  const uint64_t b_total) {
     const int lane = threadIdx.x & 63;
+    NibbleTables nib;
+    nib.init(table, lane);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (args.job.pairs + stride - 1) / stride;  // wave-uniform trip count
     const uint64_t lane_first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,14 +389,11 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if ((uint32_t)q * 4 >= m_max) break;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if ((uint32_t)(q * 4 + r) < m) {
-                        const uint32_t c = (words.pw[q] >> (8 * r)) & 0xffu, bit = 1u << (q * 4 + r);
-                        atomicOr(&table[(c & 15u) * 64 + lane], bit);
-                        atomicOr(&table[(16 + (c >> 4)) * 64 + lane], bit);
-                    }
-                }
+                const uint32_t dw = words.pw[q];
+                if ((uint32_t)(q * 4 + 0) < m) nib.template insert<0>(dw, 1u << (q * 4 + 0));
+                if ((uint32_t)(q * 4 + 1) < m) nib.template insert<1>(dw, 1u << (q * 4 + 1));
+                if ((uint32_t)(q * 4 + 2) < m) nib.template insert<2>(dw, 1u << (q * 4 + 2));
+                if ((uint32_t)(q * 4 + 3) < m) nib.template insert<3>(dw, 1u << (q * 4 + 3));
             }
             uint32_t pv = 0xFFFFFFFFu, mv = 0;
 #pragma unroll
@@ -402,9 +401,9 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
                 if ((uint32_t)q * 4 >= n_max) break;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const uint32_t c = (words.tw[q] >> (8 * u)) & 0xffu;
                     if ((uint32_t)(q * 4 + u) < n) {
-                        const uint32_t eq = table[(c & 15u) * 64 + lane] & table[(16 + (c >> 4)) * 64 + lane];
+                        const uint32_t tw = words.tw[q];
+                        const uint32_t eq = u == 0 ? nib.template lookup<0>(tw) : (u == 1 ? nib.template lookup<1>(tw) : (u == 2 ? nib.template lookup<2>(tw) : nib.template lookup<3>(tw)));
                         const uint32_t xv = eq | mv;
                         const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
                         uint32_t ph = mv | ~(xh | pv);
@@ -459,7 +458,7 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
 
 template <typename Off>
 __global__ __launch_bounds__(256, 4) void k_direct_short(PrepassArgs args) {
-    __shared__ uint32_t ltable[4][32 * 64];  // per wave: EqLo[16][64] | EqHi[16][64]
+    __shared__ __attribute__((aligned(8192))) uint32_t ltable[4][32 * 64];  // per wave: EqLo[16][64] | EqHi[16][64]; 8 KB aligned for NibbleTables
     const int lane = threadIdx.x & 63;
     uint32_t *table = ltable[threadIdx.x >> 6];
     for (int k = 0; k < 32; ++k) table[k * 64 + lane] = 0;

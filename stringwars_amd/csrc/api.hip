@@ -222,6 +222,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         {
             Carver probe{nullptr, 0, 0};
             probe.take<uint32_t>(pairs);            // perm
+            probe.take<uint16_t>(pairs);            // plan keys
             if (spec.utf8) {
                 probe.take<uint32_t>(a_bytes + 4); probe.take<uint64_t>(spec.a.count + 1);
                 probe.take<uint32_t>(utf8_scratch_words(a_bytes));
@@ -234,6 +235,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         ensure(scope->scratch, scope->scratch_bytes, need);
         Carver sc{scope->scratch, 0, scope->scratch_bytes};
         uint32_t *perm = sc.take<uint32_t>(pairs);
+        uint16_t *plan_keys = sc.take<uint16_t>(pairs);
         Carver pa{scope->plan_area, 0, 0};
         uint32_t *hist = pa.take<uint32_t>(kKeys);
         uint32_t *cursor = pa.take<uint32_t>(kKeys);
@@ -309,7 +311,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         pre.local = engine->kind == 2 ? 1 : 0;
         pre.direct_short = bitpar_ok && sym_bytes == 1 && engine->algorithm == swh_algorithm_auto_k && scope->hint_short ? 1 : 0;
         pre.banded = pre.unit_costs && spec.bound <= 63 && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
-        pre.perm = perm; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.leftover = leftover; pre.plan = plan_dev;
+        pre.perm = perm; pre.keys = plan_keys; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.leftover = leftover; pre.plan = plan_dev;
         launch_prepass(scope, pre);
 
         KernelArgs k{};

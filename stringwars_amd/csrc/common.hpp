@@ -91,6 +91,7 @@ __device__ __forceinline__ uint32_t clamp_bound(uint32_t d, uint32_t bound) {
 constexpr int kMaxClasses = 96;   // kernel classes (a class = one kernel configuration)
 constexpr int kBuckets = 64;      // length buckets inside a class (sort granularity)
 constexpr int kKeys = kMaxClasses * kBuckets;
+static_assert(kKeys <= 65536, "plan keys are stored as u16 between the planning kernels");
 
 struct Plan {
     uint32_t class_start[kMaxClasses + 1];  // exclusive prefix of pairs per class into `perm`
@@ -215,6 +216,7 @@ struct PrepassArgs {
     uint32_t local;         // local alignment: pairs with an empty side score 0
     uint32_t direct_short;  // unit-cost byte pairs with both sides <= 32 symbols are scored by k_direct_short
     uint32_t *perm;         // out: pair ids sorted by key
+    uint16_t *keys;         // scratch: every pair's plan key, written by k_plan_hist, read back by k_plan_scatter
     uint32_t *hist;         // scratch: kKeys counters
     uint32_t *cursor;       // scratch: kKeys cursors
     PlanPartial *partials;  // scratch: 2 x kMaxPartials per-block work-unit sums

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_hist(PrepassArgs args) {
         } else {
             key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
         }
+        args.keys[p] = (uint16_t)key;   // k_plan_scatter sorts by the stored keys: no second look at the offsets
         atomicAdd(&lhist[key], 1u);
     }
     // wave-reduce first: 256 lanes adding to ONE LDS word serialise completely (five such atomics per thread were
@@ -257,9 +258,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_scatter(PrepassArgs args)
             uint64_t p = tile * kScatterTile + (uint64_t)k * kPlanThreads + threadIdx.x;
             keys[k] = 0xFFFFFFFFu;
             if (p < args.job.pairs) {
-                PairInfo info = pair_info<Off>(args, p, args.gap_open, args.gap_extend, args.unit_costs != 0);
-                uint32_t key = (info.trivial || (args.direct_short && short_pair(info))) ? kClassTrivial * kBuckets
-                                            : plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
+                const uint32_t key = args.keys[p];   // as classified by k_plan_hist
                 keys[k] = key;
                 ranks[k] = atomicAdd(&lcount[key], 1u);
             }

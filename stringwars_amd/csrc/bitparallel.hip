@@ -30,9 +30,10 @@
 
 namespace swh {
 
-// Code points (decoded UTF-8, u32) use the same trick with five groups of bits -- four nibbles and the plane
-// (bits 16..20): Eq(c) = T0[c & 15] & T1[(c >> 4) & 15] & T2[(c >> 8) & 15] & T3[(c >> 12) & 15] & T4[c >> 16],
-// 4 x 16 + 32 entries = 24 KB per wave.
+// Code points (decoded UTF-8, u32, 21 bits) use the same trick with seven groups of three bits:
+// Eq(c) = T0[c & 7] & T1[(c >> 3) & 7] & ... & T6[c >> 18], 7 x 8 entries = 14 KB per wave. (Four nibbles + a 32-entry
+// plane table, 24 KB per wave, left 1.5 waves per SIMD -- the regime where a serial recurrence issues at half rate;
+// two more lookups per column buy 2.5 waves per SIMD.)
 struct SymWindow32 {
     const uint32_t *base;
     int lo, hi;
@@ -50,7 +51,7 @@ template <> struct BpTraits<uint8_t> {
     static constexpr int kWaves = 4, kEntries = 32, kMinWavesPerSimd = 4;
 };
 template <> struct BpTraits<uint32_t> {
-    static constexpr int kWaves = 2, kEntries = 96, kMinWavesPerSimd = 1;
+    static constexpr int kWaves = 2, kEntries = 56, kMinWavesPerSimd = 2;
 };
 template <typename Sym> constexpr int bp_table_words() { return BpTraits<Sym>::kEntries * 64; }
 template <typename Sym> constexpr size_t bp_lds_bytes() {
@@ -63,11 +64,8 @@ __device__ __forceinline__ void bp_table_insert(uint32_t *table, int lane, uint3
         atomicOr(&table[(c & 15u) * 64 + lane], bit);
         atomicOr(&table[(16 + (c >> 4)) * 64 + lane], bit);
     } else {
-        atomicOr(&table[(c & 15u) * 64 + lane], bit);
-        atomicOr(&table[(16 + ((c >> 4) & 15u)) * 64 + lane], bit);
-        atomicOr(&table[(32 + ((c >> 8) & 15u)) * 64 + lane], bit);
-        atomicOr(&table[(48 + ((c >> 12) & 15u)) * 64 + lane], bit);
-        atomicOr(&table[(64 + ((c >> 16) & 31u)) * 64 + lane], bit);
+#pragma unroll
+        for (int g = 0; g < 7; ++g) atomicOr(&table[(8 * g + ((c >> (3 * g)) & 7u)) * 64 + lane], bit);
     }
 }
 template <typename Sym>
@@ -75,9 +73,9 @@ __device__ __forceinline__ uint32_t bp_table_lookup(const uint32_t *table, int l
     if constexpr (sizeof(Sym) == 1) {
         return table[(c & 15u) * 64 + lane] & table[(16 + (c >> 4)) * 64 + lane];
     } else {
-        uint32_t e = table[(c & 15u) * 64 + lane] & table[(16 + ((c >> 4) & 15u)) * 64 + lane];
-        e &= table[(32 + ((c >> 8) & 15u)) * 64 + lane] & table[(48 + ((c >> 12) & 15u)) * 64 + lane];
-        return e & table[(64 + ((c >> 16) & 31u)) * 64 + lane];
+        uint32_t e = table[(c & 7u) * 64 + lane] & table[(8 + ((c >> 3) & 7u)) * 64 + lane] & table[(16 + ((c >> 6) & 7u)) * 64 + lane];
+        e &= table[(24 + ((c >> 9) & 7u)) * 64 + lane] & table[(32 + ((c >> 12) & 7u)) * 64 + lane];
+        return e & table[(40 + ((c >> 15) & 7u)) * 64 + lane] & table[(48 + ((c >> 18) & 7u)) * 64 + lane];
     }
 }
 
@@ -548,7 +546,7 @@ void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_hos
     const int waves = bytes ? BpTraits<uint8_t>::kWaves : BpTraits<uint32_t>::kWaves;
     const size_t lds = bytes ? bp_lds_bytes<uint8_t>() : bp_lds_bytes<uint32_t>();
     uint32_t blocks = (count + waves - 1) / waves;
-    const uint32_t max_blocks = (uint32_t)scope->compute_units * (bytes ? 4 : 3);
+    const uint32_t max_blocks = (uint32_t)scope->compute_units * (bytes ? 4 : 5);
     if (blocks > max_blocks) blocks = max_blocks;
     // args.boundary / boundary_stride: the carry words, sized by the caller (bp_long_carry_words, <= 4096 waves)
     StampGuard guard(scope, bytes ? "bitparallel_long" : "bitparallel_long_u32");
@@ -572,8 +570,8 @@ static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_
     KernelArgs k = args;
     k.boundary = nullptr;
     uint64_t blocks64 = (pairs + kWaves - 1) / kWaves;
-    // bytes: 33 KB blocks of 4 waves, 4 per CU; code points: 49 KB blocks of 2 waves, 3 per CU
-    uint32_t max_blocks = (uint32_t)scope->compute_units * (sizeof(Sym) == 1 ? 4 : 3);
+    // bytes: 33 KB blocks of 4 waves, 4 per CU; code points: 29 KB blocks of 2 waves, 5 per CU
+    uint32_t max_blocks = (uint32_t)scope->compute_units * (sizeof(Sym) == 1 ? 4 : 5);
     uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
     static bool attr_set = false;
     if (!attr_set) {

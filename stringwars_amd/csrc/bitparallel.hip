@@ -44,6 +44,20 @@ struct SymWindow32 {
         hi = c31((int64_t)total - (int64_t)start - 1);
     }
     __device__ __forceinline__ uint32_t fetch(int idx) const { return base[bp_med3i(idx, lo, hi)]; }
+    // Four consecutive symbols with one 128-bit load. The window is clamped into the tape as a whole; a window that had
+    // to move (first / last symbols of a tape, tapes shorter than four symbols) is re-read symbol by symbol --
+    // positions outside the tape then repeat the edge symbol, which the callers never use.
+    __device__ __forceinline__ void fetch4(int idx, uint32_t (&out)[4]) const {
+        if (hi - lo >= 3) {
+            const int c = bp_med3i(idx, lo, hi - 3);
+            uint4 v;
+            __builtin_memcpy(&v, base + c, 16);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+            if (__builtin_expect(c == idx, 1)) return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = fetch(idx + q);
+    }
 };
 
 template <typename Sym> struct BpTraits;
@@ -193,7 +207,12 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) tnxt[q] = txt.fetch(first + q);
+                for (int q = 0; q < 16; q += 4) {
+                    uint32_t four[4];
+                    txt.fetch4(first + q, four);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tnxt[q + r] = four[r];
+                }
             }
         };
         fetch_text(0 - (int)blk);
@@ -228,9 +247,17 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
                 }
             }
         } else {
-#pragma unroll 4
+            uint32_t psym[32];   // the block's symbols, eight 128-bit loads in flight before the first table update
+#pragma unroll
+            for (int q = 0; q < 32; q += 4) {
+                uint32_t four[4];
+                pat.fetch4((int)row0 + q, four);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) psym[q + r] = four[r];
+            }
+#pragma unroll
             for (int q = 0; q < 32; ++q)
-                if ((uint32_t)q < brows) bp_table_insert<Sym>(table, lane, pat.fetch((int)row0 + q), 1u << q);
+                if ((uint32_t)q < brows) bp_table_insert<Sym>(table, lane, psym[q], 1u << q);
         }
         acc[lane] = 0;
         wave_lds_fence();  // acc slots are accumulated into by other lanes below
@@ -421,7 +448,12 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                     for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4_raw(first + q * 4, tshift[q]);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) tnxt[q] = txt.fetch(first + q);
+                    for (int q = 0; q < 16; q += 4) {
+                        uint32_t four[4];
+                        txt.fetch4(first + q, four);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tnxt[q + r] = four[r];
+                    }
                 }
             };
             fetch_text(0 - lane);
@@ -443,9 +475,17 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                     }
                 }
             } else {
-#pragma unroll 4
+                uint32_t psym[32];
+#pragma unroll
+                for (int q = 0; q < 32; q += 4) {
+                    uint32_t four[4];
+                    pat.fetch4((int)row0 + q, four);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) psym[q + r] = four[r];
+                }
+#pragma unroll
                 for (int q = 0; q < 32; ++q)
-                    if ((uint32_t)q < brows) bp_table_insert<Sym>(table, lane, pat.fetch((int)row0 + q), 1u << q);
+                    if ((uint32_t)q < brows) bp_table_insert<Sym>(table, lane, psym[q], 1u << q);
             }
             const uint32_t n_eff = n + blocks_here - 1;
             const uint32_t steps = (n_eff + 15) & ~15u;

@@ -72,26 +72,38 @@ template <typename Sym> constexpr size_t bp_lds_bytes() {
     return (size_t)BpTraits<Sym>::kWaves * (bp_table_words<Sym>() + 64) * 4 + 80 * 4;
 }
 
-template <typename Sym>
-__device__ __forceinline__ void bp_table_insert(uint32_t *table, int lane, uint32_t c, uint32_t bit) {
-    if constexpr (sizeof(Sym) == 1) {
-        atomicOr(&table[(c & 15u) * 64 + lane], bit);
-        atomicOr(&table[(16 + (c >> 4)) * 64 + lane], bit);
-    } else {
-#pragma unroll
-        for (int g = 0; g < 7; ++g) atomicOr(&table[(8 * g + ((c >> (3 * g)) & 7u)) * 64 + lane], bit);
+// The code-point tables with NibbleTables' address arithmetic (bp_window.hpp): group g's entries start 2048 * g bytes
+// into the wave's table (offset field of the ds instruction), the 3-bit value goes to bits 8..10 with one shift and
+// one v_bitop3 -- the per-wave tables are 14 KB = 7 x 2 KB apart, so those bits of the base are zero.
+struct GroupTables3 {
+    uint32_t tbase, mask;
+    __device__ __forceinline__ void init(uint32_t *table, int lane) {
+        tbase = (uint32_t)(uintptr_t)(lds_u32 *)(table + lane);
+        mask = 0x700u;
+        asm volatile("" : "+v"(mask));
     }
-}
-template <typename Sym>
-__device__ __forceinline__ uint32_t bp_table_lookup(const uint32_t *table, int lane, uint32_t c) {
-    if constexpr (sizeof(Sym) == 1) {
-        return table[(c & 15u) * 64 + lane] & table[(16 + (c >> 4)) * 64 + lane];
-    } else {
-        uint32_t e = table[(c & 7u) * 64 + lane] & table[(8 + ((c >> 3) & 7u)) * 64 + lane] & table[(16 + ((c >> 6) & 7u)) * 64 + lane];
-        e &= table[(24 + ((c >> 9) & 7u)) * 64 + lane] & table[(32 + ((c >> 12) & 7u)) * 64 + lane];
-        return e & table[(40 + ((c >> 15) & 7u)) * 64 + lane] & table[(48 + ((c >> 18) & 7u)) * 64 + lane];
+    template <int G> __device__ __forceinline__ uint32_t addr(uint32_t c) const {
+        uint32_t s;
+        if constexpr (3 * G <= 8) s = c << (8 - 3 * G);
+        else s = c >> (3 * G - 8);
+        return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask, (int)tbase, 0xEA);
     }
-}
+    __device__ __forceinline__ uint32_t lookup(uint32_t c) const {
+        uint32_t e = *(const lds_u32 *)(uintptr_t)addr<0>(c) & *(const lds_u32 *)(uintptr_t)(addr<1>(c) + 2048) &
+                     *(const lds_u32 *)(uintptr_t)(addr<2>(c) + 4096);
+        e &= *(const lds_u32 *)(uintptr_t)(addr<3>(c) + 6144) & *(const lds_u32 *)(uintptr_t)(addr<4>(c) + 8192);
+        return e & *(const lds_u32 *)(uintptr_t)(addr<5>(c) + 10240) & *(const lds_u32 *)(uintptr_t)(addr<6>(c) + 12288);
+    }
+    __device__ __forceinline__ void insert(uint32_t c, uint32_t bit) const {
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)addr<0>(c), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<1>(c) + 2048), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<2>(c) + 4096), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<3>(c) + 6144), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<4>(c) + 8192), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<5>(c) + 10240), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<6>(c) + 12288), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
 
 #ifdef SWH_BP_PROFILE
 // Diagnostic build only (make EXTRA=-DSWH_BP_PROFILE): summed wave cycles per phase of k_bitparallel.
@@ -128,7 +140,9 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
     uint32_t *acc = (uint32_t *)smem + (size_t)kBpWaves * kBpTableWords + wave_in_block * 64;
     uint32_t *item_prefix = (uint32_t *)smem + (size_t)kBpWaves * (kBpTableWords + 64);  // [65]
     [[maybe_unused]] NibbleTables nib;
+    [[maybe_unused]] GroupTables3 grp;
     if constexpr (kBytes) nib.init(table, lane);
+    else grp.init(table, lane);
 
 #pragma unroll
     for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
@@ -257,7 +271,7 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
             }
 #pragma unroll
             for (int q = 0; q < 32; ++q)
-                if ((uint32_t)q < brows) bp_table_insert<Sym>(table, lane, psym[q], 1u << q);
+                if ((uint32_t)q < brows) grp.insert(psym[q], 1u << q);
         }
         acc[lane] = 0;
         wave_lds_fence();  // acc slots are accumulated into by other lanes below
@@ -329,7 +343,7 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
                     eqs[3] = nib.template lookup<3>(tcur[q]);
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) eqs[u] = bp_table_lookup<Sym>(table, lane, tcur[q * 4 + u]);
+                    for (int u = 0; u < 4; ++u) eqs[u] = grp.lookup(tcur[q * 4 + u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) column(eqs[u], gs + u);
@@ -395,7 +409,9 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
     const int wave_in_block = threadIdx.x >> 6;
     uint32_t *table = (uint32_t *)smem + (size_t)wave_in_block * kBpTableWords;  // [entries][64 lanes]
     [[maybe_unused]] NibbleTables nib;
+    [[maybe_unused]] GroupTables3 grp;
     if constexpr (kBytes) nib.init(table, lane);
+    else grp.init(table, lane);
 #pragma unroll
     for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
     const uint32_t cstart = args.plan->class_start[kClassBpLong], ccount = args.plan->class_count[kClassBpLong];
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                 }
 #pragma unroll
                 for (int q = 0; q < 32; ++q)
-                    if ((uint32_t)q < brows) bp_table_insert<Sym>(table, lane, psym[q], 1u << q);
+                    if ((uint32_t)q < brows) grp.insert(psym[q], 1u << q);
             }
             const uint32_t n_eff = n + blocks_here - 1;
             const uint32_t steps = (n_eff + 15) & ~15u;
@@ -523,7 +539,7 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                         eqs[3] = nib.template lookup<3>(tcur[q]);
                     } else {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) eqs[u] = bp_table_lookup<Sym>(table, lane, tcur[q * 4 + u]);
+                        for (int u = 0; u < 4; ++u) eqs[u] = grp.lookup(tcur[q * 4 + u]);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {

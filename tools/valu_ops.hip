@@ -35,6 +35,16 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t seed
                 if constexpr (OP == 16) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(r[i]) : "v"(c) : "vcc");
                 if constexpr (OP == 17) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(r[i]) : "v"(c) : "vcc");
                 if constexpr (OP == 18) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r[i]));
+                if constexpr (OP == 19) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(r[i]) : "v"(c));
+                if constexpr (OP == 20) asm volatile("v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "+v"(r[i]) : "v"(c));
+                if constexpr (OP == 21) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "v"(d));
+                if constexpr (OP == 22) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "v"(d));
+                if constexpr (OP == 23) asm volatile("v_max_i32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                if constexpr (OP == 24) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                if constexpr (OP == 25) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                if constexpr (OP == 26) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                if constexpr (OP == 27) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r[i]) : "v"(r[(i + 3) & 7]));
+                if constexpr (OP == 28) asm volatile("v_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r[i]) : "v"(r[(i + 3) & 7]), "v"(c));
             }
         }
     }
@@ -67,6 +77,10 @@ int main() {
     run<2>("v_alignbit_b32", 1, out); run<12>("v_alignbyte_b32", 1, out); run<13>("v_lshl_or_b32", 1, out);
     run<3>("v_lshl_add_u64", 1, out); run<4>("v_lshrrev_b64", 1, out); run<5>("v_mad_u32_u24", 1, out);
     run<6>("v_add_co+v_addc_co", 2, out); run<16>("v_add_co_u32", 1, out); run<17>("v_addc_co_u32", 1, out);
+    run<19>("v_add_u32_sdwa byte", 1, out); run<20>("v_add_u32_sdwa sext", 1, out); run<21>("v_max3_i32", 1, out);
+    run<22>("v_perm_b32", 1, out); run<23>("v_max_i32", 1, out); run<24>("v_add_u32", 1, out);
+    run<25>("v_pk_max_i16", 1, out); run<26>("v_pk_add_i16", 1, out);
+    run<27>("v_mov_b32_dpp wave_shr", 1, out); run<28>("v_and_b32_dpp wave_shr", 1, out);
     run<7>("v_cndmask_b32 vcc", 1, out); run<8>("v_bfe_u32", 1, out); run<9>("v_and_or_b32", 1, out); run<10>("v_add3_u32", 1, out);
     return 0;
 }

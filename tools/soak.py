@@ -59,6 +59,9 @@ def main():
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     scope = sw.DeviceScope(gpu_device=0)
+    piped = sw.DeviceScope(gpu_device=0)
+    piped.set_async(True)
+    piped.set_pipelined(True)
     t0, rounds, pairs_total = time.time(), 0, 0
     while time.time() - t0 < args.seconds:
         kind = str(rng.choice(["lev", "lev", "lev_utf8", "nw", "sw"]))
@@ -76,6 +79,19 @@ def main():
                 got = engine.pairs(a, b, scope, bound=bound)
                 bad = np.nonzero(got != want)[0]
                 assert bad.size == 0, (kind, algorithm, bound, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+            if rounds % 4 == 0:   # the same batch through the pipelined lanes: device tapes, device outputs, 32-bit offsets
+                import torch
+                a32, b32 = a.with_offsets(np.uint32), b.with_offsets(np.uint32)
+                da, db = a32.to_device(piped), b32.to_device(piped)
+                outs = [torch.zeros(len(a), dtype=torch.int32, device="cuda") for _ in range(4)]
+                lane_engine = cls(capabilities=piped, algorithm=algorithm)
+                for out in outs:
+                    lane_engine.pairs(da, db, piped, bound=bound, out=out)
+                piped.synchronize()
+                for out in outs:
+                    got = out.cpu().numpy().astype(np.uint32)
+                    bad = np.nonzero(got != want)[0]
+                    assert bad.size == 0, ("pipelined", kind, algorithm, bound, bad[:5], got[bad[:5]], want[bad[:5]])
         else:
             classes = int(rng.choice([2, 4, 8, 9, 21, 24, 25, 32, 256]))
             alphabet = np.arange(classes if classes < 256 else 256, dtype=np.uint32) + (65 if classes <= 32 else 0)

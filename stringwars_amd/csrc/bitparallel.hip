@@ -79,6 +79,7 @@ struct GroupTables3 {
     uint32_t tbase, mask;
     __device__ __forceinline__ void init(uint32_t *table, int lane) {
         tbase = (uint32_t)(uintptr_t)(lds_u32 *)(table + lane);
+        if (tbase & 0x700u) __builtin_trap();   // layout assumption (see NibbleTables)
         mask = 0x700u;
         asm volatile("" : "+v"(mask));
     }

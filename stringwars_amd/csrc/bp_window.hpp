@@ -83,6 +83,7 @@ struct NibbleTables {
     uint32_t tbase, mask;
     __device__ __forceinline__ void init(uint32_t *table, int lane) {
         tbase = (uint32_t)(uintptr_t)(lds_u32 *)(table + lane);
+        if (tbase & 0xF00u) __builtin_trap();   // the layout assumption above: fail loudly, never score with wrong tables
         mask = 0xF00u;
         asm volatile("" : "+v"(mask));   // keep it in a register: three distinct registers is the fast form of v_bitop3
     }

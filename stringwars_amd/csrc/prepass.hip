@@ -13,6 +13,8 @@
 //
 // Also here: UTF-8 -> code point staging (k_utf8_count / k_utf8_write) and a small device scan.
 #include "common.hpp"
+#include <cstring>
+#include <cstdlib>
 #include "bp_window.hpp"
 
 namespace swh {
@@ -890,6 +892,38 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t *count
     if (i == n - 1) offsets[n] = excl + v;
 }
 
+// The same exclusive scan in ONE launch for up to 64 K counts (a 0.5 GB tape): each of 1024 threads sums a run of
+// consecutive counts, the run totals are scanned across the block (six DPP adds per wave + 16 wave totals), and each
+// thread writes its run's prefixes. Three launches and their gaps cost more than this kernel at these sizes.
+constexpr uint64_t kScanOneMax = 64 * 1024;
+__global__ __launch_bounds__(kScanBlock) void k_scan_one(const uint32_t *counts, uint64_t n, uint64_t *offsets) {
+    __shared__ unsigned long long wave_tot[kScanBlock / 64];
+    const uint32_t per = (uint32_t)((n + kScanBlock - 1) / kScanBlock);   // <= 64
+    const uint64_t first = (uint64_t)threadIdx.x * per;
+    unsigned long long sum = 0;
+    for (uint32_t k = 0; k < per; ++k) sum += first + k < n ? counts[first + k] : 0;
+    // inclusive scan of the run totals: within the wave by shuffles (64-bit), across waves through LDS
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long up = __shfl_up(incl, off);
+        if ((int)(threadIdx.x & 63) >= off) incl += up;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wave_tot[w];
+    unsigned long long run = base + incl - sum;
+    for (uint32_t k = 0; k < per; ++k) {
+        if (first + k < n) { offsets[first + k] = run; run += counts[first + k]; }
+    }
+    if (threadIdx.x == kScanBlock - 1) {
+        unsigned long long total = 0;
+        for (uint32_t w = 0; w < kScanBlock / 64; ++w) total += wave_tot[w];
+        offsets[n] = total;
+    }
+}
+
 void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
     hipStream_t stream = scope->stream;
     const uint64_t n = args.in.count, total = args.total_bytes;
@@ -909,10 +943,16 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
         uint32_t nblocks = (uint32_t)((tiles + kScanBlock - 1) / kScanBlock);
         {
             StampGuard guard(scope, "utf8_scan");
-            hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(kScanBlock), 0, stream, tile_counts, tiles, block_sums);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, stream, block_sums, nblocks);
-            hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, stream, tile_counts, tiles, block_sums,
-                               tile_prefix);
+            // STRINGWARS_AMD_UTF8_SCAN=split forces the three-kernel scan (what tapes beyond 0.5 GB take; tests use it)
+            static const bool split_scan = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_SCAN"); return e && !strcmp(e, "split"); }();
+            if (tiles <= kScanOneMax && !split_scan) {
+                hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(kScanBlock), 0, stream, tile_counts, tiles, tile_prefix);
+            } else {
+                hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(kScanBlock), 0, stream, tile_counts, tiles, block_sums);
+                hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, stream, block_sums, nblocks);
+                hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(kScanBlock), 0, stream, tile_counts, tiles, block_sums,
+                                   tile_prefix);
+            }
         }
         {
             StampGuard guard(scope, "utf8_tile_write");

@@ -550,6 +550,24 @@ def test_utf8_validation_matches_the_oracle(sw, orc, scope):
         assert engine.pairs([s], [b"a" * lead + b"b"], scope).tolist() == [1]
 
 
+def test_utf8_three_kernel_scan_path(orc):
+    """Tapes beyond 0.5 GB scan their tile counts with three kernels instead of one; STRINGWARS_AMD_UTF8_SCAN=split
+    selects that path for any size (read once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, stringwars_amd as sw, oracle\n"
+        "a, b = sw.generate_pairs('utf8_lines', 3000, seed=5)\n"
+        "scope = sw.DeviceScope(gpu_device=0)\n"
+        "got = sw.LevenshteinDistancesUTF8(capabilities=scope).pairs(a, b, scope, bound=40)\n"
+        "want = oracle.levenshtein_pairs(a, b, utf8=True, bound=40)\n"
+        "assert (got == want).all()\n"
+        "print('split-scan ok')\n")
+    env = dict(os.environ, STRINGWARS_AMD_UTF8_SCAN="split", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0 and "split-scan ok" in done.stdout, done.stderr[-2000:]
+
+
 def test_edge_cases_and_errors(sw, orc, scope):
     engine = sw.LevenshteinDistances(capabilities=scope)
     assert engine.pairs([], [], scope).size == 0

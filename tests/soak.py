@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomized parity soak on the GPU: batches with mixed length regimes, alphabets, bounds and engines, every result
-compared with the CPU oracle (test infrastructure) bit for bit. Not part of the pytest suite (minutes, not seconds).
+compared with the CPU oracle bit for bit. Lives under tests/ (the oracle is test infrastructure) but is not collected
+by pytest: minutes, not seconds.
 
-    python tools/soak.py --seconds 240 --seed 1
+    python tests/soak.py --seconds 240 --seed 1
 """
 import argparse
 import os

@@ -11,6 +11,7 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t seed
     uint64_t w[8];
     for (int i = 0; i < 8; ++i) { r[i] = seed * (threadIdx.x + 1) + i; w[i] = ((uint64_t)r[i] << 32) | (r[i] ^ 0x55u); }
     uint32_t c = seed | 1, d = seed * 7 + 3;
+    unsigned long long smask = 0x5555555555555555ull ^ seed;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int rep = 0; rep < 8; ++rep) {
@@ -43,6 +44,12 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t seed
                 if constexpr (OP == 24) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
                 if constexpr (OP == 25) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(r[i]) : "v"(c));
                 if constexpr (OP == 26) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                if constexpr (OP == 29) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(c) : "vcc");
+                if constexpr (OP == 30) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "s"(smask));
+                if constexpr (OP == 31) asm volatile("v_cmp_lt_u32_e64 %2, %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "s"(smask));
+                if constexpr (OP == 32) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(r[i]), "v"(c) : "vcc");
+                if constexpr (OP == 33) asm volatile("v_cmp_lt_i64 vcc, %0, %1" : : "v"(w[i]), "v"(w[(i + 1) & 7]) : "vcc");
+                if constexpr (OP == 34) asm volatile("v_min_u32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
                 if constexpr (OP == 27) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r[i]) : "v"(r[(i + 3) & 7]));
                 if constexpr (OP == 28) asm volatile("v_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r[i]) : "v"(r[(i + 3) & 7]), "v"(c));
             }
@@ -81,6 +88,8 @@ int main() {
     run<22>("v_perm_b32", 1, out); run<23>("v_max_i32", 1, out); run<24>("v_add_u32", 1, out);
     run<25>("v_pk_max_i16", 1, out); run<26>("v_pk_add_i16", 1, out);
     run<27>("v_mov_b32_dpp wave_shr", 1, out); run<28>("v_and_b32_dpp wave_shr", 1, out);
-    run<7>("v_cndmask_b32 vcc", 1, out); run<8>("v_bfe_u32", 1, out); run<9>("v_and_or_b32", 1, out); run<10>("v_add3_u32", 1, out);
+    run<7>("v_cndmask_b32 vcc (vcc never written)", 1, out); run<29>("v_cmp + v_cndmask vcc", 2, out);
+    run<30>("v_cndmask_b32_e64 sgpr", 1, out); run<31>("v_cmp_e64 + v_cndmask_e64", 2, out);
+    run<32>("v_cmp_lt_u32 vcc", 1, out); run<33>("v_cmp_lt_i64 vcc", 1, out); run<34>("v_min_u32", 1, out); run<8>("v_bfe_u32", 1, out); run<9>("v_and_or_b32", 1, out); run<10>("v_add3_u32", 1, out);
     return 0;
 }

@@ -89,11 +89,15 @@ struct NibbleTables {
     }
     // x holds the symbol in byte U
     template <int U> __device__ __forceinline__ uint32_t lo_addr(uint32_t x) const {
-        const uint32_t s = U == 0 ? x << 8 : (U == 1 ? x : x >> (8 * U - 8));
+        uint32_t s = x;
+        if constexpr (U == 0) s = x << 8;
+        else if constexpr (U > 1) s = x >> (8 * U - 8);
         return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask, (int)tbase, 0xEA);
     }
     template <int U> __device__ __forceinline__ uint32_t hi_addr(uint32_t x) const {
-        const uint32_t s = U == 0 ? x << 4 : x >> (8 * U - 4);
+        uint32_t s;
+        if constexpr (U == 0) s = x << 4;
+        else s = x >> (8 * U - 4);
         return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask, (int)tbase, 0xEA);
     }
     template <int U> __device__ __forceinline__ uint32_t lookup(uint32_t x) const {

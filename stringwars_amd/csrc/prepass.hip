@@ -280,6 +280,20 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_scatter(PrepassArgs args)
     }
 }
 
+// Maximum over the 64 lanes of a wave, broadcast: four row_shr steps inside each row of 16, row_bcast 15 / 31 across
+// rows, then lane 63 holds the maximum.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define SWH_MAX_DPP(CTRL, ROWS, BOUND)                                                              \
+    do {                                                                                            \
+        const uint32_t o__ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, BOUND); \
+        v = o__ > v ? o__ : v;                                                                      \
+    } while (0)
+    SWH_MAX_DPP(0x111, 0xf, true); SWH_MAX_DPP(0x112, 0xf, true); SWH_MAX_DPP(0x114, 0xf, true); SWH_MAX_DPP(0x118, 0xf, true);
+    SWH_MAX_DPP(0x142, 0xa, false); SWH_MAX_DPP(0x143, 0xc, false);
+#undef SWH_MAX_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // One pair per lane in tape order; both strings <= 32 bytes. The recurrence is the single-block case of
 // bitparallel.hip (no systolic hand-off): the longer string is the pattern (a table update per byte is cheaper than a
 // DP column per byte). Memory is software-pipelined two rounds deep: while round r computes, the strings of round
@@ -368,13 +382,9 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
         }
         if (__any(cur.direct)) {
             const uint32_t m = cur.m, n = cur.n;
-            uint32_t m_max = m, n_max = n;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                uint32_t om = __shfl_xor(m_max, off), on = __shfl_xor(n_max, off);
-                m_max = om > m_max ? om : m_max;
-                n_max = on > n_max ? on : n_max;
-            }
+            // wave maxima of the two lengths (both <= 32) in one reduction, by DPP (no LDS crossbar traffic)
+            // wave maxima of the two lengths by DPP (no LDS crossbar traffic)
+            const uint32_t m_max = wave_max_u32(m), n_max = wave_max_u32(n);
             if constexpr (kWide) {   // windows the clamp had to move (first / last strings of a tape): re-read by dword
                 uint32_t half[4];
 #pragma unroll
@@ -387,14 +397,16 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
                     }
                 }
             }
+            const uint32_t row_mask = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if ((uint32_t)q * 4 >= m_max) break;
+                // rows past the pattern OR in a zero: no branch per byte
                 const uint32_t dw = words.pw[q];
-                if ((uint32_t)(q * 4 + 0) < m) nib.template insert<0>(dw, 1u << (q * 4 + 0));
-                if ((uint32_t)(q * 4 + 1) < m) nib.template insert<1>(dw, 1u << (q * 4 + 1));
-                if ((uint32_t)(q * 4 + 2) < m) nib.template insert<2>(dw, 1u << (q * 4 + 2));
-                if ((uint32_t)(q * 4 + 3) < m) nib.template insert<3>(dw, 1u << (q * 4 + 3));
+                nib.template insert<0>(dw, row_mask & (1u << (q * 4 + 0)));
+                nib.template insert<1>(dw, row_mask & (1u << (q * 4 + 1)));
+                nib.template insert<2>(dw, row_mask & (1u << (q * 4 + 2)));
+                nib.template insert<3>(dw, row_mask & (1u << (q * 4 + 3)));
             }
             uint32_t pv = 0xFFFFFFFFu, mv = 0;
 #pragma unroll

@@ -94,12 +94,7 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
             if (lane < P) params[lane] = bp;
         }
         wave_lds_fence();  // params are read by other lanes in phase 1
-        uint32_t n_max = have ? len2 : 0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            uint32_t other = __shfl_xor(n_max, off);
-            n_max = other > n_max ? other : n_max;
-        }
+        const uint32_t n_max = wave_max_u32(have ? len2 : 0);
         // recurrence state of my pair (phase 2): rows 0..dhi of column 0 carry vertical +1
         uint32_t vp_lo, vp_hi, vn_lo = 0, vn_hi = 0;
         {

@@ -279,12 +279,7 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
         BP_STAMP(1, true);   // string loads + table build
 
         // wave-uniform step count (lane `blk` of a pair works in steps blk .. n + blk - 1)
-        uint32_t n_eff = have ? n + G - 1 : 0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            uint32_t other = __shfl_xor(n_eff, off);
-            n_eff = other > n_eff ? other : n_eff;
-        }
+        const uint32_t n_eff = wave_max_u32(have ? n + G - 1 : 0);
         const uint32_t steps = (n_eff + 15) & ~15u;
 
         // Lanes that start a pair take the DP boundary (+1 horizontal delta) instead of a neighbour. The masks are

@@ -68,6 +68,20 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Maximum over the 64 lanes of a wave, broadcast: four row_shr steps inside each row of 16, row_bcast 15 / 31 across
+// rows, then lane 63 holds the maximum.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define SWH_MAX_DPP(CTRL, ROWS, BOUND)                                                              \
+    do {                                                                                            \
+        const uint32_t o__ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, BOUND); \
+        v = o__ > v ? o__ : v;                                                                      \
+    } while (0)
+    SWH_MAX_DPP(0x111, 0xf, true); SWH_MAX_DPP(0x112, 0xf, true); SWH_MAX_DPP(0x114, 0xf, true); SWH_MAX_DPP(0x118, 0xf, true);
+    SWH_MAX_DPP(0x142, 0xa, false); SWH_MAX_DPP(0x143, 0xc, false);
+#undef SWH_MAX_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Bit-parallel orientation: the "pattern" string supplies the 32-row blocks (lanes), the "text" string the steps.
 // Work is blocks x (text + blocks - 1) block-steps, so the cheaper assignment wins -- usually the LONGER string
 // as pattern when both need the same number of blocks (fewer steps), the shorter one when it saves a block.

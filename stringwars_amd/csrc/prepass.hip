@@ -280,20 +280,6 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_scatter(PrepassArgs args)
     }
 }
 
-// Maximum over the 64 lanes of a wave, broadcast: four row_shr steps inside each row of 16, row_bcast 15 / 31 across
-// rows, then lane 63 holds the maximum.
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#define SWH_MAX_DPP(CTRL, ROWS, BOUND)                                                              \
-    do {                                                                                            \
-        const uint32_t o__ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, BOUND); \
-        v = o__ > v ? o__ : v;                                                                      \
-    } while (0)
-    SWH_MAX_DPP(0x111, 0xf, true); SWH_MAX_DPP(0x112, 0xf, true); SWH_MAX_DPP(0x114, 0xf, true); SWH_MAX_DPP(0x118, 0xf, true);
-    SWH_MAX_DPP(0x142, 0xa, false); SWH_MAX_DPP(0x143, 0xc, false);
-#undef SWH_MAX_DPP
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // One pair per lane in tape order; both strings <= 32 bytes. The recurrence is the single-block case of
 // bitparallel.hip (no systolic hand-off): the longer string is the pattern (a table update per byte is cheaper than a
 // DP column per byte). Memory is software-pipelined two rounds deep: while round r computes, the strings of round

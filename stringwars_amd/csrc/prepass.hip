@@ -325,15 +325,26 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
             w.moved[0] = sp.pat.fetch16_raw(0, half);
 #pragma unroll
             for (int q = 0; q < 4; ++q) w.pw[q] = half[q];
-            w.moved[1] = sp.pat.fetch16_raw(16, half);
+            // bytes 16..31 only when some lane's string is that long (word lists: hardly ever)
+            w.moved[1] = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w.pw[4 + q] = half[q];
+            for (int q = 0; q < 4; ++q) w.pw[4 + q] = 0;
+            if (__any(sp.m > 16)) {
+                w.moved[1] = sp.pat.fetch16_raw(16, half);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w.pw[4 + q] = half[q];
+            }
             w.moved[2] = sp.txt.fetch16_raw(0, half);
 #pragma unroll
             for (int q = 0; q < 4; ++q) w.tw[q] = half[q];
-            w.moved[3] = sp.txt.fetch16_raw(16, half);
+            w.moved[3] = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w.tw[4 + q] = half[q];
+            for (int q = 0; q < 4; ++q) w.tw[4 + q] = 0;
+            if (__any(sp.n > 16)) {
+                w.moved[3] = sp.txt.fetch16_raw(16, half);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w.tw[4 + q] = half[q];
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) { w.pw[q] = sp.pat.fetch4(q * 4); w.tw[q] = sp.txt.fetch4(q * 4); }

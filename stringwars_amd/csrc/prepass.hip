@@ -295,8 +295,11 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (args.job.pairs + stride - 1) / stride;  // wave-uniform trip count
     const uint64_t lane_first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    struct Short { bool inside, direct, trivial; uint64_t p; int64_t trivial_value; uint32_t la, lb, m, n; ByteWindow pat, txt; };
+    // `safe`: both 32-byte windows of the pair lie inside their tapes, so they can be read as they are; the clamped
+    // ByteWindow machinery (64-bit bounds per string) is only built for the first / last strings of a tape.
+    struct Short { bool inside, direct, trivial, a_is_pattern, safe; uint64_t p, p0, t0; int64_t trivial_value; uint32_t la, lb, m, n; };
     struct Words { uint32_t pw[8], tw[8]; int moved[4]; };
+    const uint8_t *a_data = (const uint8_t *)args.job.a.data, *b_data = (const uint8_t *)args.job.b.data;
     auto open_pair = [&](uint64_t round) -> Short {
         Short sp;
         sp.p = round * stride + lane_first;
@@ -310,44 +313,57 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
         sp.la = inside ? info.la : 0;
         sp.lb = inside ? info.lb : 0;
         sp.direct = inside && short_pair(info);
-        const bool a_is_pattern = info.la >= info.lb;
-        sp.m = sp.direct ? (a_is_pattern ? info.la : info.lb) : 0;
-        sp.n = sp.direct ? (a_is_pattern ? info.lb : info.la) : 0;
-        sp.pat.init((const uint8_t *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? info.a0 : info.b0,
-                    a_is_pattern ? a_total : b_total);
-        sp.txt.init((const uint8_t *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? info.b0 : info.a0,
-                    a_is_pattern ? b_total : a_total);
+        sp.a_is_pattern = info.la >= info.lb;
+        sp.m = sp.direct ? (sp.a_is_pattern ? info.la : info.lb) : 0;
+        sp.n = sp.direct ? (sp.a_is_pattern ? info.lb : info.la) : 0;
+        sp.p0 = sp.a_is_pattern ? info.a0 : info.b0;
+        sp.t0 = sp.a_is_pattern ? info.b0 : info.a0;
+        sp.safe = info.a0 + 32 <= a_total && info.b0 + 32 <= b_total;   // lanes without a pair: offsets 0
         return sp;
     };
+    auto windows = [&](const Short &sp, ByteWindow &pat, ByteWindow &txt) {
+        pat.init(sp.a_is_pattern ? a_data : b_data, sp.p0, sp.a_is_pattern ? a_total : b_total);
+        txt.init(sp.a_is_pattern ? b_data : a_data, sp.t0, sp.a_is_pattern ? b_total : a_total);
+    };
     auto request = [&](const Short &sp, Words &w) {
+        if (kWide && __all(sp.safe)) {
+            const uint8_t *pp = (sp.a_is_pattern ? a_data : b_data) + sp.p0, *tp = (sp.a_is_pattern ? b_data : a_data) + sp.t0;
+            uint4 v;
+            __builtin_memcpy(&v, pp, 16);
+            w.pw[0] = v.x; w.pw[1] = v.y; w.pw[2] = v.z; w.pw[3] = v.w;
+            __builtin_memcpy(&v, tp, 16);
+            w.tw[0] = v.x; w.tw[1] = v.y; w.tw[2] = v.z; w.tw[3] = v.w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { w.pw[4 + q] = 0; w.tw[4 + q] = 0; w.moved[q] = 0; }
+            if (__any(sp.m > 16)) {   // bytes 16..31 only when some lane's string is that long (word lists: hardly ever)
+                __builtin_memcpy(&v, pp + 16, 16);
+                w.pw[4] = v.x; w.pw[5] = v.y; w.pw[6] = v.z; w.pw[7] = v.w;
+            }
+            if (__any(sp.n > 16)) {
+                __builtin_memcpy(&v, tp + 16, 16);
+                w.tw[4] = v.x; w.tw[5] = v.y; w.tw[6] = v.z; w.tw[7] = v.w;
+            }
+            return;
+        }
+        ByteWindow pat, txt;
+        windows(sp, pat, txt);
         if constexpr (kWide) {
             uint32_t half[4];
-            w.moved[0] = sp.pat.fetch16_raw(0, half);
+            w.moved[0] = pat.fetch16_raw(0, half);
 #pragma unroll
             for (int q = 0; q < 4; ++q) w.pw[q] = half[q];
-            // bytes 16..31 only when some lane's string is that long (word lists: hardly ever)
-            w.moved[1] = 0;
+            w.moved[1] = pat.fetch16_raw(16, half);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w.pw[4 + q] = 0;
-            if (__any(sp.m > 16)) {
-                w.moved[1] = sp.pat.fetch16_raw(16, half);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w.pw[4 + q] = half[q];
-            }
-            w.moved[2] = sp.txt.fetch16_raw(0, half);
+            for (int q = 0; q < 4; ++q) w.pw[4 + q] = half[q];
+            w.moved[2] = txt.fetch16_raw(0, half);
 #pragma unroll
             for (int q = 0; q < 4; ++q) w.tw[q] = half[q];
-            w.moved[3] = 0;
+            w.moved[3] = txt.fetch16_raw(16, half);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w.tw[4 + q] = 0;
-            if (__any(sp.n > 16)) {
-                w.moved[3] = sp.txt.fetch16_raw(16, half);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w.tw[4 + q] = half[q];
-            }
+            for (int q = 0; q < 4; ++q) w.tw[4 + q] = half[q];
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { w.pw[q] = sp.pat.fetch4(q * 4); w.tw[q] = sp.txt.fetch4(q * 4); }
+            for (int q = 0; q < 8; ++q) { w.pw[q] = pat.fetch4(q * 4); w.tw[q] = txt.fetch4(q * 4); }
 #pragma unroll
             for (int q = 0; q < 4; ++q) w.moved[q] = 0;
         }
@@ -388,7 +404,9 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
                 for (int h = 0; h < 4; ++h) {
                     uint32_t *dst = h < 2 ? words.pw + 4 * h : words.tw + 4 * (h - 2);
                     if (__builtin_expect(words.moved[h] != 0, 0)) {
-                        (h < 2 ? cur.pat : cur.txt).fix16(16 * (h & 1), words.moved[h], half);
+                        ByteWindow pat, txt;
+                        windows(cur, pat, txt);
+                        (h < 2 ? pat : txt).fix16(16 * (h & 1), words.moved[h], half);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) dst[q] = half[q];
                     }

@@ -50,6 +50,7 @@ struct RowStream<uint8_t> {
     int avail;            // readable symbols relative to base (total - start)
     bool tiny;            // tape shorter than 4 bytes: bytewise path
     uint32_t cur, nxt;
+    int nxt_shift;        // realignment of `nxt`, applied where it is consumed (next to the load it would expose the latency)
     __device__ __forceinline__ void init(const uint8_t *data, uint64_t start, uint64_t total) {
         base = data + start;
         tiny = total < 4;
@@ -59,25 +60,31 @@ struct RowStream<uint8_t> {
         int64_t av = (int64_t)total - (int64_t)start;
         avail = (int)(av > 0x40000000ll ? 0x40000000ll : av);
         cur = nxt = 0;
+        nxt_shift = 24;
     }
-    __device__ __forceinline__ uint32_t fetch(int idx) const {
+    // bytes idx..idx+3 as loaded (clamped into the tape) plus the shift that puts byte idx first
+    __device__ __forceinline__ void prefetch(int idx) {
         if (!tiny) {
             int c = med3i(idx, lo, hi);
-            uint32_t dw;
-            __builtin_memcpy(&dw, base + c, 4);
-            int d = med3i(idx - c, -3, 3);
-            return d >= 0 ? dw >> (8 * d) : dw << (-8 * d);
+            __builtin_memcpy(&nxt, base + c, 4);
+            nxt_shift = 8 * med3i(idx - c, -3, 3) + 24;
+            return;
         }
         uint32_t dw = 0;
         for (int u = 0; u < 4; ++u) {
             int pos = idx + u;
             if (pos >= lo && pos < avail) dw |= (uint32_t)base[pos] << (8 * u);
         }
-        return dw;
+        nxt = dw;
+        nxt_shift = 24;
     }
-    __device__ __forceinline__ void prefetch(int idx) { nxt = fetch(idx); }
-    __device__ __forceinline__ void advance() { cur = nxt; }
+    __device__ __forceinline__ uint32_t realigned_next() const {
+        return (uint32_t)((((unsigned long long)nxt) << 24) >> (uint32_t)nxt_shift);
+    }
+    __device__ __forceinline__ void advance() { cur = realigned_next(); }
     __device__ __forceinline__ uint32_t sym(int u) const { return (cur >> (8 * u)) & 0xffu; }
+    // row symbol of the step after u (u = 3: first symbol of the prefetched word)
+    __device__ __forceinline__ uint32_t sym_after(int u) const { return u < 3 ? sym(u + 1) : (realigned_next() & 0xffu); }
 };
 
 template <>
@@ -101,6 +108,7 @@ struct RowStream<uint32_t> {
         for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     }
     __device__ __forceinline__ uint32_t sym(int u) const { return cur[u]; }
+    __device__ __forceinline__ uint32_t sym_after(int u) const { return u < 3 ? cur[u + 1] : nxt[0]; }
 };
 
 // Result plumbing shared with the bit-parallel kernel.
@@ -263,6 +271,15 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                         ebnd_next[u] = __hip_atomic_load(bnd_e + 1 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            // class model: the cost row of the NEXT step's row symbol is fetched (byte -> class, then 32 bytes of costs:
+            // two dependent LDS round trips) while the current step's W cells are computed
+            [[maybe_unused]] uint4 row_lo_next{0, 0, 0, 0}, row_hi_next{0, 0, 0, 0};
+            [[maybe_unused]] auto fetch_cost_row = [&](uint32_t row_sym) {
+                const uint32_t rc = lclass_of[row_sym & 0xffu];
+                row_lo_next = *(const uint4 *)(smem + rc * 32);
+                if constexpr (PQ > 2) row_hi_next = *(const uint4 *)(smem + rc * 32 + 16);
+            };
+            if constexpr (kClass) fetch_cost_row(stream.realigned_next());   // step 0's symbol = byte 0 of the first word
             for (uint32_t s0 = 0; s0 < steps; s0 += 4) {
                 stream.advance();
                 stream.prefetch((int)s0 + 4 - gl);
@@ -286,6 +303,11 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                     int recv_e = kNegInf;
                     if constexpr (kAffine) recv_e = dpp_shift_up<G>(pass == 0 ? kNegInf : ebnd_cur[u], out_e);
                     const uint32_t sym = stream.sym(u);
+                    [[maybe_unused]] uint4 row_lo_cur, row_hi_cur;
+                    if constexpr (kClass) {
+                        row_lo_cur = row_lo_next; row_hi_cur = row_hi_next;
+                        fetch_cost_row(stream.sym_after(u));
+                    }
                     if (s - (uint32_t)gl < rows) {  // active: DP row r = s - gl + 1
                         int diag = prev_h, left = recv_h, e = recv_e;
                         [[maybe_unused]] const int bias2 = -2 * ext;   // skewed models use substitution scores as sub - 2 ext (ext == open when linear)
@@ -319,10 +341,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                         if constexpr (kClass) {
                             // one 32-byte cost row per step (the row symbol's class), then bytes are picked in
                             // registers: no per-cell LDS traffic at all
-                            const uint32_t rc = lclass_of[sym & 0xffu];
-                            const uint4 r_lo = *(const uint4 *)(smem + rc * 32);
-                            uint4 r_hi{0, 0, 0, 0};
-                            if constexpr (PQ > 2) r_hi = *(const uint4 *)(smem + rc * 32 + 16);
+                            const uint4 r_lo = row_lo_cur, r_hi = row_hi_cur;
 #pragma unroll
                             for (int g4 = 0; g4 < W; g4 += 4) {
                                 const uint32_t *sg = sel + (g4 >> 2) * PQ;

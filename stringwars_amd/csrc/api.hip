@@ -368,9 +368,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 // one boundary column (H, E) per concurrently resident group
                 uint64_t stride = (uint64_t)(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb) + 64 + 16;
                 uint64_t groups = (uint64_t)scope->compute_units * 8 * 4;  // max blocks * waves (G = 64)
-                ensure(scope->boundary, scope->boundary_bytes, groups * stride * 2 * sizeof(int32_t));
+                // two areas: class kernels alternate between two streams and run side by side (launch_wavefront)
+                ensure(scope->boundary, scope->boundary_bytes, 2 * groups * stride * 2 * sizeof(int32_t));
                 k.boundary = (int32_t *)scope->boundary;
                 k.boundary_stride = stride;
+                scope->wf_side_boundary = groups * stride * 2;
             }
             launch_wavefront(scope, k, plan);
         }

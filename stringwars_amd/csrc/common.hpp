@@ -183,6 +183,11 @@ struct Scope {
     hipStream_t side_stream = nullptr;  // plan read-back overlaps the first DP kernel
     hipEvent_t plan_ready = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;   // second tape's UTF-8 decode runs on side_stream beside the first's
+    // wavefront class kernels alternate between the scope's stream and side_stream (launch_wavefront): each is a
+    // persistent grid with its own tail, and a 10 K-pair batch is only a few rounds of waves per kernel
+    hipStream_t wf_main = nullptr;
+    unsigned wf_toggle = 0;
+    uint64_t wf_side_boundary = 0;   // int32 elements between the two streams' boundary areas
     bool hint_short = true;     // the previous call saw short pairs: enqueue k_direct_short (first call: assume yes)
     // Pipelined mode: calls alternate between `lanes` (internal scopes with their own stream, scratch and plan
     // buffers), so the planning pre-pass of call i+1 overlaps the DP kernel of call i. Results are ordered for the

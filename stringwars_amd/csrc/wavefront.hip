@@ -442,8 +442,15 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
             attr_set = true;
         }
     }
+    // alternate streams between class kernels (see Scope::wf_main); the side stream's kernels get their own boundary area
+    KernelArgs launch_args = args;
+    if (scope->wf_main) {
+        const bool side = (scope->wf_toggle++ & 1u) != 0;
+        scope->stream = side ? scope->side_stream : scope->wf_main;
+        if (side && launch_args.boundary) launch_args.boundary += scope->wf_side_boundary;
+    }
     StampGuard guard(scope, name);
-    hipLaunchKernelGGL((k_wavefront<Sym, G, W, MODEL, PQ>), dim3(blocks), dim3(256), lds, scope->stream, args, cls);
+    hipLaunchKernelGGL((k_wavefront<Sym, G, W, MODEL, PQ>), dim3(blocks), dim3(256), lds, scope->stream, launch_args, cls);
 }
 
 // Tuning knob (STRINGWARS_AMD_WF_CAP=<columns per lane>): strips wider than the cap run as several passes of 32
@@ -523,7 +530,29 @@ static void launch_class_model(Scope *scope, const KernelArgs &args, const Plan 
                                            "wavefront_class_g64_w32_multipass");
 }
 
+static void launch_wavefront_classes(Scope *scope, const KernelArgs &args, const Plan &plan);
+
 void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan) {
+    // fork: the side stream starts where the main stream is now; join: the main stream waits for the side stream
+    hipStream_t main_stream = scope->stream;
+    SWH_HIP_CHECK(hipEventRecord(scope->fork_ev, main_stream));
+    SWH_HIP_CHECK(hipStreamWaitEvent(scope->side_stream, scope->fork_ev, 0));
+    scope->wf_main = main_stream;
+    scope->wf_toggle = 0;
+    try {
+        launch_wavefront_classes(scope, args, plan);
+    } catch (...) {
+        scope->stream = main_stream;
+        scope->wf_main = nullptr;
+        throw;
+    }
+    scope->stream = main_stream;
+    scope->wf_main = nullptr;
+    SWH_HIP_CHECK(hipEventRecord(scope->join_ev, scope->side_stream));
+    SWH_HIP_CHECK(hipStreamWaitEvent(main_stream, scope->join_ev, 0));
+}
+
+static void launch_wavefront_classes(Scope *scope, const KernelArgs &args, const Plan &plan) {
     bool matrix = args.scoring.matrix != nullptr;
     if (args.sym_bytes == 4) {
         launch_model<uint32_t, kUniformLinear>(scope, args, plan);

@@ -80,7 +80,7 @@ swh_status_t swh_scope_join(swh_scope_t scope, const char **error);
 typedef struct swh_timing_t {
     double total_ms;          /* all kernels of the last call, first-start to last-stop */
     double dominant_ms;       /* longest single kernel */
-    double compute_ms;        /* sum of the DP kernels (everything but the planning / staging pre-pass) */
+    double compute_ms;        /* time covered by the DP kernels (union of their intervals; everything but the planning / staging pre-pass) */
     char dominant_name[64];   /* its name */
     uint64_t cells;           /* nominal DP cells of the call (sum len_s(a)*len_s(b)) */
     uint64_t bytes;           /* algorithmic HBM bytes: symbols + offsets + results */

@@ -10,6 +10,8 @@
 #include <new>
 
 #include "common.hpp"
+#include <algorithm>
+#include <utility>
 
 namespace swh {
 
@@ -49,24 +51,41 @@ static void collect_timing(Scope *scope) {
     t.total_ms = 0; t.dominant_ms = 0; t.compute_ms = 0; t.dominant_name[0] = 0; t.kernels = (uint32_t)scope->stamps_used;
     if (!scope->stamps_used) return;
     float span = 0;
-    (void)hipEventElapsedTime(&span, scope->stamps[0].start, scope->stamps[scope->stamps_used - 1].stop);
+    for (size_t i = 0; i < scope->stamps_used; ++i) {   // the last kernel to finish need not be the last one launched
+        float to_stop = 0;
+        (void)hipEventElapsedTime(&to_stop, scope->stamps[0].start, scope->stamps[i].stop);
+        if (to_stop > span) span = to_stop;
+    }
     t.total_ms = span;
+    // DP kernels may run side by side on two streams (wavefront classes): compute_ms is the length of the UNION of
+    // their intervals, not the sum of their durations
+    std::vector<std::pair<float, float>> dp;
     for (size_t i = 0; i < scope->stamps_used; ++i) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, scope->stamps[i].start, scope->stamps[i].stop);
-        if (strncmp(scope->stamps[i].name, "plan_", 5) != 0 && strncmp(scope->stamps[i].name, "utf8_", 5) != 0)
-            t.compute_ms += ms;
+        if (strncmp(scope->stamps[i].name, "plan_", 5) != 0 && strncmp(scope->stamps[i].name, "utf8_", 5) != 0) {
+            float from = 0;
+            (void)hipEventElapsedTime(&from, scope->stamps[0].start, scope->stamps[i].start);
+            dp.emplace_back(from, from + ms);
+        }
         if (ms > t.dominant_ms) {
             t.dominant_ms = ms;
             snprintf(t.dominant_name, sizeof t.dominant_name, "%s", scope->stamps[i].name);
         }
     }
+    std::sort(dp.begin(), dp.end());
+    float covered = 0, reach = -1e30f;
+    for (const auto &iv : dp) {
+        if (iv.first > reach) { covered += iv.second - iv.first; reach = iv.second; }
+        else if (iv.second > reach) { covered += iv.second - reach; reach = iv.second; }
+    }
+    t.compute_ms = covered;
 }
 
 // Reads the events of the scope's last call once they are complete and adds the call to the running totals.
 static void harvest_timing(Scope *scope) {
     if (!scope->profiling || !scope->stamps_pending || !scope->stamps_used) { scope->stamps_pending = false; return; }
-    (void)hipEventSynchronize(scope->stamps[scope->stamps_used - 1].stop);
+    for (size_t i = 0; i < scope->stamps_used; ++i) (void)hipEventSynchronize(scope->stamps[i].stop);   // two streams: no single last event
     const uint64_t cells = scope->last_timing.cells, bytes = scope->last_timing.bytes;
     collect_timing(scope);
     scope->last_timing.cells = cells; scope->last_timing.bytes = bytes;

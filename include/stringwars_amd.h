@@ -68,10 +68,11 @@ swh_status_t swh_scope_compute_units(swh_scope_t scope, size_t *compute_units);
 swh_status_t swh_scope_set_async(swh_scope_t scope, int async);
 swh_status_t swh_scope_synchronize(swh_scope_t scope, const char **error);
 /* Pipelined mode (implies async): successive engine calls alternate between two internal lanes (stream + scratch), so
- * the planning pre-pass of one call overlaps the DP kernel of the previous one. Inputs must already be complete on the
- * device when a call is made. `swh_scope_join` makes the scope's own stream (the one given to
- * swh_scope_init_gpu_stream) wait for the latest call, for consumers ordered on that stream (e.g. an RCCL gather);
- * `swh_scope_synchronize` waits for everything. */
+ * the host-side planning of one call overlaps the DP kernel of the previous one. Ordering: a call starts after
+ * everything that was enqueued on the scope's own stream (the one given to swh_scope_init_gpu_stream) before it --
+ * producers of its inputs AND earlier consumers of the output buffer it overwrites. `swh_scope_join` makes that stream
+ * wait for the latest call, for consumers ordered on it (e.g. an RCCL gather); `swh_scope_synchronize` waits for
+ * everything. Buffers touched by streams the scope does not know about must be idle. */
 swh_status_t swh_scope_set_pipelined(swh_scope_t scope, int enabled, const char **error);
 swh_status_t swh_scope_join(swh_scope_t scope, const char **error);
 

@@ -42,6 +42,13 @@ lib.orc_nw_pairs.restype = C.c_long
 lib.orc_nw_pairs.argtypes = [_vp, _vp, _vp, _vp, C.c_int, C.c_size_t, C.c_size_t, _vp, C.c_int, C.c_int, _vp]
 lib.orc_lev_costs_pairs.restype = C.c_long
 lib.orc_lev_costs_pairs.argtypes = [_vp, _vp, _vp, _vp, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+lib.orc_align_score_general.restype = C.c_int64
+lib.orc_align_score_general.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_int, C.c_int, C.c_int]
+lib.orc_lev_antidiagonal.restype = C.c_uint32
+lib.orc_lev_antidiagonal.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t]
+for _n in ("orc_selfcheck_levenshtein", "orc_selfcheck_alignment"):
+    getattr(lib, _n).restype = C.c_long
+    getattr(lib, _n).argtypes = [C.c_uint64, C.c_size_t, C.c_uint32, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_uint64)]
 lib.orc_cells.restype = C.c_uint64
 lib.orc_cells.argtypes = [_vp, _vp, _vp, _vp, C.c_int, C.c_size_t, C.c_int]
 
@@ -84,6 +91,26 @@ def nw_score(a, b, matrix: np.ndarray, open: int, extend: int, local: bool = Fal
     m = np.ascontiguousarray(matrix, dtype=np.int8)
     fn = lib.orc_sw_score if local else lib.orc_nw_score
     return int(fn(a.ctypes.data, a.size, b.ctypes.data, b.size, m.ctypes.data, open, extend))
+
+
+def align_score_general(a, b, matrix: np.ndarray, open: int, extend: int, local: bool = False) -> int:
+    """The second, independent alignment scorer (Waterman-Smith-Beyer general-gap table, cubic)."""
+    a, b = _buf(a), _buf(b)
+    m = np.ascontiguousarray(matrix, dtype=np.int8)
+    return int(lib.orc_align_score_general(a.ctypes.data, a.size, b.ctypes.data, b.size, m.ctypes.data, open, extend, int(local)))
+
+
+def levenshtein_antidiagonal(a, b) -> int:
+    a, b = _buf(a), _buf(b)
+    return int(lib.orc_lev_antidiagonal(a.ctypes.data, a.size, b.ctypes.data, b.size))
+
+
+def selfcheck(kind: str, seed: int, cases: int, alphabet: int, max_len: int):
+    """Runs the C cross-check loop; returns (disagreements, index of the first one or -1, DP cells covered)."""
+    fn = lib.orc_selfcheck_levenshtein if kind == "levenshtein" else lib.orc_selfcheck_alignment
+    first, cells = C.c_long(-1), C.c_uint64(0)
+    bad = fn(seed, cases, alphabet, max_len, C.byref(first), C.byref(cells))
+    return int(bad), int(first.value), int(cells.value)
 
 
 def _width(offsets: np.ndarray) -> int:

@@ -261,6 +261,179 @@ ORC_API uint32_t orc_hyyro_bytes(const uint8_t *a, size_t la, const uint8_t *b, 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Second, independent alignment scorer: Waterman-Smith-Beyer 1976 general-gap DP over the FULL */
+/* (la+1) x (lb+1) table, O(la*lb*(la+lb)). No E/F state, no rolling rows: every cell looks back  */
+/* over every gap length k with gap(k) = open + (k-1)*extend spelled out. Shares nothing with    */
+/* orc_nw_score / orc_sw_score but the definition; tests cross-check the two on >= 1e5 cases.    */
+/* `local` != 0 gives the Smith-Waterman score (floor 0, maximum over all cells).               */
+/* ------------------------------------------------------------------------------------------ */
+ORC_API int64_t orc_align_score_general(const uint8_t *a, size_t la, const uint8_t *b, size_t lb,
+                                        const int8_t *subs, int open, int extend, int local) {
+    const size_t w = lb + 1;
+    int64_t *T = (int64_t *)malloc((la + 1) * w * sizeof(int64_t));
+    int64_t best_all = 0;
+    for (size_t i = 0; i <= la; ++i) {
+        for (size_t j = 0; j <= lb; ++j) {
+            int64_t v;
+            if (i == 0 && j == 0) v = 0;
+            else {
+                v = INT64_MIN / 4;
+                if (i && j) {
+                    int64_t d = T[(i - 1) * w + (j - 1)] + subs[(size_t)a[i - 1] * 256 + b[j - 1]];
+                    if (d > v) v = d;
+                }
+                for (size_t k = 1; k <= i; ++k) {   /* k symbols of `a` against a gap */
+                    int64_t g = T[(i - k) * w + j] + open + (int64_t)(k - 1) * extend;
+                    if (g > v) v = g;
+                }
+                for (size_t k = 1; k <= j; ++k) {   /* k symbols of `b` against a gap */
+                    int64_t g = T[i * w + (j - k)] + open + (int64_t)(k - 1) * extend;
+                    if (g > v) v = g;
+                }
+            }
+            if (local && v < 0) v = 0;
+            if (v > best_all) best_all = v;
+            T[i * w + j] = v;
+        }
+    }
+    int64_t r = local ? best_all : T[la * w + lb];
+    free(T);
+    return r;
+}
+
+/* Third Levenshtein implementation (independent of both above): the full (la+1) x (lb+1) table filled  */
+/* anti-diagonal by anti-diagonal -- the GPU kernels' traversal order, on the CPU.                     */
+ORC_API uint32_t orc_lev_antidiagonal(const uint8_t *a, size_t la, const uint8_t *b, size_t lb) {
+    const size_t w = lb + 1;
+    uint32_t *T = (uint32_t *)malloc((la + 1) * w * sizeof(uint32_t));
+    for (size_t d = 0; d <= la + lb; ++d) {
+        size_t i_lo = d > lb ? d - lb : 0, i_hi = d < la ? d : la;
+        for (size_t i = i_lo; i <= i_hi; ++i) {
+            size_t j = d - i;
+            uint32_t v;
+            if (i == 0) v = (uint32_t)j;
+            else if (j == 0) v = (uint32_t)i;
+            else {
+                uint32_t s = T[(i - 1) * w + j - 1] + (a[i - 1] != b[j - 1]);
+                uint32_t u = T[(i - 1) * w + j] + 1, l = T[i * w + j - 1] + 1;
+                v = s < u ? s : u;
+                v = v < l ? v : l;
+            }
+            T[i * w + j] = v;
+        }
+    }
+    uint32_t r = T[la * w + lb];
+    free(T);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Self-checks run by tests/test_oracle.py in a C loop (SURVEY 8c "beyond KATs" (i)): the        */
+/* implementations above must agree on seeded random inputs. Return the number of disagreeing   */
+/* cases; *first_bad receives the index of the first one (or -1); *cells the DP cells covered.  */
+/* ------------------------------------------------------------------------------------------ */
+static uint64_t orc_mix(uint64_t *state) {   /* SplitMix64 */
+    uint64_t z = (*state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static size_t orc_pick_length(uint64_t *rng, size_t max_len) {
+    static const uint16_t edges[] = {0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300};
+    uint64_t r = orc_mix(rng) % 100;
+    size_t len;
+    if (r < 55) len = orc_mix(rng) % 41;                 /* words */
+    else if (r < 80) len = 40 + orc_mix(rng) % 101;      /* tokens */
+    else if (r < 92) len = edges[orc_mix(rng) % (sizeof edges / sizeof edges[0])];   /* 64-bit word boundaries */
+    else len = orc_mix(rng) % (max_len + 1);
+    return len > max_len ? max_len : len;
+}
+static void orc_random_pair(uint64_t *rng, uint32_t alphabet, size_t max_len, uint8_t *a, size_t *la, uint8_t *b,
+                            size_t *lb) {
+    *la = orc_pick_length(rng, max_len);
+    for (size_t i = 0; i < *la; ++i) a[i] = (uint8_t)(orc_mix(rng) % alphabet);
+    if (orc_mix(rng) & 1) {   /* related: a with a few edits */
+        size_t n = *la;
+        memcpy(b, a, n);
+        uint64_t edits = orc_mix(rng) % 9;
+        for (uint64_t e = 0; e < edits; ++e) {
+            uint64_t op = orc_mix(rng) % 3;
+            if (op == 0 && n) b[orc_mix(rng) % n] = (uint8_t)(orc_mix(rng) % alphabet);
+            else if (op == 1 && n < max_len) {
+                size_t pos = orc_mix(rng) % (n + 1);
+                memmove(b + pos + 1, b + pos, n - pos);
+                b[pos] = (uint8_t)(orc_mix(rng) % alphabet);
+                ++n;
+            } else if (op == 2 && n) {
+                size_t pos = orc_mix(rng) % n;
+                memmove(b + pos, b + pos + 1, n - pos - 1);
+                --n;
+            }
+        }
+        *lb = n;
+    } else {
+        *lb = orc_pick_length(rng, max_len);
+        for (size_t i = 0; i < *lb; ++i) b[i] = (uint8_t)(orc_mix(rng) % alphabet);
+    }
+}
+
+/* Wagner-Fischer vs Hyyro bit-parallel (and, every 16th case, the anti-diagonal table) on `cases` pairs over   */
+/* `alphabet` symbols with lengths 0..max_len, incl. the 63/64/65 ... word boundaries.                            */
+ORC_API long orc_selfcheck_levenshtein(uint64_t seed, size_t cases, uint32_t alphabet, size_t max_len,
+                                       long *first_bad, uint64_t *cells) {
+    uint8_t *a = (uint8_t *)malloc(max_len + 1), *b = (uint8_t *)malloc(max_len + 1);
+    uint64_t rng = seed * 0xD1342543DE82EF95ull + alphabet;
+    long bad = 0;
+    *first_bad = -1;
+    *cells = 0;
+    for (size_t c = 0; c < cases; ++c) {
+        size_t la, lb;
+        orc_random_pair(&rng, alphabet, max_len, a, &la, b, &lb);
+        uint32_t wf = orc_lev_bytes(a, la, b, lb), hy = orc_hyyro_bytes(a, la, b, lb);
+        int ok = wf == hy && orc_hyyro_bytes(b, lb, a, la) == wf;
+        if ((c & 15) == 0) ok = ok && orc_lev_antidiagonal(a, la, b, lb) == wf;
+        *cells += (uint64_t)la * lb;
+        if (!ok) { if (!bad) *first_bad = (long)c; ++bad; }
+    }
+    free(a); free(b);
+    return bad;
+}
+
+/* Gotoh (orc_nw_score / orc_sw_score) vs the general-gap table on random strings over `alphabet` symbols,     */
+/* random i8 matrices (every 3rd asymmetric) and random gaps with |open| >= |extend| (the reference's          */
+/* settings, bench.rs:342, :353). With a gap that is cheaper to open than to extend the two differ by          */
+/* definition: Gotoh's boundary row / column is ONE gap of length i, the general-gap table may split it.        */
+ORC_API long orc_selfcheck_alignment(uint64_t seed, size_t cases, uint32_t alphabet, size_t max_len,
+                                     long *first_bad, uint64_t *cells) {
+    uint8_t *a = (uint8_t *)malloc(max_len + 1), *b = (uint8_t *)malloc(max_len + 1);
+    int8_t *subs = (int8_t *)malloc(65536);
+    uint64_t rng = seed * 0xA0761D6478BD642Full + alphabet;
+    long bad = 0;
+    *first_bad = -1;
+    *cells = 0;
+    for (size_t c = 0; c < cases; ++c) {
+        if (c % 64 == 0) {   /* a fresh matrix every 64 cases */
+            int asym = (c / 64) % 3 == 2;
+            for (uint32_t i = 0; i < alphabet; ++i)
+                for (uint32_t j = 0; j <= i; ++j) {
+                    int8_t v = (int8_t)(i == j ? (int)(orc_mix(&rng) % 12) : (int)(orc_mix(&rng) % 12) - 8);
+                    subs[i * 256 + j] = v;
+                    subs[j * 256 + i] = asym ? (int8_t)((int)(orc_mix(&rng) % 16) - 8) : v;
+                }
+        }
+        size_t la, lb;
+        orc_random_pair(&rng, alphabet, max_len, a, &la, b, &lb);
+        const int extend = -(int)(orc_mix(&rng) % 6), open = extend - (int)(orc_mix(&rng) % 12);
+        int ok = orc_nw_score(a, la, b, lb, subs, open, extend) == orc_align_score_general(a, la, b, lb, subs, open, extend, 0);
+        ok = ok && orc_sw_score(a, la, b, lb, subs, open, extend) == orc_align_score_general(a, la, b, lb, subs, open, extend, 1);
+        *cells += (uint64_t)la * lb;
+        if (!ok) { if (!bad) *first_bad = (long)c; ++bad; }
+    }
+    free(a); free(b); free(subs);
+    return bad;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Tape (Arrow-style: data + count+1 offsets) batch drivers. `offset_width` is 4 or 8 bytes.   */
 /* Return 0, or -(i+1) when pair i holds invalid UTF-8.                                        */
 /* ------------------------------------------------------------------------------------------ */

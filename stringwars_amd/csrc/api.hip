@@ -161,6 +161,12 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
     Scope *lane = scope->lanes[scope->next_lane];
     scope->next_lane ^= 1;
     scope->last_lane = lane;
+    // The lane starts where the caller's stream is now: whatever was enqueued there before this call -- the producer of
+    // the inputs, or a consumer still reading the output buffer this call is about to overwrite (an RCCL gather of an
+    // earlier step) -- completes first. swh_scope_join gives the other direction.
+    if (hipEventRecord(scope->order_ev, scope->stream) != hipSuccess ||
+        hipStreamWaitEvent(lane->stream, scope->order_ev, 0) != hipSuccess)
+        return fail(error, swh_device_error_k, "could not order a pipeline lane after the scope's stream");
     swh_status_t status = run_call_on(lane, engine, spec, error);
     if (status == swh_success_k && hipEventRecord(lane->lane_done, lane->stream) != hipSuccess)
         return fail(error, swh_device_error_k, "hipEventRecord failed on a pipeline lane");
@@ -383,6 +389,14 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             if (wavefront_strip_cap() && c >= kClassWf64 && wide_w(c - kClassWf64 < kNumWideW ? c - kClassWf64 : kNumWideW - 1) > wavefront_strip_cap()) multi = true;
         }
         if (any_wf) {
+            // int32 scores with a -2^29 "minus infinity": keep every reachable score well inside it
+            const uint64_t worst_step = std::max<uint64_t>({(uint64_t)std::abs(engine->scoring.open), (uint64_t)std::abs(engine->scoring.extend),
+                                                            (uint64_t)std::abs(engine->scoring.match), (uint64_t)std::abs(engine->scoring.mismatch),
+                                                            engine->scoring.matrix ? 128u : 0u});
+            if (worst_step * ((uint64_t)plan.max_la + plan.max_lb + 2) >= 0x10000000ull) {
+                SWH_HIP_CHECK(hipStreamSynchronize(stream));
+                return fail(error, swh_unsupported_length_k, "scores of this batch could leave the 32-bit range of the wavefront kernels (costs x lengths too large)");
+            }
             if (multi) {
                 // one boundary column (H, E) per concurrently resident group
                 uint64_t stride = (uint64_t)(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb) + 64 + 16;
@@ -489,6 +503,7 @@ swh_status_t swh_scope_free(swh_scope_t handle) {
     (void)hipSetDevice(scope->device);
     (void)hipStreamSynchronize(scope->stream);
     if (scope->lane_done) (void)hipEventDestroy(scope->lane_done);
+    if (scope->order_ev) (void)hipEventDestroy(scope->order_ev);
     for (auto &st : scope->stamps) { (void)hipEventDestroy(st.start); (void)hipEventDestroy(st.stop); }
     if (scope->scratch) (void)hipFree(scope->scratch);
     if (scope->stage) (void)hipFree(scope->stage);
@@ -534,6 +549,8 @@ swh_status_t swh_scope_set_pipelined(swh_scope_t handle, int enabled, const char
     swh_status_t status = swh_scope_synchronize(handle, error);
     if (status != swh_success_k) return status;
     if (enabled) {
+        if (!scope->order_ev && hipEventCreateWithFlags(&scope->order_ev, hipEventDisableTiming) != hipSuccess)
+            return fail(error, swh_device_error_k, "hipEventCreate failed for the pipeline");
         for (Scope *&lane : scope->lanes) {
             if (lane) continue;
             swh_scope_t created = nullptr;

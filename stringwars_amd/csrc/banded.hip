@@ -224,11 +224,7 @@ static void launch_banded_items(Scope *scope, const KernelArgs &args, uint64_t p
     uint32_t max_blocks = (uint32_t)scope->compute_units * (uint32_t)(160 * 1024 / lds);   // 77 KB (P = 64) / 41 KB per block
     uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
     if (!blocks) return;
-    static bool attr_set = false;  // one per instantiation
-    if (!attr_set) {
-        SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_banded<Sym, WBITS, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    opt_in_dynamic_lds(scope, (const void *)k_banded<Sym, WBITS, P>, lds);
     StampGuard guard(scope, "banded");
     hipLaunchKernelGGL((k_banded<Sym, WBITS, P>), dim3(blocks), dim3(256), lds, scope->stream, args, (uint32_t)kClassBanded);
 }

@@ -603,12 +603,10 @@ void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_hos
     // args.boundary / boundary_stride: the carry words, sized by the caller (bp_long_carry_words, <= 4096 waves)
     StampGuard guard(scope, bytes ? "bitparallel_long" : "bitparallel_long_u32");
     if (bytes) {
-        static bool attr_set = false;
-        if (!attr_set) { SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_bitparallel_long<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        opt_in_dynamic_lds(scope, (const void *)k_bitparallel_long<uint8_t>, lds);
         hipLaunchKernelGGL(k_bitparallel_long<uint8_t>, dim3(blocks), dim3(waves * 64), lds, scope->stream, args);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) { SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_bitparallel_long<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        opt_in_dynamic_lds(scope, (const void *)k_bitparallel_long<uint32_t>, lds);
         hipLaunchKernelGGL(k_bitparallel_long<uint32_t>, dim3(blocks), dim3(waves * 64), lds, scope->stream, args);
     }
     SWH_HIP_CHECK(hipGetLastError());
@@ -625,11 +623,7 @@ static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_
     // bytes: 33 KB blocks of 4 waves, 4 per CU; code points: 29 KB blocks of 2 waves, 5 per CU
     uint32_t max_blocks = (uint32_t)scope->compute_units * (sizeof(Sym) == 1 ? 4 : 5);
     uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_bitparallel<Sym>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    opt_in_dynamic_lds(scope, (const void *)k_bitparallel<Sym>, lds);
     StampGuard guard(scope, sizeof(Sym) == 1 ? "bitparallel" : "bitparallel_u32");
     hipLaunchKernelGGL(k_bitparallel<Sym>, dim3(blocks), dim3(kWaves * 64), lds, scope->stream, k);
     SWH_HIP_CHECK(hipGetLastError());

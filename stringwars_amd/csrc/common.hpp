@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/stringwars_amd.h"
@@ -196,6 +197,10 @@ struct Scope {
     Scope *lanes[2] = {nullptr, nullptr};
     int next_lane = 0;
     hipEvent_t lane_done = nullptr;   // (on a lane) recorded after the lane's latest call
+    hipEvent_t order_ev = nullptr;    // (on the parent) the caller's stream at the time of a pipelined call: the lane waits for it
+    // kernels whose dynamic LDS was raised above 64 KB on THIS scope's device (function attributes are per device; a
+    // process-wide flag would leave a second device without the opt-in)
+    std::unordered_map<const void *, size_t> lds_opt_in;
     Scope *last_lane = nullptr;       // (on the parent) lane that took the latest call
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
@@ -283,11 +288,20 @@ struct Utf8Args {
 };
 void launch_utf8_decode(Scope *scope, const Utf8Args &args);
 
+#define SWH_HIP_CHECK_DECLARED 1
 #define SWH_HIP_CHECK(expr)                                                                          \
     do {                                                                                              \
         hipError_t err__ = (expr);                                                                    \
         if (err__ != hipSuccess) throw ::swh::HipFailure{err__, #expr};                               \
     } while (0)
 struct HipFailure { hipError_t code; const char *what; };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (scope = device, kernel)
+inline void opt_in_dynamic_lds(Scope *scope, const void *func, size_t bytes) {
+    auto it = scope->lds_opt_in.find(func);
+    if (it != scope->lds_opt_in.end() && it->second >= bytes) return;
+    SWH_HIP_CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    scope->lds_opt_in[func] = bytes;
+}
 
 }  // namespace swh

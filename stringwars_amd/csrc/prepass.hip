@@ -125,10 +125,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_hist(PrepassArgs args) {
             key = kClassTrivial * kBuckets;
             int64_t v = info.trivial_value;
             // distances are stored positive: the max-plus core negates, the trivial path mirrors it
-            if (args.job.negate) {
-                v = -v;
-                if (args.unit_costs) v = (int64_t)clamp_bound((uint32_t)v, args.job.bound);
-            }
+            // the cutoff applies to every distance, whatever the costs (same as store_score in wavefront.hip)
+            if (args.job.negate) v = (int64_t)clamp_bound((uint32_t)(-v), args.job.bound);
             store_result(args.job, p, v);
         } else if (is_short && args.direct_short) {
             key = kClassTrivial * kBuckets;   // scored by k_direct_short

@@ -434,14 +434,7 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
     uint32_t max_blocks = (uint32_t)scope->compute_units * (lds > 4096 ? 2 : 8);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks == 0) return;
-    if (lds > 65536) {
-        static bool attr_set = false;  // one flag per instantiation
-        if (!attr_set) {
-            SWH_HIP_CHECK(hipFuncSetAttribute((const void *)k_wavefront<Sym, G, W, MODEL, PQ>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-    }
+    if (lds > 65536) opt_in_dynamic_lds(scope, (const void *)k_wavefront<Sym, G, W, MODEL, PQ>, lds);
     // alternate streams between class kernels (see Scope::wf_main); the side stream's kernels get their own boundary area
     KernelArgs launch_args = args;
     if (scope->wf_main) {

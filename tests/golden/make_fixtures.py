@@ -1,10 +1,20 @@
-"""Generates tests/golden/slices.npz: the first pairs of every synthetic config with the
+"""Generates tests/golden/slices.npz: the first 256 pairs of every synthetic config with the
 oracle's outputs, so the GPU box can check generator + kernels with no reference code present.
 
-Run from the repo root:  python tests/golden/make_fixtures.py
-Inputs come from stringwars_amd.generate_pairs (seed 42); expected outputs from oracle/ (Wagner-Fischer /
-Gotoh restatements, cross-checked against the Hyyro bit-parallel implementation before writing).
+Run from the repo root:  python tests/golden/make_fixtures.py      (about two minutes of CPU)
+
+Inputs come from stringwars_amd.generate_pairs (seed 42); expected outputs from oracle/ (Wagner-Fischer and
+Gotoh restatements; Levenshtein cross-checked against the Hyyro bit-parallel implementation, alignment scores of
+the first pairs against the general-gap table, before anything is written).
+
+Layout. The word-sized workloads (words16, tokens64, short_words) carry their 256 input pairs verbatim. The
+KB-sized ones (utf8_lines ~1 KB, protein4k / bytes4k ~4 KB per string: 0.5-2 MB of incompressible text per
+workload) carry the inputs of a short prefix verbatim (`<name>.a_data` ...: 32 / 6 / 4 pairs, as in round 1) and,
+for the full 256 pairs, a SHA-256 over the generated tapes (`<name>.n256.sha256`) next to the 256 expected outputs
+(`<name>.n256.*`): a test regenerates the 256 pairs, checks the digest -- which pins the generator -- and then
+compares the kernels' outputs with the stored vectors.
 """
+import hashlib
 import os
 import sys
 
@@ -15,22 +25,50 @@ sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 import stringwars_amd as sw  # noqa: E402
 
-SLICES = {"words16": 256, "tokens64": 256, "utf8_lines": 32, "protein4k": 6, "short_words": 256, "bytes4k": 4}
-out = {}
-for name, count in SLICES.items():
-    a, b = sw.generate_pairs(name, count, seed=42)
-    out[f"{name}.a_data"], out[f"{name}.a_offsets"] = a.data, a.offsets
-    out[f"{name}.b_data"], out[f"{name}.b_offsets"] = b.data, b.offsets
-    wf = oracle.levenshtein_pairs(a, b)
-    assert (wf == oracle.levenshtein_pairs(a, b, algo="hyyro")).all()
-    out[f"{name}.lev_bytes"] = wf
-    if name == "utf8_lines":
-        out[f"{name}.lev_utf8"] = oracle.levenshtein_pairs(a, b, utf8=True)
-    if name in ("protein4k", "bytes4k"):
-        alphabet = sw.synth.AMINO_ACIDS if name == "protein4k" else None
-        matrix = sw.substitution_matrix(42, alphabet)
-        out[f"{name}.matrix"] = matrix
-        out[f"{name}.nw_linear_m4"] = oracle.nw_pairs(a, b, matrix, -4, -4)
-        out[f"{name}.nw_affine_m11_m1"] = oracle.nw_pairs(a, b, matrix, -11, -1)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "slices.npz"), **out)
-print({k: v.shape for k, v in out.items() if not k.endswith("data")})
+FULL = 256
+VERBATIM = {"words16": 256, "tokens64": 256, "utf8_lines": 32, "protein4k": 6, "short_words": 256, "bytes4k": 4}
+
+
+def tape_digest(a, b) -> str:
+    h = hashlib.sha256()
+    for array in (a.data, a.offsets, b.data, b.offsets):
+        h.update(np.ascontiguousarray(array).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    out = {}
+    for name, verbatim in VERBATIM.items():
+        a, b = sw.generate_pairs(name, FULL, seed=42)
+        head_a, head_b = sw.generate_pairs(name, verbatim, seed=42)
+        out[f"{name}.a_data"], out[f"{name}.a_offsets"] = head_a.data, head_a.offsets
+        out[f"{name}.b_data"], out[f"{name}.b_offsets"] = head_b.data, head_b.offsets
+        wf = oracle.levenshtein_pairs(a, b)
+        assert (wf == oracle.levenshtein_pairs(a, b, algo="hyyro")).all()
+        out[f"{name}.lev_bytes"] = wf[:verbatim]
+        out[f"{name}.n256.sha256"] = np.frombuffer(tape_digest(a, b).encode(), dtype=np.uint8)
+        out[f"{name}.n256.lev_bytes"] = wf
+        if name == "utf8_lines":
+            cp = oracle.levenshtein_pairs(a, b, utf8=True)
+            out[f"{name}.lev_utf8"] = cp[:verbatim]
+            out[f"{name}.n256.lev_utf8"] = cp
+        if name in ("protein4k", "bytes4k"):
+            alphabet = sw.synth.AMINO_ACIDS if name == "protein4k" else None
+            matrix = sw.substitution_matrix(42, alphabet)
+            out[f"{name}.matrix"] = matrix
+            for tag, (open_, extend) in {"linear_m4": (-4, -4), "affine_m11_m1": (-11, -1)}.items():
+                nw = oracle.nw_pairs(a, b, matrix, open_, extend)
+                out[f"{name}.nw_{tag}"] = nw[:verbatim]
+                out[f"{name}.n256.nw_{tag}"] = nw
+                out[f"{name}.n256.sw_{tag}"] = np.array(
+                    [oracle.nw_score(a[i], b[i], matrix, open_, extend, local=True) for i in range(FULL)], dtype=np.int64)
+                # the cubic second implementation on prefixes of the first pairs (whole 4 KB strings would take hours)
+                for i in range(4):
+                    pa, pb = a[i][:300], b[i][:280]
+                    assert oracle.nw_score(pa, pb, matrix, open_, extend) == oracle.align_score_general(pa, pb, matrix, open_, extend)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "slices.npz"), **out)
+    print({k: v.shape for k, v in out.items() if not k.endswith("data")})
+
+
+if __name__ == "__main__":
+    main()

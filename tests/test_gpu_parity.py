@@ -112,6 +112,37 @@ def test_golden_slices_needleman_wunsch(sw, scope, name):
     assert (affine.pairs(a, b, scope) == z[f"{name}.nw_affine_m11_m1"]).all()
 
 
+@pytest.mark.parametrize("name", ["words16", "tokens64", "utf8_lines", "protein4k", "short_words", "bytes4k"])
+def test_golden_256_pairs_of_every_config(sw, scope, name):
+    """the first 256 pairs of each synthetic config against the committed oracle outputs. The KB-sized
+    workloads are regenerated here (their SHA-256 is part of the fixture, tests/golden/make_fixtures.py)."""
+    import hashlib
+    z = np.load(os.path.join(GOLDEN, "slices.npz"))
+    a, b = sw.generate_pairs(name, 256, seed=42)
+    h = hashlib.sha256()
+    for array in (a.data, a.offsets, b.data, b.offsets):
+        h.update(np.ascontiguousarray(array).tobytes())
+    assert h.hexdigest() == bytes(z[f"{name}.n256.sha256"]).decode()
+    want = z[f"{name}.n256.lev_bytes"]
+    for algorithm in ALGORITHMS:
+        engine = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm)
+        assert (engine.pairs(a, b, scope) == want).all()
+    assert (sw.LevenshteinDistances(capabilities=scope).pairs(a, b, scope, bound=32) == np.minimum(want, 33)).all()
+    if name == "utf8_lines":
+        utf8 = sw.LevenshteinDistancesUTF8(capabilities=scope)
+        want = z["utf8_lines.n256.lev_utf8"]
+        assert (utf8.pairs(a, b, scope) == want).all()
+        for k in (0, 7, 32, 63):
+            assert (utf8.pairs(a, b, scope, bound=k) == np.minimum(want, k + 1)).all()
+    if name in ("protein4k", "bytes4k"):
+        matrix = z[f"{name}.matrix"]
+        for tag, (open_, extend) in {"linear_m4": (-4, -4), "affine_m11_m1": (-11, -1)}.items():
+            nw = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=open_, extend=extend, capabilities=scope)
+            assert (nw.pairs(a, b, scope) == z[f"{name}.n256.nw_{tag}"]).all()
+            local = sw.SmithWatermanScores(substitution_matrix=matrix, open=open_, extend=extend, capabilities=scope)
+            assert (local.pairs(a, b, scope) == z[f"{name}.n256.sw_{tag}"]).all()
+
+
 # ----------------------------------------------------------------------------------------------------
 # random sweeps against the oracle
 # ----------------------------------------------------------------------------------------------------
@@ -341,6 +372,32 @@ def test_general_cost_levenshtein(sw, orc, scope, costs):
     want = orc.levenshtein_costs_pairs(a, b, *costs)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, (costs, bad[:5], got[bad[:5]], want[bad[:5]])
+
+
+@pytest.mark.parametrize("costs", [(0, 2, 3, 3), (0, 1, 2, 1), (1, 3, 4, 2)])
+def test_general_cost_levenshtein_bounded(sw, orc, scope, costs):
+    """The cutoff out = min(d, bound + 1) holds for every cost model, empty sides included (pairs with an
+    empty side used to skip the clamp unless the costs were (0,1,1,1))."""
+    engine = sw.LevenshteinDistances(*costs, capabilities=scope)
+    assert engine.pairs([b""], [b"abcdef"], scope, bound=4).tolist() == [5]
+    assert engine.pairs([b"abcdef", b"", b"ab"], [b"", b"", b"ab"], scope, bound=4).tolist() == [5, 0, min(2 * costs[0], 5)]
+    rng = np.random.default_rng(29)
+    items_a, items_b = random_pairs(rng, 800, list(range(0, 50)) + [130, 200], 5)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    full = orc.levenshtein_costs_pairs(a, b, *costs)
+    for bound in (0, 4, 17, 300):
+        assert (engine.pairs(a, b, scope, bound=bound) == np.minimum(full, bound + 1)).all()
+
+
+def test_scores_beyond_int32_are_refused(sw, scope):
+    """Gap costs at the accepted limit times long strings leave the wavefront kernels' 32-bit score range: the call is
+    refused (unsupported_length) instead of returning wrapped scores."""
+    engine = sw.NeedlemanWunschScores(substitution_matrix=unary_matrix(2, -1), open=-4096, extend=-4096, capabilities=scope)
+    assert engine.pairs([b"ACGT" * 50], [b"ACGA" * 50], scope).size == 1
+    long_a, long_b = [b"AC" * 20000], [b"GT" * 20000]
+    with pytest.raises(sw.StringWarsError) as info:
+        engine.pairs(long_a, long_b, scope)
+    assert info.value.status == "unsupported_length"
 
 
 @pytest.mark.parametrize("gaps", [(-4, -4), (-11, -1), (-2, -2), (-5, -1), (0, 0)])
@@ -619,6 +676,21 @@ def test_config2_full_size_properties(sw, orc, scope):
     assert int(forward.astype(np.uint64).sum()) == int(forward[::-1].astype(np.uint64).sum())
 
 
+def _pick(sw, tape, index):
+    """Host sub-tape holding strings `index` of `tape` (for oracle samples spread over a full-size batch)."""
+    lengths = tape.lengths[index]
+    offsets = np.zeros(len(index) + 1, np.uint64)
+    np.cumsum(lengths, out=offsets[1:])
+    starts = tape.offsets[index].astype(np.int64)
+    data = np.concatenate([tape.data[s:s + n] for s, n in zip(starts, lengths)]) if len(index) else np.zeros(0, np.uint8)
+    return sw.Strs(data=data, offsets=offsets)
+
+
+def _code_point_lengths(tape):
+    leads = np.concatenate([[0], np.cumsum((tape.data & 0xC0) != 0x80)])
+    return np.diff(leads[tape.offsets.astype(np.int64)])
+
+
 def test_config3_bounded_utf8(sw, orc, scope):
     """Config C3 (reduced count for the oracle): ~1 KB UTF-8 lines, bound k = 32."""
     a, b = sw.generate_pairs("utf8_lines", 2000, seed=42)
@@ -629,6 +701,97 @@ def test_config3_bounded_utf8(sw, orc, scope):
     assert got.max() <= 33 and (got == 33).any() and (got < 33).any()
     full = engine.pairs(a, b, scope)
     assert (np.minimum(full, 33) == got).all()
+
+
+def test_config3_full_size_properties(sw, orc, scope):
+    """BASELINE config C3 at full size: 100 K UTF-8 line pairs of ~1 KB, bounded k = 32 -- the production shape of the
+    banded kernel (32-pair items below 131 K pairs) and of the two-tape decode. Whole batch: work units, symmetry,
+    identity, bounds, bounded == min(unbounded, k + 1); 2 % of the pairs, spread over the batch, against the oracle."""
+    pairs, k = 100_000, 32
+    a, b = sw.generate_pairs("utf8_lines", pairs, seed=42)
+    da, db = a.to_device(scope), b.to_device(scope)
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    scope.set_profiling(True)
+    bounded = engine.pairs(da, db, scope, bound=k)
+    timing = scope.last_timing()
+    scope.set_profiling(False)
+    cpa, cpb = _code_point_lengths(a), _code_point_lengths(b)
+    assert timing["cells"] == int((cpa * cpb).sum())                      # cells counted in code points (bench.rs:434)
+    assert (engine.pairs(db, da, scope, bound=k) == bounded).all()        # symmetry
+    assert (engine.pairs(da, da, scope, bound=k) == 0).all()              # identity
+    assert bounded.max() == k + 1 and (bounded >= np.minimum(np.abs(cpa - cpb), k + 1)).all()
+    share = float((bounded == k + 1).mean())
+    assert 0.2 < share < 0.8                                              # SURVEY 8d: about half the pairs exceed k
+    unbounded = engine.pairs(da, db, scope)
+    assert (np.minimum(unbounded, k + 1) == bounded).all()
+    assert (unbounded <= np.maximum(cpa, cpb)).all()
+    for other in (0, 7, 63):                                              # the other window widths of the banded kernel
+        assert (engine.pairs(da, db, scope, bound=other) == np.minimum(unbounded, other + 1)).all()
+    sample = np.arange(17, pairs, 50)                                     # 2,000 pairs
+    want = orc.levenshtein_pairs(_pick(sw, a, sample), _pick(sw, b, sample), utf8=True)
+    assert (unbounded[sample] == want).all()
+    assert (bounded[sample] == np.minimum(want, k + 1)).all()
+    # the same tapes as bytes (banded<u8> and the byte bit-parallel kernel at G ~ 32 blocks)
+    bytes_engine = sw.LevenshteinDistances(capabilities=scope)
+    bytes_bounded = bytes_engine.pairs(da, db, scope, bound=k)
+    bytes_full = bytes_engine.pairs(da, db, scope)
+    assert (np.minimum(bytes_full, k + 1) == bytes_bounded).all()
+    head = np.arange(0, pairs, 200)
+    assert (bytes_full[head] == orc.levenshtein_pairs(_pick(sw, a, head), _pick(sw, b, head), algo="hyyro")).all()
+
+
+@pytest.mark.parametrize("gaps", [(-4, -4), (-11, -1)], ids=["linear", "affine"])
+def test_config4_full_size_properties(sw, orc, scope, gaps):
+    """BASELINE config C4 at full size: 10 K pairs of ~4 KB amino-acid sequences, 256x256 i8 matrix, linear and
+    affine gaps -- the production shape of the class-table wavefront kernels on two streams. Whole batch: work units,
+    symmetry (the matrix is symmetric), the self-alignment score, bounds, local >= global; 1 % against the oracle."""
+    pairs = 10_000
+    open_, extend = gaps
+    a, b = sw.generate_pairs("protein4k", pairs, seed=42)
+    da, db = a.to_device(scope), b.to_device(scope)
+    matrix = sw.substitution_matrix(42)
+    assert (matrix == matrix.T).all()
+    engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=open_, extend=extend, capabilities=scope)
+    scope.set_profiling(True)
+    forward = engine.pairs(da, db, scope)
+    timing = scope.last_timing()
+    scope.set_profiling(False)
+    la, lb = a.lengths, b.lengths
+    assert timing["cells"] == int((la * lb).sum())
+    assert (engine.pairs(db, da, scope) == forward).all()                 # symmetry
+    diagonal = matrix[np.arange(256), np.arange(256)].astype(np.int64)
+    def self_score(tape):
+        prefix = np.concatenate([[0], np.cumsum(diagonal[tape.data])])
+        return np.diff(prefix[tape.offsets.astype(np.int64)])
+    sa, sb = self_score(a), self_score(b)
+    assert (engine.pairs(da, da, scope) == sa).all()                      # identity: every symbol against itself
+    # diagonal >= 4 > off-diagonal: an aligned column (x, y) scores at most (m[x][x] + m[y][y]) / 2, gaps are negative
+    assert (2 * forward.astype(np.int64) <= sa + sb).all()
+    def gap(n):
+        return np.where(n > 0, open_ + (n - 1) * extend, 0)
+    assert (forward >= gap(la) + gap(lb)).all()                           # all-gaps alignment
+    local = sw.SmithWatermanScores(substitution_matrix=matrix, open=open_, extend=extend, capabilities=scope).pairs(da, db, scope)
+    assert (local >= np.maximum(forward, 0)).all()
+    sample = np.arange(3, pairs, 100)                                     # 100 pairs = 1 %
+    sub_a, sub_b = _pick(sw, a, sample), _pick(sw, b, sample)
+    assert (forward[sample] == orc.nw_pairs(sub_a, sub_b, matrix, open_, extend)).all()
+    few = sample[:12]
+    assert local[few].tolist() == [orc.nw_score(a[int(i)], b[int(i)], matrix, open_, extend, local=True) for i in few]
+
+
+def test_config4_full_byte_alphabet(sw, orc, scope):
+    """C4's second run: bytes 0-255, all 256 matrix rows in use -> the LDS-gather matrix kernels."""
+    pairs = 2_000
+    a, b = sw.generate_pairs("bytes4k", pairs, seed=42)
+    da, db = a.to_device(scope), b.to_device(scope)
+    matrix = sw.substitution_matrix(42, None)
+    sample = np.arange(5, pairs, 100)
+    for open_, extend in ((-4, -4), (-11, -1)):
+        engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=open_, extend=extend, capabilities=scope)
+        forward = engine.pairs(da, db, scope)
+        if (matrix == matrix.T).all():
+            assert (engine.pairs(db, da, scope) == forward).all()
+        assert (forward[sample] == orc.nw_pairs(_pick(sw, a, sample), _pick(sw, b, sample), matrix, open_, extend)).all()
 
 
 def test_config5_short_words_large(sw, orc, scope):

@@ -79,6 +79,85 @@ def test_two_implementations_agree(orc, sw, alphabet):
     assert (orc.levenshtein_pairs(ta, tb) == orc.levenshtein_pairs(ta, tb, algo="hyyro")).all()
 
 
+@pytest.mark.parametrize("alphabet", [2, 4, 26, 256])
+def test_wagner_fischer_vs_hyyro_one_million_pairs(orc, alphabet):
+    """two independent CPU implementations agree on >= 1e6 random pairs (4 x 250,000), alphabets
+    {2, 4, 26, 256}, lengths 0-300 incl. the 63/64/65, 127/128/129 ... word boundaries; both argument orders; every
+    16th pair also against the anti-diagonal full table. The loop runs in C (oracle.c: orc_selfcheck_levenshtein)."""
+    bad, first, cells = orc.selfcheck("levenshtein", 20260101, 250_000, alphabet, 300)
+    assert bad == 0, f"first disagreement at case {first}"
+    assert cells > 1_000_000_000
+
+
+@pytest.mark.parametrize("alphabet", [2, 4, 20, 256])
+def test_gotoh_vs_general_gap_table(orc, alphabet):
+    """The NW / SW oracle (Gotoh, rolling rows) against a second implementation that shares only the definition:
+    the Waterman-Smith-Beyer general-gap table (cubic, every gap length spelled out). 4 x 30,000 = 120,000 random
+    cases: symmetric and asymmetric i8 matrices, gaps with |open| >= |extend|, lengths 0-40, global and local."""
+    bad, first, cells = orc.selfcheck("alignment", 20260102, 30_000, alphabet, 40)
+    assert bad == 0, f"first disagreement at case {first}"
+    assert cells > 10_000_000
+
+
+def _enumerate_alignments(a, b, matrix, open_, extend):
+    """Best score over ALL alignments of a and b, by brute force: every monotone path of diagonal / down / right
+    moves, maximal runs of down (right) moves scored as one gap of that length. No dynamic programming."""
+    best = [None]
+
+    def walk(i, j, score, run_kind, run_len):
+        def close(sc):
+            return sc + (open_ + (run_len - 1) * extend if run_len else 0)
+        if i == len(a) and j == len(b):
+            total = close(score)
+            if best[0] is None or total > best[0]:
+                best[0] = total
+            return
+        if i < len(a) and j < len(b):
+            walk(i + 1, j + 1, close(score) + int(matrix[a[i], b[j]]), 0, 0)
+        if i < len(a):
+            if run_kind == 1:
+                walk(i + 1, j, score, 1, run_len + 1)
+            else:
+                walk(i + 1, j, close(score), 1, 1)
+        if j < len(b):
+            if run_kind == 2:
+                walk(i, j + 1, score, 2, run_len + 1)
+            else:
+                walk(i, j + 1, close(score), 2, 1)
+
+    walk(0, 0, 0, 0, 0)
+    return best[0]
+
+
+def test_alignment_scores_by_exhaustive_enumeration(orc):
+    """Third anchor for NW / SW: exhaustive enumeration of every alignment of strings of up to 5 (global) / 4 (local:
+    every pair of substrings) symbols over a 3-letter alphabet, against both oracle implementations."""
+    rng = np.random.default_rng(11)
+    for case in range(160):
+        matrix = np.zeros((256, 256), np.int8)
+        sub = rng.integers(-6, 7, (3, 3))
+        if case % 2 == 0:
+            sub = np.minimum(sub, sub.T)
+        matrix[:3, :3] = sub
+        extend = -int(rng.integers(0, 4))
+        open_ = extend - int(rng.integers(0, 6))
+        a = rng.integers(0, 3, int(rng.integers(0, 6)), dtype=np.uint8)
+        b = rng.integers(0, 3, int(rng.integers(0, 6)), dtype=np.uint8)
+        want = _enumerate_alignments(a, b, matrix, open_, extend)
+        assert orc.nw_score(a, b, matrix, open_, extend) == want
+        assert orc.align_score_general(a, b, matrix, open_, extend) == want
+        if case % 4 == 0:
+            a, b = a[:4], b[:4]
+            local = 0
+            for i0 in range(len(a) + 1):
+                for i1 in range(i0, len(a) + 1):
+                    for j0 in range(len(b) + 1):
+                        for j1 in range(j0, len(b) + 1):
+                            local = max(local, _enumerate_alignments(a[i0:i1], b[j0:j1], matrix, open_, extend))
+            assert orc.nw_score(a, b, matrix, open_, extend, local=True) == local
+            assert orc.align_score_general(a, b, matrix, open_, extend, local=True) == local
+
+
 small = st.binary(max_size=24)
 
 
@@ -91,7 +170,7 @@ def test_metric_properties(orc, a, b, c):
     assert abs(len(a) - len(b)) <= d(a, b) <= max(len(a), len(b))
     assert d(a, c) <= d(a, b) + d(b, c)
     assert d(a, a + c) == len(c)
-    assert d(a, b) == d(a, b, "hyyro")
+    assert d(a, b) == d(a, b, "hyyro") == orc.levenshtein_antidiagonal(a, b)
 
 
 @settings(max_examples=100, deadline=None)
@@ -118,16 +197,35 @@ def test_invalid_utf8_rejected(orc, bad):
         orc.utf8_decode(bad)
 
 
+def _digest(a, b) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for array in (a.data, a.offsets, b.data, b.offsets):
+        h.update(np.ascontiguousarray(array).tobytes())
+    return h.hexdigest()
+
+
 def test_golden_slices_reproducible(orc, sw):
-    """The committed fixture = generator(seed 42) + oracle; regenerate and compare (catches drift in either)."""
+    """The committed fixture = generator(seed 42) + oracle; regenerate and compare (catches drift in either).
+    All six workloads: the SHA-256 of the first 256 generated pairs; oracle outputs for the word-sized ones at 256
+    pairs and for the KB-sized ones on their verbatim prefix (the 4 KB alignments at 256 pairs take minutes on a CPU:
+    they are compared with the kernels' outputs in the -m gpu suite)."""
     z = np.load(os.path.join(GOLDEN, "slices.npz"))
-    for name, count in {"words16": 256, "tokens64": 256, "utf8_lines": 32, "short_words": 256}.items():
-        a, b = sw.generate_pairs(name, count, seed=42)
-        assert (a.data == z[f"{name}.a_data"]).all() and (a.offsets == z[f"{name}.a_offsets"]).all()
-        assert (b.data == z[f"{name}.b_data"]).all() and (b.offsets == z[f"{name}.b_offsets"]).all()
-        assert (orc.levenshtein_pairs(a, b) == z[f"{name}.lev_bytes"]).all()
+    for name in ("words16", "tokens64", "utf8_lines", "protein4k", "short_words", "bytes4k"):
+        a, b = sw.generate_pairs(name, 256, seed=42)
+        assert _digest(a, b) == bytes(z[f"{name}.n256.sha256"]).decode()
+        prefix = len(z[f"{name}.a_offsets"]) - 1
+        head = sw.Strs(data=z[f"{name}.a_data"], offsets=z[f"{name}.a_offsets"])
+        assert all(head[i] == a[i] for i in range(prefix))
+        assert (z[f"{name}.n256.lev_bytes"][:prefix] == z[f"{name}.lev_bytes"]).all()
+    for name in ("words16", "tokens64", "short_words"):
+        a, b = sw.generate_pairs(name, 256, seed=42)
+        assert (orc.levenshtein_pairs(a, b) == z[f"{name}.n256.lev_bytes"]).all()
     a, b = sw.generate_pairs("utf8_lines", 32, seed=42)
-    assert (orc.levenshtein_pairs(a, b, utf8=True) == z["utf8_lines.lev_utf8"]).all()
+    assert (orc.levenshtein_pairs(a, b, utf8=True) == z["utf8_lines.n256.lev_utf8"][:32]).all()
+    a, b = sw.generate_pairs("protein4k", 2, seed=42)
+    assert (orc.nw_pairs(a, b, z["protein4k.matrix"], -4, -4) == z["protein4k.n256.nw_linear_m4"][:2]).all()
+    assert orc.nw_score(a[0], b[0], z["protein4k.matrix"], -11, -1, local=True) == z["protein4k.n256.sw_affine_m11_m1"][0]
 
 
 def test_generator_is_sliceable(sw):

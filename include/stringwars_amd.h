@@ -48,7 +48,8 @@ typedef enum swh_status_t {
 typedef enum swh_algorithm_t {
     swh_algorithm_auto_k = 0,        /* fastest measured path per length class */
     swh_algorithm_wavefront_k = 1,   /* anti-diagonal wavefront, register-tiled, DPP hand-off */
-    swh_algorithm_bitparallel_k = 2  /* Myers/Hyyro bit-vectors, systolic over 32-row blocks */
+    swh_algorithm_bitparallel_k = 2, /* Myers/Hyyro bit-vectors, systolic over 32-row blocks; globally planned (device pre-pass) */
+    swh_algorithm_tiled_k = 3        /* the same recurrence, every workgroup plans its own tile: no pre-pass, no host round trip */
 } swh_algorithm_t;
 
 /* ---- Device scope: replaces `DeviceScope::gpu_device(0)` (bench.rs:379, :652, :978). ------- */
@@ -115,6 +116,29 @@ swh_status_t swh_copy_to_host(swh_scope_t scope, void *host_dst, const void *dev
 typedef struct swh_tape_u32_t { const uint8_t *data; const uint32_t *offsets; size_t count; } swh_tape_u32_t;
 typedef struct swh_tape_u64_t { const uint8_t *data; const uint64_t *offsets; size_t count; } swh_tape_u64_t;
 
+/* ---- Prepared tapes: `BytesTape<u64, UnifiedAlloc>` filled once and `CharsTapeView::try_from(bytes_view)` validated
+ *      once, both OUTSIDE the timed closures (bench.rs:292-306), then sub-viewed per iteration (bench.rs:134-139).
+ * `swh_tape_prepare_*` makes a tape resident on the scope's device (host tapes are uploaded; device tapes are used in
+ * place and must outlive the handle), measures it (count, symbols, longest string) and, with `utf8 != 0`, validates
+ * and decodes it to code points -- invalid UTF-8 fails HERE with swh_invalid_utf8_k, as `try_into` does, not in every
+ * engine call. Engine calls on prepared views skip the per-call decode and, knowing the longest string, the planning
+ * pre-pass and its host round trip. */
+typedef struct swh_prepared_s *swh_prepared_t;
+typedef struct swh_prepared_info_t {
+    size_t count;             /* strings */
+    uint64_t bytes, symbols;  /* tape bytes; symbols = bytes, or code points for a UTF-8 tape */
+    uint32_t longest;         /* longest string in symbols */
+    int utf8, ascii;          /* prepared as UTF-8; every code point is a single byte */
+} swh_prepared_info_t;
+swh_status_t swh_tape_prepare_u32(swh_scope_t scope, const swh_tape_u32_t *tape, int utf8, swh_prepared_t *prepared,
+                                  const char **error);
+swh_status_t swh_tape_prepare_u64(swh_scope_t scope, const swh_tape_u64_t *tape, int utf8, swh_prepared_t *prepared,
+                                  const char **error);
+swh_status_t swh_prepared_info(swh_prepared_t prepared, swh_prepared_info_t *info);
+swh_status_t swh_prepared_free(swh_prepared_t prepared);
+/* Strings [first, first + count) of a prepared tape: `BytesTapeView::subview(lo, hi)` (bench.rs:134-139). */
+typedef struct swh_prepared_view_t { swh_prepared_t tape; size_t first, count; } swh_prepared_view_t;
+
 /* ---- Levenshtein: `LevenshteinDistances::new(&scope, 0, 1, 1, 1)` (bench.rs:382-393). ------ */
 typedef struct swh_levenshtein_s *swh_levenshtein_t;
 /* Costs are non-negative; gap of length k costs open + (k-1)*extend. */
@@ -152,6 +176,15 @@ swh_status_t swh_levenshtein_utf8_cross_u64tape(swh_levenshtein_t engine, swh_sc
                                                 const swh_tape_u64_t *a, const swh_tape_u64_t *b, size_t *out,
                                                 size_t row_stride_bytes, const char **error);
 
+/* The same calls on prepared views (both tapes prepared on the scope's device, both as bytes or both as UTF-8 -- the
+ * symbols are then code points, as for `LevenshteinDistancesUtf8`). `b == NULL` in the cross-product means a x a. */
+swh_status_t swh_levenshtein_pairs_prepared(swh_levenshtein_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
+                                            const swh_prepared_view_t *b, uint32_t bound, uint32_t *out,
+                                            size_t out_stride_bytes, const char **error);
+swh_status_t swh_levenshtein_cross_prepared(swh_levenshtein_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
+                                            const swh_prepared_view_t *b, size_t *out, size_t row_stride_bytes,
+                                            const char **error);
+
 /* ---- Needleman-Wunsch: `NeedlemanWunschScores::new(&scope, &byte_to_class, &class_costs,
  *      open, extend)` (bench.rs:658-670, :985-997); scores are max-plus, gaps usually negative. */
 typedef struct swh_nw_s *swh_nw_t;
@@ -176,6 +209,11 @@ swh_status_t swh_nw_cross_u64tape(swh_nw_t engine, swh_scope_t scope, const swh_
                                   const swh_tape_u64_t *b, ptrdiff_t *out, size_t row_stride_bytes,
                                   const char **error);
 
+swh_status_t swh_nw_pairs_prepared(swh_nw_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
+                                   const swh_prepared_view_t *b, int32_t *out, size_t out_stride_bytes, const char **error);
+swh_status_t swh_nw_cross_prepared(swh_nw_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
+                                   const swh_prepared_view_t *b, ptrdiff_t *out, size_t row_stride_bytes, const char **error);
+
 /* ---- Smith-Waterman: `SmithWatermanScores::new(&scope, &byte_to_class, &class_costs, open, extend)`
  *      (bench.rs:882-963). Local alignment score: max over all cells, floored at 0;
  *      same matrix / gap conventions as Needleman-Wunsch. */
@@ -195,6 +233,11 @@ swh_status_t swh_sw_pairs_u64tape(swh_sw_t engine, swh_scope_t scope, const swh_
 swh_status_t swh_sw_cross_u64tape(swh_sw_t engine, swh_scope_t scope, const swh_tape_u64_t *a,
                                   const swh_tape_u64_t *b, ptrdiff_t *out, size_t row_stride_bytes,
                                   const char **error);
+
+swh_status_t swh_sw_pairs_prepared(swh_sw_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
+                                   const swh_prepared_view_t *b, int32_t *out, size_t out_stride_bytes, const char **error);
+swh_status_t swh_sw_cross_prepared(swh_sw_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
+                                   const swh_prepared_view_t *b, ptrdiff_t *out, size_t row_stride_bytes, const char **error);
 
 /* ---- Introspection: `log_stringzilla_metadata` (utils.rs:78-92). --------------------------- */
 const char *swh_version(void);

@@ -47,7 +47,7 @@ STATUS_NAMES = {
     5: "no_device", 6: "device_error", 7: "not_implemented",
 }
 UNBOUNDED = 0xFFFFFFFF
-ALGORITHM_AUTO, ALGORITHM_WAVEFRONT, ALGORITHM_BITPARALLEL = 0, 1, 2
+ALGORITHM_AUTO, ALGORITHM_WAVEFRONT, ALGORITHM_BITPARALLEL, ALGORITHM_TILED = 0, 1, 2, 3
 
 
 class TapeU32(C.Structure):
@@ -56,6 +56,17 @@ class TapeU32(C.Structure):
 
 class TapeU64(C.Structure):
     _fields_ = [("data", C.c_void_p), ("offsets", C.c_void_p), ("count", C.c_size_t)]
+
+
+class PreparedInfo(C.Structure):
+    """``swh_prepared_info_t``"""
+    _fields_ = [("count", C.c_size_t), ("bytes", C.c_uint64), ("symbols", C.c_uint64), ("longest", C.c_uint32),
+                ("utf8", C.c_int), ("ascii", C.c_int)]
+
+
+class PreparedView(C.Structure):
+    """``swh_prepared_view_t``: strings [first, first + count) of a prepared tape."""
+    _fields_ = [("tape", C.c_void_p), ("first", C.c_size_t), ("count", C.c_size_t)]
 
 
 class Timing(C.Structure):
@@ -122,6 +133,16 @@ SIGNATURES = {
     "swh_sw_pairs_u32tape": (C.c_int, [_P, _P, C.POINTER(TapeU32), C.POINTER(TapeU32), _P, C.c_size_t, _ERR]),
     "swh_sw_pairs_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), _P, C.c_size_t, _ERR]),
     "swh_sw_cross_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), _P, C.c_size_t, _ERR]),
+    "swh_tape_prepare_u32": (C.c_int, [_P, C.POINTER(TapeU32), C.c_int, C.POINTER(_P), _ERR]),
+    "swh_tape_prepare_u64": (C.c_int, [_P, C.POINTER(TapeU64), C.c_int, C.POINTER(_P), _ERR]),
+    "swh_prepared_info": (C.c_int, [_P, C.POINTER(PreparedInfo)]),
+    "swh_prepared_free": (C.c_int, [_P]),
+    "swh_levenshtein_pairs_prepared": (C.c_int, [_P, _P, C.POINTER(PreparedView), C.POINTER(PreparedView), C.c_uint32, _P, C.c_size_t, _ERR]),
+    "swh_levenshtein_cross_prepared": (C.c_int, [_P, _P, C.POINTER(PreparedView), C.POINTER(PreparedView), _P, C.c_size_t, _ERR]),
+    "swh_nw_pairs_prepared": (C.c_int, [_P, _P, C.POINTER(PreparedView), C.POINTER(PreparedView), _P, C.c_size_t, _ERR]),
+    "swh_nw_cross_prepared": (C.c_int, [_P, _P, C.POINTER(PreparedView), C.POINTER(PreparedView), _P, C.c_size_t, _ERR]),
+    "swh_sw_pairs_prepared": (C.c_int, [_P, _P, C.POINTER(PreparedView), C.POINTER(PreparedView), _P, C.c_size_t, _ERR]),
+    "swh_sw_cross_prepared": (C.c_int, [_P, _P, C.POINTER(PreparedView), C.POINTER(PreparedView), _P, C.c_size_t, _ERR]),
     "swh_version": (C.c_char_p, []),
     "swh_capabilities": (C.c_char_p, []),
     # harness header

@@ -83,16 +83,38 @@ static void collect_timing(Scope *scope) {
 }
 
 // Reads the events of the scope's last call once they are complete and adds the call to the running totals.
-static void harvest_timing(Scope *scope) {
-    if (!scope->profiling || !scope->stamps_pending || !scope->stamps_used) { scope->stamps_pending = false; return; }
-    for (size_t i = 0; i < scope->stamps_used; ++i) (void)hipEventSynchronize(scope->stamps[i].stop);   // two streams: no single last event
+// `complete`: the caller has synchronised with the scope's last call. Otherwise (the start of the next call in
+// asynchronous mode) completion is only known when profiling is on, through the call's stop events.
+static void harvest_timing(Scope *scope, bool complete) {
+    const bool timed = scope->profiling && scope->stamps_pending && scope->stamps_used;
+    if (timed) {
+        for (size_t i = 0; i < scope->stamps_used; ++i) (void)hipEventSynchronize(scope->stamps[i].stop);   // two streams: no single last event
+        complete = true;
+    }
     const uint64_t cells = scope->last_timing.cells, bytes = scope->last_timing.bytes;
-    collect_timing(scope);
-    scope->last_timing.cells = cells; scope->last_timing.bytes = bytes;
-    scope->totals.total_ms += scope->last_timing.total_ms;
-    scope->totals.dominant_ms += scope->last_timing.dominant_ms;
-    scope->totals.compute_ms += scope->last_timing.compute_ms;
-    scope->totals.calls += 1;
+    if (timed) {
+        collect_timing(scope);
+        scope->last_timing.cells = cells; scope->last_timing.bytes = bytes;
+    }
+    // a plan-free call reports its work units through host-mapped memory
+    if (scope->summary_pending && complete) {
+        const CallSummary sm = *scope->summary_host;
+        scope->last_timing.cells = sm.cells;
+        scope->last_timing.bytes = (scope->summary_extra_bytes ? scope->summary_extra_bytes : sm.symbols * scope->summary_sym_bytes) +
+                                   scope->summary_pairs * (2 * scope->summary_ow + scope->summary_elem);
+        if (!sm.violation) {
+            scope->hint_lengths = true;
+            scope->hint_max_la = sm.max_la; scope->hint_max_lb = sm.max_lb;
+            scope->hint_short = (uint64_t)sm.short_pairs * 4 >= scope->summary_pairs;
+        }
+    }
+    scope->summary_pending = false;
+    if (timed) {
+        scope->totals.total_ms += scope->last_timing.total_ms;
+        scope->totals.dominant_ms += scope->last_timing.dominant_ms;
+        scope->totals.compute_ms += scope->last_timing.compute_ms;
+        scope->totals.calls += 1;
+    }
     scope->stamps_pending = false;
 }
 
@@ -134,11 +156,29 @@ static bool is_device_pointer(const void *p) {
 // ---- one engine call ---------------------------------------------------------------------------
 struct HostTape { const uint8_t *data; const void *offsets; size_t count; int off64; };
 
+// swh_prepared_t: a tape made ready once -- resident on the device, measured, and (UTF-8) validated and decoded --
+// the counterpart of the `BytesTapeView` / `CharsTapeView` the reference builds ONCE outside its timed closures
+// (bench.rs:292-306) and sub-views per iteration (bench.rs:134-139).
+struct Prepared {
+    int device = 0;
+    bool utf8 = false;           // symbols are Unicode scalar values
+    bool ascii = false;          // utf8 and every code point is one byte: the byte tape is the code-point tape
+    uint32_t off64 = 0;          // width of the byte tape's offsets
+    TapeRef bytes{};             // device: u8 data, u32/u64 offsets
+    TapeRef symbols{};           // utf8: u32 code points + u64 code-point offsets; otherwise unused
+    uint64_t total_bytes = 0, total_symbols = 0;
+    uint32_t longest_bytes = 0, longest_symbols = 0;
+    std::vector<void *> owned;   // device buffers that go with the handle
+};
+
 struct CallSpec {
     HostTape a, b;
     bool cross, utf8;
     uint32_t bound;
     void *out; size_t out_stride, row_stride; bool out64;
+    const Prepared *pa = nullptr, *pb = nullptr;   // prepared tapes (both or neither); a.count / b.count = the views' counts
+    size_t a_first = 0, b_first = 0;
+    bool force_planned = false;                    // redo of a call whose plan-free kernel met a pair it could not score
 };
 
 static uint64_t read_offset(const void *offs, int off64, size_t i, bool device, hipStream_t stream) {
@@ -174,6 +214,20 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
     return status;
 }
 
+// Which kernels a unit-cost Levenshtein call runs on.
+enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort };
+
+// Strings up to this many symbols (G <= 8 blocks) are scored by the tiled kernel when their lengths are known; beyond it
+// a tile holds too few pairs per block count and the global sort of the planned path packs the waves better.
+static uint32_t tiled_longest_limit() {
+    static const uint32_t limit = [] { const char *e = getenv("STRINGWARS_AMD_TILED_MAX"); return e ? (uint32_t)atoi(e) : 256u; }();
+    return limit;
+}
+static bool direct_short_preferred() {   // STRINGWARS_AMD_SHORT=tiled sends word-sized batches to the tiled kernel instead
+    static const bool direct = [] { const char *e = getenv("STRINGWARS_AMD_SHORT"); return !(e && !strcmp(e, "tiled")); }();
+    return direct;
+}
+
 static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSpec &spec, const char **error) {
     if (!scope || !engine) return fail(error, swh_invalid_argument_k, "null scope or engine");
     if (!spec.out && spec.a.count) return fail(error, swh_invalid_argument_k, "null output pointer");
@@ -181,25 +235,41 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         return fail(error, swh_invalid_argument_k, "pairwise call needs tapes of equal count");
     const uint64_t pairs = spec.cross ? (uint64_t)spec.a.count * spec.b.count : spec.a.count;
     if (pairs >= 0xFFFFFFF0ull) return fail(error, swh_unsupported_length_k, "more than 2^32 pairs in one call");
-    harvest_timing(scope);   // an earlier asynchronous call on this scope / lane: its events are complete by now
+    const bool prepared = spec.pa != nullptr;
+    if (prepared) {
+        if (!spec.pb) return fail(error, swh_invalid_argument_k, "both tapes must be prepared, or neither");
+        if (spec.pa->utf8 != spec.pb->utf8) return fail(error, swh_invalid_argument_k, "one tape was prepared as UTF-8, the other as bytes");
+        if (spec.pa->device != scope->device || spec.pb->device != scope->device)
+            return fail(error, swh_invalid_argument_k, "a prepared tape lives on another device than the scope");
+    }
+    harvest_timing(scope, false);   // an earlier asynchronous call on this scope / lane
     scope->stamps_used = 0;
     scope->last_timing = swh_timing_t{};
     if (pairs == 0) return swh_success_k;
-    if (spec.utf8 && engine->scoring.matrix)
+    // code points of pure-ASCII tapes are their bytes: such a pair of prepared tapes runs on the byte kernels
+    const bool utf8 = prepared ? (spec.pa->utf8 && !(spec.pa->ascii && spec.pb->ascii)) : spec.utf8;
+    if (prepared && !utf8 && spec.pa->off64 != spec.pb->off64)
+        return fail(error, swh_invalid_argument_k, "prepared byte tapes must share one offset width");
+    const bool unit_utf8_only = utf8 && engine->scoring.matrix;
+    if (unit_utf8_only)
         return fail(error, swh_not_implemented_k, "affine or matrix scoring over UTF-8 code points");
     try {
         SWH_HIP_CHECK(hipSetDevice(scope->device));
         hipStream_t stream = scope->stream;
-        const size_t ow = spec.a.off64 ? 8 : 4;
+        const size_t ow = prepared ? (utf8 ? 8 : (spec.pa->off64 ? 8 : 4)) : (spec.a.off64 ? 8 : 4);
         const size_t elem = spec.out64 ? 8 : 4;
 
         // -- residency --------------------------------------------------------------------------
-        bool dev_a_data = is_device_pointer(spec.a.data), dev_a_off = is_device_pointer(spec.a.offsets);
-        bool dev_b_data = is_device_pointer(spec.b.data), dev_b_off = is_device_pointer(spec.b.offsets);
-        bool dev_out = is_device_pointer(spec.out);
-        bool same_tape = spec.b.data == spec.a.data && spec.b.offsets == spec.a.offsets && spec.b.count == spec.a.count;
+        bool dev_a_data = true, dev_a_off = true, dev_b_data = true, dev_b_off = true;
+        bool same_tape = false;
+        if (!prepared) {
+            dev_a_data = is_device_pointer(spec.a.data); dev_a_off = is_device_pointer(spec.a.offsets);
+            dev_b_data = is_device_pointer(spec.b.data); dev_b_off = is_device_pointer(spec.b.offsets);
+            same_tape = spec.b.data == spec.a.data && spec.b.offsets == spec.a.offsets && spec.b.count == spec.a.count;
+        }
+        const bool dev_out = is_device_pointer(spec.out);
         uint64_t a_bytes = 0, b_bytes = 0;
-        bool need_sizes = !dev_a_data || !dev_b_data || spec.utf8;
+        const bool need_sizes = !prepared && (!dev_a_data || !dev_b_data || utf8);
         if (need_sizes) {
             a_bytes = read_offset(spec.a.offsets, spec.a.off64, spec.a.count, dev_a_off, stream);
             b_bytes = same_tape ? a_bytes : read_offset(spec.b.offsets, spec.b.off64, spec.b.count, dev_b_off, stream);
@@ -230,25 +300,76 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             return dst;
         };
         TapeRef ta, tb;
-        ta.data = stage_in(spec.a.data, a_bytes, dev_a_data);
-        ta.offsets = stage_in(spec.a.offsets, (spec.a.count + 1) * ow, dev_a_off);
-        ta.count = spec.a.count;
-        if (same_tape) tb = ta;
-        else {
-            tb.data = stage_in(spec.b.data, b_bytes, dev_b_data);
-            tb.offsets = stage_in(spec.b.offsets, (spec.b.count + 1) * ow, dev_b_off);
-            tb.count = spec.b.count;
+        uint32_t sym_bytes = 1, off64 = (uint32_t)spec.a.off64;
+        if (prepared) {
+            auto view = [&](const Prepared *pt, size_t first, size_t count) {
+                const TapeRef &whole = utf8 ? pt->symbols : pt->bytes;
+                TapeRef t;
+                t.data = whole.data;
+                t.offsets = (const char *)whole.offsets + first * ow;
+                t.count = count;
+                return t;
+            };
+            ta = view(spec.pa, spec.a_first, spec.a.count);
+            tb = view(spec.pb, spec.b_first, spec.b.count);
+            sym_bytes = utf8 ? 4 : 1;
+            off64 = utf8 ? 1 : spec.pa->off64;
+        } else {
+            ta.data = stage_in(spec.a.data, a_bytes, dev_a_data);
+            ta.offsets = stage_in(spec.a.offsets, (spec.a.count + 1) * ow, dev_a_off);
+            ta.count = spec.a.count;
+            if (same_tape) tb = ta;
+            else {
+                tb.data = stage_in(spec.b.data, b_bytes, dev_b_data);
+                tb.offsets = stage_in(spec.b.offsets, (spec.b.count + 1) * ow, dev_b_off);
+                tb.count = spec.b.count;
+            }
         }
         char *out_dev = dev_out ? (char *)spec.out : st.take<char>(out_bytes);
 
-        // -- scratch carving ------------------------------------------------------------------------
+        // -- which kernels? ------------------------------------------------------------------------------
+        // Unit-cost Levenshtein whose string lengths are known -- from prepared tapes (a guarantee) or from the previous
+        // call on this scope (a belief the kernels verify) -- skips the planning pre-pass altogether.
         const bool bitpar_ok = engine->kind == 0 && engine->unit_costs && engine->algorithm != swh_algorithm_wavefront_k;
+        Route route = kRoutePlanned;
+        uint32_t longest = 0;
+        bool guaranteed = false;
+        if (bitpar_ok && !spec.force_planned && engine->algorithm != swh_algorithm_bitparallel_k) {
+            const bool forced = engine->algorithm == swh_algorithm_tiled_k;
+            bool known = false;
+            uint32_t la_max = 0, lb_max = 0;
+            if (prepared) {
+                known = guaranteed = true;
+                la_max = utf8 ? spec.pa->longest_symbols : spec.pa->longest_bytes;
+                lb_max = utf8 ? spec.pb->longest_symbols : spec.pb->longest_bytes;
+            } else if (scope->hint_lengths) {
+                known = true;
+                la_max = scope->hint_max_la; lb_max = scope->hint_max_lb;
+            } else if (forced) {
+                known = true;
+                la_max = lb_max = 2048;
+            }
+            // an unverified belief needs the host to look at the outcome: synchronous calls with a device or host output
+            const bool can_verify = !scope->async || !dev_out;
+            if (known && (guaranteed || can_verify)) {
+                longest = la_max > lb_max ? la_max : lb_max;
+                const uint32_t shorter_side = la_max < lb_max ? la_max : lb_max;
+                const bool band_pays = spec.bound <= 63 && longest > 32;   // plan_key(): the banded kernel wins from ~6 blocks at k = 32
+                if (forced) route = (!guaranteed || shorter_side <= 2048) ? kRouteTiled : kRoutePlanned;
+                else if (!band_pays && longest <= tiled_longest_limit())
+                    route = (longest <= 32 && sym_bytes == 1 && direct_short_preferred()) ? kRouteDirectShort : kRouteTiled;
+            }
+        }
+
+        // -- scratch carving ------------------------------------------------------------------------
         size_t need = 0;
         {
             Carver probe{nullptr, 0, 0};
-            probe.take<uint32_t>(pairs);            // perm
-            probe.take<uint16_t>(pairs);            // plan keys
-            if (spec.utf8) {
+            if (route == kRoutePlanned) {
+                probe.take<uint32_t>(pairs);            // perm
+                probe.take<uint16_t>(pairs);            // plan keys
+            }
+            if (utf8 && !prepared) {
                 probe.take<uint32_t>(a_bytes + 4); probe.take<uint64_t>(spec.a.count + 1);
                 probe.take<uint32_t>(utf8_scratch_words(a_bytes));
                 probe.take<uint32_t>(b_bytes + 4); probe.take<uint64_t>(spec.b.count + 1);
@@ -259,19 +380,17 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         }
         ensure(scope->scratch, scope->scratch_bytes, need);
         Carver sc{scope->scratch, 0, scope->scratch_bytes};
-        uint32_t *perm = sc.take<uint32_t>(pairs);
-        uint16_t *plan_keys = sc.take<uint16_t>(pairs);
-        Carver pa{scope->plan_area, 0, 0};
-        uint32_t *hist = pa.take<uint32_t>(kKeys);
-        uint32_t *cursor = pa.take<uint32_t>(kKeys);
-        PlanPartial *partials = pa.take<PlanPartial>(2 * kMaxPartials);
-        uint32_t *leftover = pa.take<uint32_t>(4);
-        Plan *plan_dev = pa.take<Plan>(1);
+        uint32_t *perm = nullptr;
+        uint16_t *plan_keys = nullptr;
+        if (route == kRoutePlanned) {
+            perm = sc.take<uint32_t>(pairs);
+            plan_keys = sc.take<uint16_t>(pairs);
+        }
+        Plan *plan_dev = scope->plan_dev;
 
         // -- UTF-8 staging ----------------------------------------------------------------------------
-        uint32_t sym_bytes = 1, off64 = (uint32_t)spec.a.off64;
         uint32_t *invalid_dev = nullptr;
-        if (spec.utf8) {
+        if (utf8 && !prepared) {
             uint32_t decode_slot = 0;
             auto decode = [&](const TapeRef &in, uint64_t bytes, TapeRef &out_tape) {
                 Utf8Args u{};
@@ -284,15 +403,9 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 launch_utf8_decode(scope, u);
                 out_tape.data = u.symbols; out_tape.offsets = u.offsets; out_tape.count = in.count;
             };
-            // the flag is carved last in the probe; take it first here is fine (sizes are padded equally)
             TapeRef da, db;
-            uint32_t *flag_slot = nullptr;
-            {
-                // reserve the flag before the decode buffers so both decodes can share it
-                flag_slot = sc.take<uint32_t>(4);
-                invalid_dev = flag_slot;
-                SWH_HIP_CHECK(hipMemsetAsync(invalid_dev, 0, 16, stream));
-            }
+            invalid_dev = sc.take<uint32_t>(4);   // one flag + two balance words, shared by both decodes
+            SWH_HIP_CHECK(hipMemsetAsync(invalid_dev, 0, 16, stream));
             if (same_tape) {
                 decode(ta, a_bytes, da);
                 db = da;
@@ -318,7 +431,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             sym_bytes = 4; off64 = 1;
         }
 
-        // -- job + pre-pass -------------------------------------------------------------------------------
+        // -- job ----------------------------------------------------------------------------------------------
         Job job{};
         job.a = ta; job.b = tb; job.pairs = pairs; job.b_count = spec.b.count; job.cross = spec.cross ? 1 : 0;
         job.bound = engine->kind == 0 ? spec.bound : SWH_UNBOUNDED;
@@ -336,8 +449,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         pre.local = engine->kind == 2 ? 1 : 0;
         pre.direct_short = bitpar_ok && sym_bytes == 1 && engine->algorithm == swh_algorithm_auto_k && scope->hint_short ? 1 : 0;
         pre.banded = pre.unit_costs && spec.bound <= 63 && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
-        pre.perm = perm; pre.keys = plan_keys; pre.hist = hist; pre.cursor = cursor; pre.partials = partials; pre.leftover = leftover; pre.plan = plan_dev;
-        launch_prepass(scope, pre);
+        pre.perm = perm; pre.keys = plan_keys; pre.hist = scope->plan_hist; pre.cursor = scope->plan_cursor;
+        pre.partials = scope->plan_partials; pre.leftover = scope->plan_leftover; pre.plan = plan_dev;
 
         KernelArgs k{};
         k.job = job; k.perm = perm; k.plan = plan_dev; k.scoring = engine->scoring;
@@ -345,6 +458,58 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         k.affine = engine->scoring.open != engine->scoring.extend ? 1 : 0;
         k.local = engine->kind == 2 ? 1 : 0;
 
+        uint32_t *invalid_host = (uint32_t *)(scope->plan_host + 1);
+        *invalid_host = 0;
+        auto copy_results_back = [&]() {
+            if (dev_out) return;
+            if (spec.cross) {
+                SWH_HIP_CHECK(hipMemcpy2DAsync(spec.out, spec.row_stride, out_dev, dev_row_stride, spec.b.count * elem,
+                                               spec.a.count, hipMemcpyDeviceToHost, stream));
+            } else if (spec.out_stride == elem) {
+                SWH_HIP_CHECK(hipMemcpyAsync(spec.out, out_dev, out_bytes, hipMemcpyDeviceToHost, stream));
+            } else {
+                SWH_HIP_CHECK(hipMemcpy2DAsync(spec.out, spec.out_stride, out_dev, elem, elem, pairs,
+                                               hipMemcpyDeviceToHost, stream));
+            }
+        };
+        auto invalid_utf8 = [&]() -> swh_status_t {
+            SWH_HIP_CHECK(hipStreamSynchronize(stream));
+            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in an input tape (marker %u)", *invalid_host - 1);
+            if (error) *error = g_error_text;
+            return swh_invalid_utf8_k;
+        };
+
+        if (route != kRoutePlanned) {
+            // ---- no pre-pass: one DP launch; its summary (work units, longest strings, "a pair did not fit") arrives in
+            // host-mapped memory with the kernel's completion ------------------------------------------------------------
+            if (route == kRouteDirectShort) launch_direct_short_alone(scope, pre);
+            else launch_bitparallel_tiled(scope, k, pairs, longest);
+            if (invalid_dev) SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));
+            copy_results_back();
+            scope->summary_sym_bytes = need_sizes ? 0 : sym_bytes;
+            scope->summary_pairs = pairs; scope->summary_ow = ow; scope->summary_elem = elem;
+            scope->summary_extra_bytes = need_sizes ? a_bytes + b_bytes : 0;
+            scope->summary_pending = true;
+            scope->stamps_pending = scope->profiling;
+            if (!scope->async || !dev_out) {
+                SWH_HIP_CHECK(hipStreamSynchronize(stream));
+                if (*invalid_host) return invalid_utf8();
+                if (scope->summary_host->violation) {
+                    // the belief about the lengths was wrong (it came from an earlier batch): redo on the planned path
+                    scope->hint_lengths = false;
+                    scope->summary_pending = false;
+                    scope->stamps_pending = false;
+                    CallSpec again = spec;
+                    again.force_planned = true;
+                    return run_call_on(scope, engine, again, error);
+                }
+                harvest_timing(scope, true);
+            }
+            return swh_success_k;
+        }
+
+        // ---- planned path: classify + counting sort on the device, then the DP kernels the plan's classes call for ----
+        launch_prepass(scope, pre);
         // The bit-parallel kernel reads its work list from the device plan, so it is enqueued right away;
         // the host copy of the plan (needed only to pick wavefront kernels) travels on a side stream and
         // overlaps it.
@@ -352,21 +517,16 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         if (pre.banded) launch_banded(scope, k, pairs);
         if (bitpar_ok) launch_bitparallel(scope, k, pairs);
         Plan &plan = *scope->plan_host;
-        uint32_t *invalid_host = (uint32_t *)(scope->plan_host + 1);
-        *invalid_host = 0;
         SWH_HIP_CHECK(hipStreamWaitEvent(scope->side_stream, scope->plan_ready, 0));
         SWH_HIP_CHECK(hipMemcpyAsync(&plan, plan_dev, sizeof(Plan), hipMemcpyDeviceToHost, scope->side_stream));
-        if (spec.utf8)
+        if (invalid_dev)
             SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, scope->side_stream));
         SWH_HIP_CHECK(hipStreamSynchronize(scope->side_stream));
         // enqueue k_direct_short next time only if short pairs are a real share of the batch (it sweeps all offsets)
         scope->hint_short = (uint64_t)plan.short_pairs * 4 >= pairs;
-        if (*invalid_host) {
-            SWH_HIP_CHECK(hipStreamSynchronize(stream));
-            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in an input tape (marker %u)", *invalid_host - 1);
-            if (error) *error = g_error_text;
-            return swh_invalid_utf8_k;
-        }
+        scope->hint_lengths = true;
+        scope->hint_max_la = plan.max_la; scope->hint_max_lb = plan.max_lb;
+        if (*invalid_host) return invalid_utf8();
 
         // patterns of more than 64 blocks: multi-pass bit-parallel kernel, carries between passes in scratch
         if (bitpar_ok && plan.class_count[kClassBpLong]) {
@@ -410,24 +570,13 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             launch_wavefront(scope, k, plan);
         }
 
-        // -- results back ------------------------------------------------------------------------------------
-        if (!dev_out) {
-            if (spec.cross) {
-                SWH_HIP_CHECK(hipMemcpy2DAsync(spec.out, spec.row_stride, out_dev, dev_row_stride, spec.b.count * elem,
-                                               spec.a.count, hipMemcpyDeviceToHost, stream));
-            } else if (spec.out_stride == elem) {
-                SWH_HIP_CHECK(hipMemcpyAsync(spec.out, out_dev, out_bytes, hipMemcpyDeviceToHost, stream));
-            } else {
-                SWH_HIP_CHECK(hipMemcpy2DAsync(spec.out, spec.out_stride, out_dev, elem, elem, pairs,
-                                               hipMemcpyDeviceToHost, stream));
-            }
-        }
+        copy_results_back();
         scope->last_timing.cells = plan.cells;
-        scope->last_timing.bytes = (need_sizes ? a_bytes + b_bytes : plan.symbols) + pairs * (2 * ow + elem);
+        scope->last_timing.bytes = (need_sizes ? a_bytes + b_bytes : plan.symbols * sym_bytes) + pairs * (2 * ow + elem);
         scope->stamps_pending = scope->profiling;
         if (!scope->async || !dev_out) {
             SWH_HIP_CHECK(hipStreamSynchronize(stream));
-            harvest_timing(scope);
+            harvest_timing(scope, true);
         }
         return swh_success_k;
     } catch (const HipFailure &f) {
@@ -447,7 +596,7 @@ using namespace swh;
 extern "C" {
 
 const char *swh_version(void) { return "0.1.0"; }
-const char *swh_capabilities(void) { return "gfx950,hip,wavefront,bitparallel,banded,utf8,bounded,nw-linear,nw-affine,sw-linear,sw-affine,cross"; }
+const char *swh_capabilities(void) { return "gfx950,hip,wavefront,bitparallel,tiled,banded,utf8,bounded,nw-linear,nw-affine,sw-linear,sw-affine,cross,prepared"; }
 
 static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_t *out, const char **error) {
     if (!out) return fail(error, swh_invalid_argument_k, "null scope pointer");
@@ -470,10 +619,24 @@ static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_
         if (borrow) { scope->stream = (hipStream_t)stream; scope->owns_stream = false; }
         else { SWH_HIP_CHECK(hipStreamCreateWithFlags(&scope->stream, hipStreamNonBlocking)); scope->owns_stream = true; }
         SWH_HIP_CHECK(hipHostMalloc((void **)&scope->plan_host, sizeof(Plan) + 64, hipHostMallocDefault));
-        size_t plan_area_bytes = 2 * ((kKeys * 4 + 255) & ~255) + ((2 * kMaxPartials * sizeof(PlanPartial) + 255) & ~255) + 256 +
-                                 ((sizeof(Plan) + 255) & ~255);
-        SWH_HIP_CHECK(hipMalloc((void **)&scope->plan_area, plan_area_bytes));
-        SWH_HIP_CHECK(hipMemset(scope->plan_area, 0, plan_area_bytes));
+        {   // plan area: hist | cursor | partials | leftover + done counter | plan; zeroed once (the kernels re-zero what they use)
+            Carver measure{nullptr, 0, 0};
+            measure.take<uint32_t>(kKeys); measure.take<uint32_t>(kKeys); measure.take<PlanPartial>(2 * kMaxPartials);
+            measure.take<uint32_t>(8); measure.take<Plan>(1);
+            SWH_HIP_CHECK(hipMalloc((void **)&scope->plan_area, measure.used));
+            SWH_HIP_CHECK(hipMemset(scope->plan_area, 0, measure.used));
+            Carver pa{scope->plan_area, 0, measure.used};
+            scope->plan_hist = pa.take<uint32_t>(kKeys);
+            scope->plan_cursor = pa.take<uint32_t>(kKeys);
+            scope->plan_partials = pa.take<PlanPartial>(2 * kMaxPartials);
+            scope->plan_leftover = pa.take<uint32_t>(8);
+            scope->done_counter = scope->plan_leftover + 4;
+            scope->plan_dev = pa.take<Plan>(1);
+        }
+        // summary of plan-free calls: pinned, mapped, coherent -- the kernels write it, the host reads it after synchronising
+        SWH_HIP_CHECK(hipHostMalloc((void **)&scope->summary_host, 256, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(scope->summary_host, 0, 256);
+        SWH_HIP_CHECK(hipHostGetDevicePointer((void **)&scope->summary_dev, scope->summary_host, 0));
         SWH_HIP_CHECK(hipStreamCreateWithFlags(&scope->side_stream, hipStreamNonBlocking));
         SWH_HIP_CHECK(hipEventCreateWithFlags(&scope->plan_ready, hipEventDisableTiming));
         SWH_HIP_CHECK(hipEventCreateWithFlags(&scope->fork_ev, hipEventDisableTiming));
@@ -509,6 +672,7 @@ swh_status_t swh_scope_free(swh_scope_t handle) {
     if (scope->stage) (void)hipFree(scope->stage);
     if (scope->boundary) (void)hipFree(scope->boundary);
     if (scope->plan_host) (void)hipHostFree(scope->plan_host);
+    if (scope->summary_host) (void)hipHostFree(scope->summary_host);
     if (scope->plan_area) (void)hipFree(scope->plan_area);
     if (scope->side_stream) (void)hipStreamDestroy(scope->side_stream);
     if (scope->fork_ev) (void)hipEventDestroy(scope->fork_ev);
@@ -535,11 +699,11 @@ swh_status_t swh_scope_synchronize(swh_scope_t handle, const char **error) {
         if (lane) {
             hipError_t lerr = hipStreamSynchronize(lane->stream);
             if (lerr != hipSuccess) return fail_hip(error, HipFailure{lerr, "hipStreamSynchronize (lane)"});
-            harvest_timing(lane);
+            harvest_timing(lane, true);
         }
     hipError_t err = hipStreamSynchronize(scope->stream);
     if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipStreamSynchronize"});
-    harvest_timing(scope);
+    harvest_timing(scope, true);
     if (scope->pipelined && scope->last_lane) scope->last_timing = scope->last_lane->last_timing;
     return swh_success_k;
 }
@@ -642,6 +806,100 @@ swh_status_t swh_copy_to_host(swh_scope_t handle, void *dst, const void *src, si
     if (err == hipSuccess) err = hipStreamSynchronize(scope->stream);
     if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipMemcpy D2H"});
     return swh_success_k;
+}
+
+// ---- prepared tapes ----------------------------------------------------------------------------------
+static void free_prepared(Prepared *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (void *buffer : p->owned) (void)hipFree(buffer);
+    delete p;
+}
+
+static swh_status_t prepare_tape(Scope *scope, const HostTape &tape, bool utf8, swh_prepared_t *out, const char **error) {
+    if (!scope || !out) return fail(error, swh_invalid_argument_k, "null argument");
+    *out = nullptr;
+    if (scope->pipelined) return fail(error, swh_invalid_argument_k, "prepare tapes before switching the scope to pipelined mode");
+    Prepared *p = new Prepared();
+    try {
+        SWH_HIP_CHECK(hipSetDevice(scope->device));
+        hipStream_t stream = scope->stream;
+        p->device = scope->device;
+        p->utf8 = utf8;
+        p->off64 = (uint32_t)tape.off64;
+        const size_t ow = tape.off64 ? 8 : 4;
+        const bool dev_data = is_device_pointer(tape.data), dev_off = is_device_pointer(tape.offsets);
+        p->total_bytes = tape.count || tape.offsets ? read_offset(tape.offsets, tape.off64, tape.count, dev_off, stream) : 0;
+        auto own = [&](size_t bytes) -> void * {
+            void *buffer = nullptr;
+            SWH_HIP_CHECK(hipMalloc(&buffer, bytes ? bytes : 16));
+            p->owned.push_back(buffer);
+            return buffer;
+        };
+        // residency: host tapes are uploaded once (`BytesTape<u64, UnifiedAlloc>::extend`, bench.rs:292-301)
+        const void *data = tape.data, *offsets = tape.offsets;
+        if (!dev_data) {
+            void *buffer = own(p->total_bytes + 16);
+            if (p->total_bytes) SWH_HIP_CHECK(hipMemcpyAsync(buffer, tape.data, p->total_bytes, hipMemcpyHostToDevice, stream));
+            data = buffer;
+        }
+        if (!dev_off) {
+            void *buffer = own((tape.count + 1) * ow + 16);
+            SWH_HIP_CHECK(hipMemcpyAsync(buffer, tape.offsets, (tape.count + 1) * ow, hipMemcpyHostToDevice, stream));
+            offsets = buffer;
+        }
+        p->bytes = TapeRef{data, offsets, tape.count};
+        // measurements: longest string in bytes (and in code points below)
+        uint32_t *words = (uint32_t *)own(64);   // [0] longest bytes, [1] longest symbols, [4..7] UTF-8 flag + balances
+        SWH_HIP_CHECK(hipMemsetAsync(words, 0, 64, stream));
+        launch_tape_longest(scope, offsets, p->off64, tape.count, words);
+        uint64_t total_symbols = p->total_bytes;
+        if (utf8) {
+            // validate + decode once: `CharsTapeView::try_from` (bench.rs:303-306)
+            Utf8Args u{};
+            u.in = p->bytes; u.off64 = p->off64; u.total_bytes = p->total_bytes; u.slot = 0;
+            u.symbols = (uint32_t *)own((p->total_bytes + 4) * sizeof(uint32_t));
+            u.offsets = (uint64_t *)own((tape.count + 1) * sizeof(uint64_t));
+            void *scratch = nullptr;
+            SWH_HIP_CHECK(hipMalloc(&scratch, utf8_scratch_words(p->total_bytes) * sizeof(uint32_t) + 256));
+            u.counts = (uint32_t *)scratch;
+            u.invalid = words + 4;
+            hipError_t decode_error = hipSuccess;
+            try { launch_utf8_decode(scope, u); } catch (const HipFailure &f) { decode_error = f.code; }
+            launch_tape_longest(scope, u.offsets, 1, tape.count, words + 1);
+            uint32_t host_words[8] = {0};
+            SWH_HIP_CHECK(hipMemcpyAsync(host_words, words, sizeof host_words, hipMemcpyDeviceToHost, stream));
+            SWH_HIP_CHECK(hipMemcpyAsync(&total_symbols, u.offsets + tape.count, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            SWH_HIP_CHECK(hipStreamSynchronize(stream));
+            (void)hipFree(scratch);
+            if (decode_error != hipSuccess) throw HipFailure{decode_error, "UTF-8 decode"};
+            if (host_words[4]) {
+                free_prepared(p);
+                snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in the tape (marker %u)", host_words[4] - 1);
+                if (error) *error = g_error_text;
+                return swh_invalid_utf8_k;
+            }
+            p->longest_bytes = host_words[0];
+            p->longest_symbols = host_words[1];
+            p->symbols = TapeRef{u.symbols, u.offsets, tape.count};
+            p->ascii = total_symbols == p->total_bytes;
+        } else {
+            uint32_t host_words[2] = {0, 0};
+            SWH_HIP_CHECK(hipMemcpyAsync(host_words, words, sizeof host_words, hipMemcpyDeviceToHost, stream));
+            SWH_HIP_CHECK(hipStreamSynchronize(stream));
+            p->longest_bytes = p->longest_symbols = host_words[0];
+            p->symbols = p->bytes;
+        }
+        p->total_symbols = total_symbols;
+        *out = (swh_prepared_t)p;
+        return swh_success_k;
+    } catch (const HipFailure &f) {
+        free_prepared(p);
+        return fail_hip(error, f);
+    } catch (const std::bad_alloc &) {
+        free_prepared(p);
+        return fail(error, swh_bad_alloc_k, "host allocation failed");
+    }
 }
 
 // ---- engines --------------------------------------------------------------------------------------
@@ -876,6 +1134,81 @@ swh_status_t swh_sw_pairs_u64tape(swh_sw_t e, swh_scope_t s, const swh_tape_u64_
 swh_status_t swh_sw_cross_u64tape(swh_sw_t e, swh_scope_t s, const swh_tape_u64_t *a, const swh_tape_u64_t *b,
                                   ptrdiff_t *out, size_t row_stride, const char **error) {
     return cross_call(e, 2, s, a, b, false, out, row_stride, error);
+}
+
+// ---- prepared tapes and the calls on them ------------------------------------------------------------------
+swh_status_t swh_tape_prepare_u32(swh_scope_t scope, const swh_tape_u32_t *tape, int utf8, swh_prepared_t *prepared, const char **error) {
+    if (!tape) return fail(error, swh_invalid_argument_k, "null tape");
+    return prepare_tape((Scope *)scope, SWH_TAPE(tape, 0), utf8 != 0, prepared, error);
+}
+swh_status_t swh_tape_prepare_u64(swh_scope_t scope, const swh_tape_u64_t *tape, int utf8, swh_prepared_t *prepared, const char **error) {
+    if (!tape) return fail(error, swh_invalid_argument_k, "null tape");
+    return prepare_tape((Scope *)scope, SWH_TAPE(tape, 1), utf8 != 0, prepared, error);
+}
+swh_status_t swh_prepared_info(swh_prepared_t handle, swh_prepared_info_t *info) {
+    const Prepared *p = (const Prepared *)handle;
+    if (!p || !info) return swh_invalid_argument_k;
+    info->count = (size_t)p->bytes.count;
+    info->bytes = p->total_bytes;
+    info->symbols = p->total_symbols;
+    info->longest = p->utf8 ? p->longest_symbols : p->longest_bytes;
+    info->utf8 = p->utf8 ? 1 : 0;
+    info->ascii = p->ascii ? 1 : 0;
+    return swh_success_k;
+}
+swh_status_t swh_prepared_free(swh_prepared_t handle) {
+    free_prepared((Prepared *)handle);
+    return swh_success_k;
+}
+
+static swh_status_t prepared_call(void *e, int kind, swh_scope_t s, const swh_prepared_view_t *a, const swh_prepared_view_t *b,
+                                  bool cross, uint32_t bound, void *out, size_t stride, const char **error) {
+    if (!a || !a->tape) return fail(error, swh_invalid_argument_k, "null prepared view");
+    if (e && ((Engine *)e)->kind != kind) return fail(error, swh_invalid_argument_k, "engine kind mismatch");
+    const swh_prepared_view_t *bb = (b && b->tape) ? b : (cross ? a : nullptr);
+    if (!bb) return fail(error, swh_invalid_argument_k, "null prepared view");
+    const Prepared *pa = (const Prepared *)a->tape, *pb = (const Prepared *)bb->tape;
+    if (a->first > pa->bytes.count || a->count > pa->bytes.count - a->first || bb->first > pb->bytes.count ||
+        bb->count > pb->bytes.count - bb->first)
+        return fail(error, swh_invalid_argument_k, "view exceeds the prepared tape");
+    CallSpec spec{};
+    spec.a = HostTape{nullptr, nullptr, a->count, 0};
+    spec.b = HostTape{nullptr, nullptr, bb->count, 0};
+    spec.cross = cross; spec.utf8 = pa->utf8; spec.bound = bound; spec.out = out;
+    if (cross) {
+        spec.out_stride = 8; spec.out64 = true;
+        spec.row_stride = stride ? stride : bb->count * 8;
+        if (spec.row_stride < bb->count * 8) return fail(error, swh_invalid_argument_k, "row_stride_bytes too small");
+    } else {
+        spec.out_stride = stride ? stride : 4; spec.out64 = false;
+        if (spec.out_stride < 4) return fail(error, swh_invalid_argument_k, "out_stride_bytes must be >= 4");
+    }
+    spec.pa = pa; spec.pb = pb; spec.a_first = a->first; spec.b_first = bb->first;
+    return run_call((Scope *)s, (Engine *)e, spec, error);
+}
+swh_status_t swh_levenshtein_pairs_prepared(swh_levenshtein_t e, swh_scope_t s, const swh_prepared_view_t *a, const swh_prepared_view_t *b,
+                                            uint32_t bound, uint32_t *out, size_t stride, const char **error) {
+    return prepared_call(e, 0, s, a, b, false, bound, out, stride, error);
+}
+swh_status_t swh_levenshtein_cross_prepared(swh_levenshtein_t e, swh_scope_t s, const swh_prepared_view_t *a, const swh_prepared_view_t *b,
+                                            size_t *out, size_t row_stride, const char **error) {
+    return prepared_call(e, 0, s, a, b, true, SWH_UNBOUNDED, out, row_stride, error);
+}
+swh_status_t swh_nw_pairs_prepared(swh_nw_t e, swh_scope_t s, const swh_prepared_view_t *a, const swh_prepared_view_t *b, int32_t *out,
+                                   size_t stride, const char **error) {
+    return prepared_call(e, 1, s, a, b, false, SWH_UNBOUNDED, out, stride, error);
+}
+swh_status_t swh_nw_cross_prepared(swh_nw_t e, swh_scope_t s, const swh_prepared_view_t *a, const swh_prepared_view_t *b, ptrdiff_t *out,
+                                   size_t row_stride, const char **error) {
+    return prepared_call(e, 1, s, a, b, true, SWH_UNBOUNDED, out, row_stride, error);
+}
+swh_status_t swh_sw_pairs_prepared(swh_sw_t e, swh_scope_t s, const swh_prepared_view_t *a, const swh_prepared_view_t *b, int32_t *out,
+                                   size_t stride, const char **error) {
+    return prepared_call(e, 2, s, a, b, false, SWH_UNBOUNDED, out, stride, error);
+}
+swh_status_t swh_sw_cross_prepared(swh_sw_t e, swh_scope_t s, const swh_prepared_view_t *a, const swh_prepared_view_t *b, ptrdiff_t *out,
+                                   size_t row_stride, const char **error) {
+    return prepared_call(e, 2, s, a, b, true, SWH_UNBOUNDED, out, row_stride, error);
 }
 
 }  // extern "C"

@@ -83,6 +83,18 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row_shr 1/2/4/8 inside each row of 16, then
+// row_bcast 15 / 31 carry the row totals forward).
+__device__ __forceinline__ uint32_t wave_inclusive_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // Bit-parallel orientation: the "pattern" string supplies the 32-row blocks (lanes), the "text" string the steps.
 // Work is blocks x (text + blocks - 1) block-steps, so the cheaper assignment wins -- usually the LONGER string
 // as pattern when both need the same number of blocks (fewer steps), the shorter one when it saves a block.
@@ -119,6 +131,78 @@ struct Plan {
 };
 
 struct PlanPartial { unsigned long long cells, symbols; uint32_t max_la, max_lb, short_pairs, pad; };
+static_assert(sizeof(PlanPartial) == 32, "report_call_summary reads a partial as four 64-bit words");
+// What a call that ran without the planning pre-pass (tiled.hip, k_direct_short alone) reports back: written by the last
+// workgroup to finish, straight into host-mapped memory, so the host has it after the stream synchronisation it does
+// anyway -- no copy, no extra round trip. `violation`: some pair did not fit the kernel (the call must be redone on the
+// planned path).
+struct CallSummary {
+    unsigned long long cells, symbols;
+    uint32_t max_la, max_lb, short_pairs, violation;
+};
+// Tail of the kernels that run without the planning pre-pass, called by every thread of the workgroup; thread 0 passes the
+// workgroup's sums (`pad` != 0: it met a pair it could not score). The last workgroup to get here folds all partials and
+// writes the call's summary into host-mapped memory; the counter resets itself for the next launch.
+struct SummaryLds {   // workgroup scratch of report_call_summary (the caller lends it: <= 16 waves per workgroup)
+    unsigned long long rcells[16], rsyms[16];
+    uint32_t rmaxa[16], rmaxb[16], rshort[16], rviol[16];
+    uint32_t is_last;
+};
+__device__ __forceinline__ void report_call_summary(const PlanPartial &mine, PlanPartial *partials, uint32_t *done_counter,
+                                                    CallSummary *summary, SummaryLds &lds) {
+    auto &rcells = lds.rcells; auto &rsyms = lds.rsyms;
+    auto &rmaxa = lds.rmaxa; auto &rmaxb = lds.rmaxb; auto &rshort = lds.rshort; auto &rviol = lds.rviol;
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = mine;
+        __threadfence();
+        lds.is_last = atomicAdd(done_counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!lds.is_last) return;
+    __threadfence();
+    unsigned long long cells = 0, syms = 0;
+    uint32_t maxa = 0, maxb = 0, shorts = 0, viol = 0;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
+        const unsigned long long *q = (const unsigned long long *)&partials[i];
+        cells += __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        syms += __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t pa = (uint32_t)w2, pb = (uint32_t)(w2 >> 32);
+        maxa = pa > maxa ? pa : maxa;
+        maxb = pb > maxb ? pb : maxb;
+        shorts += (uint32_t)w3;
+        viol |= (uint32_t)(w3 >> 32);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cells += __shfl_xor(cells, off);
+        syms += __shfl_xor(syms, off);
+        shorts += __shfl_xor(shorts, off);
+        viol |= __shfl_xor(viol, off);
+        const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+        maxa = oa > maxa ? oa : maxa;
+        maxb = ob > maxb ? ob : maxb;
+    }
+    const uint32_t wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { rcells[wave] = cells; rsyms[wave] = syms; rmaxa[wave] = maxa; rmaxb[wave] = maxb; rshort[wave] = shorts; rviol[wave] = viol; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < waves; ++w) {
+            cells += rcells[w]; syms += rsyms[w]; shorts += rshort[w]; viol |= rviol[w];
+            maxa = rmaxa[w] > maxa ? rmaxa[w] : maxa;
+            maxb = rmaxb[w] > maxb ? rmaxb[w] : maxb;
+        }
+        __hip_atomic_store(&summary->cells, cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&summary->symbols, syms, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&summary->max_la, maxa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&summary->max_lb, maxb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&summary->short_pairs, shorts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&summary->violation, viol ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // partials[0, kMaxPartials) belong to k_plan_hist, [kMaxPartials, 2 kMaxPartials) to k_direct_short (see PrepassArgs::leftover)
 constexpr int kMaxPartials = 2048;
 
@@ -181,6 +265,9 @@ struct Scope {
     size_t boundary_bytes = 0;
     Plan *plan_host = nullptr;  // pinned
     char *plan_area = nullptr;  // device: hist | cursor | partials | plan, zeroed once (the scan kernel re-zeroes hist)
+    uint32_t *plan_hist = nullptr, *plan_cursor = nullptr, *plan_leftover = nullptr;   // carved from plan_area at scope creation
+    PlanPartial *plan_partials = nullptr;
+    Plan *plan_dev = nullptr;
     hipStream_t side_stream = nullptr;  // plan read-back overlaps the first DP kernel
     hipEvent_t plan_ready = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;   // second tape's UTF-8 decode runs on side_stream beside the first's
@@ -190,6 +277,16 @@ struct Scope {
     unsigned wf_toggle = 0;
     uint64_t wf_side_boundary = 0;   // int32 elements between the two streams' boundary areas
     bool hint_short = true;     // the previous call saw short pairs: enqueue k_direct_short (first call: assume yes)
+    // Longest strings of the previous call on this scope (symbols), the basis for running the NEXT call on raw tapes
+    // without a planning pre-pass; the kernels verify it per pair and raise CallSummary::violation if it no longer holds.
+    bool hint_lengths = false;
+    uint32_t hint_max_la = 0, hint_max_lb = 0;
+    CallSummary *summary_host = nullptr;   // pinned, mapped: written by kernels, read by the host after a synchronisation
+    CallSummary *summary_dev = nullptr;    // the same memory as the device sees it
+    uint32_t *done_counter = nullptr;      // device: workgroups finished (self-resetting), for "last one reports"
+    bool summary_pending = false;          // a plan-free call's summary has not been read yet (harvest_timing)
+    uint64_t summary_pairs = 0, summary_extra_bytes = 0;   // what the algorithmic byte count of that call needs besides the summary
+    uint32_t summary_sym_bytes = 1, summary_ow = 8, summary_elem = 4;
     // Pipelined mode: calls alternate between `lanes` (internal scopes with their own stream, scratch and plan
     // buffers), so the planning pre-pass of call i+1 overlaps the DP kernel of call i. Results are ordered for the
     // caller by swh_scope_join / swh_scope_synchronize.
@@ -249,6 +346,9 @@ struct PrepassArgs {
     // once (nothing to plan); k_plan_scan folds the sums and re-zeroes the counter.
     uint32_t *leftover;
     Plan *plan;             // out (device)
+    // k_direct_short on its own (launch_direct_short_alone): no planning kernels follow, the last workgroup reports
+    CallSummary *summary;
+    uint32_t *done_counter;
 };
 void launch_prepass(Scope *scope, const PrepassArgs &args);
 
@@ -263,6 +363,14 @@ struct KernelArgs {
     uint64_t boundary_stride;  // int32 elements per group slot
 };
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs);
+// tiled.hip: bit-parallel Levenshtein with per-workgroup planning (no pre-pass, no host round trip)
+struct TilePlan { uint32_t tile, tiles, blocks, shift; };
+TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text);
+void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text);
+// prepass.hip: k_direct_short on its own (every pair known to be word-sized)
+void launch_direct_short_alone(Scope *scope, const PrepassArgs &args);
+// Longest string of a tape (in offsets units) -> *longest (device word, atomicMax; zero it first)
+void launch_tape_longest(Scope *scope, const void *offsets, uint32_t off64, uint64_t count, uint32_t *longest);
 // pairs of class kClassBpLong (needs the host plan: carry scratch is sized by the longest text)
 void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_host);
 // u32 carry words per wave of k_bitparallel_long: 2 pass parities x (+1 | -1 deltas) x one bit per text column, plus

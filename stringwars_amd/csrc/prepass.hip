@@ -476,6 +476,13 @@ __device__ __forceinline__ void direct_short_run(const PrepassArgs &args, uint32
         atomicAdd(&lleft, left);
     }
     __syncthreads();
+    if (args.summary) {
+        // on its own (launch_direct_short_alone): nobody plans the pairs this kernel could not score -- report them
+        __shared__ SummaryLds summary_lds;
+        report_call_summary(PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, lleft ? 1u : 0u}, args.partials + kMaxPartials,
+                            args.done_counter, args.summary, summary_lds);
+        return;
+    }
     if (threadIdx.x == 0) {
         args.partials[kMaxPartials + blockIdx.x] = PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, 0};
         if (lleft) atomicAdd(args.leftover, lleft);
@@ -494,6 +501,49 @@ __global__ __launch_bounds__(256, 4) void k_direct_short(PrepassArgs args) {
     else direct_short_run<Off, false>(args, table, a_total, b_total);
 }
 
+static int direct_short_blocks(const Scope *scope, uint64_t pairs) {
+    int dblocks = (int)((pairs + 255) / 256);
+    if (dblocks > scope->compute_units * 4) dblocks = scope->compute_units * 4;
+    if (dblocks > kMaxPartials) dblocks = kMaxPartials;
+    return dblocks < 1 ? 1 : dblocks;
+}
+
+// Every pair is known (tape statistics) or believed (previous call; verified by the kernel) to be word-sized: one
+// launch, no planning kernels, the summary comes back through host-mapped memory.
+void launch_direct_short_alone(Scope *scope, const PrepassArgs &args_in) {
+    PrepassArgs args = args_in;
+    args.direct_short = 1;
+    args.partials = scope->plan_partials;
+    args.summary = scope->summary_dev;
+    args.done_counter = scope->done_counter;
+    const int dblocks = direct_short_blocks(scope, args.job.pairs);
+    StampGuard guard(scope, "direct_short");
+    if (args.off64) hipLaunchKernelGGL(k_direct_short<uint64_t>, dim3(dblocks), dim3(256), 0, scope->stream, args);
+    else hipLaunchKernelGGL(k_direct_short<uint32_t>, dim3(dblocks), dim3(256), 0, scope->stream, args);
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
+// Longest string of a tape, for swh_tape_prepare: grid-stride maximum of offsets[i + 1] - offsets[i].
+template <typename Off>
+__global__ __launch_bounds__(256) void k_tape_longest(const Off *offsets, uint64_t count, uint32_t *longest) {
+    uint64_t best = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t len = (uint64_t)(offsets[i + 1] - offsets[i]);
+        best = len > best ? len : best;
+    }
+    uint32_t v = best > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)best;
+    v = wave_max_u32(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(longest, v);
+}
+void launch_tape_longest(Scope *scope, const void *offsets, uint32_t off64, uint64_t count, uint32_t *longest) {
+    if (!count) return;
+    uint64_t blocks64 = (count + 1023) / 1024;
+    const uint32_t blocks = (uint32_t)(blocks64 > (uint64_t)scope->compute_units * 8 ? (uint64_t)scope->compute_units * 8 : blocks64);
+    if (off64) hipLaunchKernelGGL(k_tape_longest<uint64_t>, dim3(blocks), dim3(256), 0, scope->stream, (const uint64_t *)offsets, count, longest);
+    else hipLaunchKernelGGL(k_tape_longest<uint32_t>, dim3(blocks), dim3(256), 0, scope->stream, (const uint32_t *)offsets, count, longest);
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
 void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     PrepassArgs args = args_in;
     hipStream_t stream = scope->stream;
@@ -506,9 +556,7 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     int dblocks = 0;
     if (args.direct_short) {
         StampGuard guard(scope, "direct_short");
-        dblocks = (int)((pairs + 255) / 256);
-        if (dblocks > scope->compute_units * 4) dblocks = scope->compute_units * 4;
-        if (dblocks > kMaxPartials) dblocks = kMaxPartials;
+        dblocks = direct_short_blocks(scope, pairs);
         if (args.off64) hipLaunchKernelGGL(k_direct_short<uint64_t>, dim3(dblocks), dim3(256), 0, stream, args);
         else hipLaunchKernelGGL(k_direct_short<uint32_t>, dim3(dblocks), dim3(256), 0, stream, args);
     }
@@ -717,18 +765,6 @@ __device__ __noinline__ void utf8_tile_write_edge(Utf8WriteLds &lds, const uint8
     if (threadIdx.x == 0) balance[tile] = wave_bal[0] + wave_bal[1] + wave_bal[2] + wave_bal[3];
 }
 
-// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row_shr 1/2/4/8 inside each row of 16, then
-// row_bcast 15 / 31 carry the row totals forward).
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-
 // Lead bytes (everything but 10xxxxxx) of four packed bytes as 0x80 flags: !bit7 | bit6.
 __device__ __forceinline__ uint32_t lead_flags4(uint32_t dw) { return (~dw | (dw << 1)) & 0x80808080u; }
 
@@ -772,7 +808,7 @@ __global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, ui
     uint32_t incls[kUtf8Passes];
 #pragma unroll
     for (int q = 0; q < kUtf8Passes; ++q) {
-        incls[q] = wave_inclusive_sum((uint32_t)__popc(lead_flags4(curs[q])));
+        incls[q] = wave_inclusive_sum_u32((uint32_t)__popc(lead_flags4(curs[q])));
         if (lane == 63) lds.wave_tot[q][wave] = incls[q];
         lds.raw[q * 256 + threadIdx.x] = curs[q];
     }

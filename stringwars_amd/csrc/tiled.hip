@@ -1,0 +1,321 @@
+// tiled.hip -- unit-cost Levenshtein without a planning pre-pass: every workgroup plans its own tile.
+//
+// The globally planned path (prepass.hip -> bitparallel.hip) spends three launches (histogram, scan, scatter), a
+// permutation array and a round trip of the plan to the host before the first DP column is computed -- a third of a
+// synchronous call on a 1 M-pair batch of tokens, nine tenths of it on 10 K words. Here a workgroup takes a TILE of
+// consecutive pairs (<= 1024), and in LDS
+//   B. classifies them: pattern side, G = blocks of 32 rows, text length n; finishes the trivial ones;
+//   C. moves a class's few left-over pairs up into the next class when that saves a mostly empty work item;
+//   D-F. counting-sorts the tile by (G, n bucket) into a u16 index list;
+//   G. runs the work items of bp_item.hpp on it, longest first, waves taking items from an LDS ticket.
+// Pairs of one item are consecutive in the sorted tile, so the lanes of a wave finish together just as with the global
+// sort; what is lost is one partly filled item per class and tile. What is gained: one launch per call, no host
+// round trip, no permutation / key arrays in HBM, and results that land in a 4 KB window per tile instead of being
+// scattered over the whole output.
+//
+// The kernel is exact for every pair whose pattern fits 64 blocks (2048 symbols). A longer pair raises the
+// `violation` flag (host-mapped memory) and is left alone: the host only picks this kernel when tape statistics or the
+// previous call say no such pair exists, checks the flag after the call and falls back to the planned path if it is
+// set (api.hip).
+#include "bp_item.hpp"
+
+namespace swh {
+
+constexpr int kTileMax = 1024;     // pairs per tile: u16 indices, and tiles must outnumber the workgroups
+constexpr int kTileBuckets = 32;   // text-length buckets per class
+constexpr int kTileClasses = 64;
+constexpr int kTileBins = kTileClasses * kTileBuckets;
+
+struct TileLds {
+    uint16_t sorted[kTileMax];            // tile-local pair indices, sorted by (class, text-length bucket)
+    uint32_t bins[kTileBins / 2];         // two u16 counters per word: counts, then exclusive prefixes
+    uint32_t class_count[kTileClasses];   // pairs per natural class; after step C: per final class
+    uint16_t class_thr[kTileClasses];     // ranks >= thr move up to class_tgt
+    uint16_t class_tgt[kTileClasses];
+    uint32_t item_prefix[kTileClasses + 1];
+    uint32_t wave_sums[4];
+    uint32_t ticket;
+};
+struct TileTail {   // after the last tile the counters' space serves the call summary
+    unsigned long long cells, syms;
+    uint32_t maxa, maxb, shorts, misfit;
+    SummaryLds summary;
+};
+static_assert(sizeof(TileTail) <= sizeof(uint32_t) * kTileBins / 2, "the tail reuses TileLds::bins");
+
+template <typename Sym> constexpr size_t tiled_lds_bytes() {
+    return (size_t)BpTraits<Sym>::kWaves * (bp_table_words<Sym>() + 64) * 4 + sizeof(TileLds);
+}
+
+struct TiledArgs {
+    KernelArgs k;
+    uint32_t tile;          // pairs per tile
+    uint32_t tiles;
+    uint32_t shift;         // text-length bucket = min(n >> shift, kTileBuckets - 1)
+    PlanPartial *partials;  // per-workgroup work-unit sums (cells, symbols, maxima, "met a pair that does not fit")
+    uint32_t *done_counter;
+    CallSummary *summary;   // host-mapped: the last workgroup reports (common.hpp: report_call_summary)
+};
+
+template <typename Sym, bool kWide>
+__device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, const uint64_t a_total, const uint64_t b_total) {
+    constexpr int kWaves = BpTraits<Sym>::kWaves, kThreads = kWaves * 64, kTableWords = bp_table_words<Sym>();
+    constexpr int kPer = kTileMax / kThreads;   // pairs per thread and tile
+    const KernelArgs &args = targs.k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    BpWave<Sym> wv;
+    wv.init((uint32_t *)smem + (size_t)wave * kTableWords, (uint32_t *)smem + (size_t)kWaves * kTableWords + wave * 64, lane,
+            a_total, b_total);
+    TileLds &tl = *(TileLds *)(smem + (size_t)kWaves * (kTableWords + 64) * 4);
+    unsigned long long cells = 0, syms = 0;
+    uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
+
+    for (uint32_t tile = blockIdx.x; tile < targs.tiles; tile += gridDim.x) {
+        const uint64_t base = (uint64_t)tile * targs.tile;
+        const uint32_t count = (uint32_t)(args.job.pairs - base < targs.tile ? args.job.pairs - base : targs.tile);
+        // ---- A: clear the counters ------------------------------------------------------------------------------
+        for (int i = threadIdx.x; i < kTileBins / 2; i += kThreads) tl.bins[i] = 0;
+        if (threadIdx.x < kTileClasses) tl.class_count[threadIdx.x] = 0;
+        if (threadIdx.x == 0) tl.ticket = 0;
+        __syncthreads();
+        // ---- B: classify my pairs ---------------------------------------------------------------------------------
+        uint32_t cls[kPer], txt[kPer], rank[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t idx = (uint32_t)k * kThreads + threadIdx.x;
+            cls[k] = 0xFFu; txt[k] = 0; rank[k] = 0;
+            if (idx < count) {
+                const uint64_t p = base + idx;
+                uint64_t a0, b0;
+                uint32_t la, lb;
+                if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
+                else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
+                cells += (unsigned long long)la * lb;
+                syms += (unsigned long long)la + lb;
+                maxa = la > maxa ? la : maxa;
+                maxb = lb > maxb ? lb : maxb;
+                shorts += (la <= 32 && lb <= 32) ? 1u : 0u;
+                const uint32_t diff = la > lb ? la - lb : lb - la;
+                if (la == 0 || lb == 0) {
+                    store_result(args.job, p, (int64_t)clamp_bound(la + lb, args.job.bound));
+                } else if (args.job.bound != 0xFFFFFFFFu && diff > args.job.bound) {
+                    store_result(args.job, p, (int64_t)args.job.bound + 1);
+                } else {
+                    const bool pattern_is_a = bp_pattern_is_a(la, lb);
+                    const uint32_t m = pattern_is_a ? la : lb, n = pattern_is_a ? lb : la;
+                    const uint32_t g = (m + 31) >> 5;
+                    if (g > (uint32_t)kTileClasses) {
+                        misfit = 1;   // both strings beyond 2048 symbols: not for this kernel (the host redoes the call)
+                    } else {
+                        cls[k] = g - 1;
+                        txt[k] = n;
+                        rank[k] = atomicAdd(&tl.class_count[g - 1], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- C: left-overs move up; work items per class (wave 0) -------------------------------------------------
+        if (wave == 0) {
+            const uint32_t mine = tl.class_count[lane];
+            tl.class_thr[lane] = (uint16_t)mine;
+            tl.class_tgt[lane] = (uint16_t)lane;
+            unsigned long long present = __ballot(mine != 0);
+            wave_lds_fence();
+            if (lane == 0) {
+                uint32_t incoming = 0;
+                while (present) {
+                    const int c = __builtin_ctzll(present);
+                    present &= present - 1;
+                    const uint32_t native = tl.class_count[c];
+                    uint32_t total = native + incoming;
+                    incoming = 0;
+                    const uint32_t per = 64u / (uint32_t)(c + 1), rest = total % per;
+                    if (rest && present) {
+                        const int up = __builtin_ctzll(present);
+                        const uint32_t per_up = 64u / (uint32_t)(up + 1);
+                        // at most half an item of the class above, instead of a mostly idle item of this one
+                        if (rest <= native && 2 * rest <= per_up) {
+                            tl.class_thr[c] = (uint16_t)(native - rest);
+                            tl.class_tgt[c] = (uint16_t)up;
+                            incoming = rest;
+                            total -= rest;
+                        }
+                    }
+                    tl.class_count[c] = total;
+                }
+            }
+            wave_lds_fence();
+            const uint32_t final_count = tl.class_count[lane], per = 64u / (uint32_t)(lane + 1);
+            const uint32_t items = (final_count + per - 1) / per;
+            const uint32_t incl = wave_inclusive_sum_u32(items);
+            tl.item_prefix[lane] = incl - items;
+            if (lane == 63) tl.item_prefix[64] = incl;
+        }
+        __syncthreads();
+        // ---- D: final keys, ranks inside a key ---------------------------------------------------------------------
+        uint32_t key[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            key[k] = 0xFFFFFFFFu;
+            if (cls[k] != 0xFFu) {
+                uint32_t c = cls[k];
+                if (rank[k] >= tl.class_thr[c]) c = tl.class_tgt[c];
+                const uint32_t bucket = txt[k] >> targs.shift;
+                key[k] = c * kTileBuckets + (bucket < (uint32_t)kTileBuckets - 1 ? bucket : (uint32_t)kTileBuckets - 1);
+                const uint32_t old = atomicAdd(&tl.bins[key[k] >> 1], (key[k] & 1u) ? 0x10000u : 1u);
+                rank[k] = (key[k] & 1u) ? old >> 16 : old & 0xFFFFu;
+            }
+        }
+        __syncthreads();
+        // ---- E: exclusive scan of the key counters (two u16 per word, in place) -------------------------------------
+        {
+            constexpr int kWords = kTileBins / 2 / kThreads;   // consecutive words per thread
+            uint32_t words[kWords], sum = 0;
+#pragma unroll
+            for (int q = 0; q < kWords; ++q) {
+                words[q] = tl.bins[threadIdx.x * kWords + q];
+                sum += (words[q] & 0xFFFFu) + (words[q] >> 16);
+            }
+            const uint32_t incl = wave_inclusive_sum_u32(sum);
+            if (lane == 63) tl.wave_sums[wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum;
+            for (int w = 0; w < wave; ++w) run += tl.wave_sums[w];
+#pragma unroll
+            for (int q = 0; q < kWords; ++q) {
+                const uint32_t lo = words[q] & 0xFFFFu, hi = words[q] >> 16;
+                tl.bins[threadIdx.x * kWords + q] = run | ((run + lo) << 16);
+                run += lo + hi;
+            }
+        }
+        __syncthreads();
+        // ---- F: scatter the tile-local indices ------------------------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (key[k] != 0xFFFFFFFFu) {
+                const uint32_t word = tl.bins[key[k] >> 1];
+                const uint32_t start = (key[k] & 1u) ? word >> 16 : word & 0xFFFFu;
+                tl.sorted[start + rank[k]] = (uint16_t)((uint32_t)k * kThreads + threadIdx.x);
+            }
+        }
+        __syncthreads();
+        // ---- G: work items, heaviest first (high class, long text), dealt by an LDS ticket --------------------------------
+        {
+            const uint32_t items_total = tl.item_prefix[64];
+            const uint32_t my_prefix = tl.item_prefix[lane];
+            for (;;) {
+                uint32_t t = 0;
+                if (lane == 0) t = __hip_atomic_fetch_add(&tl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t >= items_total) break;
+                const uint32_t item = items_total - 1 - t;
+                const uint32_t G = (uint32_t)__popcll(__ballot(my_prefix <= item));   // class = prefix entries <= item
+                const uint32_t per = 64 / G;
+                const uint32_t chunk = item - tl.item_prefix[G - 1];
+                const uint32_t cword = tl.bins[((G - 1) * kTileBuckets) >> 1];   // (even key: low half) start of class G
+                const uint32_t cstart = cword & 0xFFFFu, ccount = tl.class_count[G - 1];
+                const uint32_t slot = (uint32_t)lane / G;
+                const uint32_t pidx = chunk * per + slot;
+                const bool have = slot < per && pidx < ccount;
+                uint64_t p = 0, a0 = 0, b0 = 0;
+                uint32_t la = 0, lb = 0;
+                if (have) {
+                    p = base + tl.sorted[cstart + pidx];
+                    if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
+                    else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
+                }
+                bp_item<Sym, kWide>(args, wv, G, have, p, a0, la, b0, lb);
+            }
+        }
+        __syncthreads();   // the next tile rewrites the lists
+    }
+    {
+        TileTail &tail = *(TileTail *)tl.bins;   // the tile loop ended with a barrier
+        unsigned long long &lcells = tail.cells, &lsyms = tail.syms;
+        uint32_t &lmaxa = tail.maxa, &lmaxb = tail.maxb, &lshorts = tail.shorts, &lmisfit = tail.misfit;
+        if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; lmisfit = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            cells += __shfl_xor(cells, off);
+            syms += __shfl_xor(syms, off);
+            shorts += __shfl_xor(shorts, off);
+            misfit |= __shfl_xor(misfit, off);
+            const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+            maxa = oa > maxa ? oa : maxa;
+            maxb = ob > maxb ? ob : maxb;
+        }
+        if (lane == 0) {
+            atomicAdd(&lcells, cells);
+            atomicAdd(&lsyms, syms);
+            atomicMax(&lmaxa, maxa);
+            atomicMax(&lmaxb, maxb);
+            atomicAdd(&lshorts, shorts);
+            atomicOr(&lmisfit, misfit);
+        }
+        __syncthreads();
+        report_call_summary(PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, lmisfit}, targs.partials, targs.done_counter, targs.summary, tail.summary);
+    }
+}
+
+template <typename Sym>
+__global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel_tiled(TiledArgs targs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KernelArgs &args = targs.k;
+    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
+                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
+    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
+                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
+    if constexpr (sizeof(Sym) == 1) {
+        if (a_total >= 16 && b_total >= 16) tiled_run<Sym, true>(targs, smem, a_total, b_total);
+        else tiled_run<Sym, false>(targs, smem, a_total, b_total);
+    } else {
+        tiled_run<Sym, false>(targs, smem, a_total, b_total);
+    }
+}
+
+// Tile size: every workgroup slot should get the same number of tiles (1, 2, ...), tiles stay <= kTileMax pairs, and a
+// batch too small to give every slot a useful tile uses fewer workgroups instead of smaller tiles.
+TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text) {
+    TilePlan tp{};
+    constexpr uint32_t kTileMin = 256;
+    const uint64_t rounds = (pairs + (uint64_t)slots * kTileMax - 1) / ((uint64_t)slots * kTileMax);
+    uint64_t tile = (pairs + slots * rounds - 1) / (slots * rounds);
+    if (tile < kTileMin) tile = kTileMin;
+    if (tile > (uint64_t)kTileMax) tile = kTileMax;
+    tp.tile = (uint32_t)tile;
+    tp.tiles = (uint32_t)((pairs + tile - 1) / tile);
+    tp.blocks = tp.tiles < slots ? tp.tiles : slots;
+    uint32_t shift = 0;
+    while (((uint64_t)longest_text >> shift) >= (uint64_t)kTileBuckets) ++shift;
+    tp.shift = shift;
+    return tp;
+}
+
+template <typename Sym>
+static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text) {
+    constexpr int kWaves = BpTraits<Sym>::kWaves;
+    constexpr size_t lds = tiled_lds_bytes<Sym>();
+    uint32_t slots = (uint32_t)scope->compute_units * (uint32_t)((160 * 1024) / lds);
+    if (slots > (uint32_t)kMaxPartials) slots = kMaxPartials;
+    const TilePlan tp = plan_tiles(pairs, slots, longest_text);
+    TiledArgs t{};
+    t.k = args;
+    t.k.boundary = nullptr;
+    t.tile = tp.tile; t.tiles = tp.tiles; t.shift = tp.shift;
+    t.partials = scope->plan_partials;
+    t.done_counter = scope->done_counter;
+    t.summary = scope->summary_dev;
+    opt_in_dynamic_lds(scope, (const void *)k_bitparallel_tiled<Sym>, lds);
+    StampGuard guard(scope, sizeof(Sym) == 1 ? "bitparallel_tiled" : "bitparallel_tiled_u32");
+    hipLaunchKernelGGL(k_bitparallel_tiled<Sym>, dim3(tp.blocks), dim3(kWaves * 64), lds, scope->stream, t);
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
+void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text) {
+    if (args.sym_bytes == 4) launch_tiled_sym<uint32_t>(scope, args, pairs, longest_text);
+    else launch_tiled_sym<uint8_t>(scope, args, pairs, longest_text);
+}
+
+}  // namespace swh

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 KAT = json.load(open(os.path.join(GOLDEN, "kat.json"), encoding="utf-8"))
-ALGORITHMS = ["auto", "wavefront", "bitparallel"]
+ALGORITHMS = ["auto", "wavefront", "bitparallel", "tiled"]
 
 
 def unary_matrix(match, mismatch):
@@ -559,6 +559,154 @@ def test_pipelined_scope_lanes(sw, orc):
     da, db, want, out = batches[0]
     engine.pairs(da, db, torch_scope, out=out)
     assert (out.cpu().numpy().astype(np.uint32) == want).all()
+
+
+# ----------------------------------------------------------------------------------------------------
+# prepared tapes and the plan-free kernels (tiled bit-parallel, direct-short on its own)
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("workload,count", [("words16", 10_000), ("tokens64", 60_000), ("short_words", 150_000), ("utf8_lines", 600)])
+def test_prepared_byte_tapes(sw, orc, scope, workload, count):
+    """`swh_tape_prepare_*` + `*_pairs_prepared`: same distances as the raw-tape call, whole tapes and sub-views
+    (bench.rs:134-139), bounded and unbounded, host-resident and device-resident sources."""
+    a, b = sw.generate_pairs(workload, count, seed=7)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
+    info = pa.info
+    assert info["count"] == count and info["bytes"] == int(a.offsets[-1]) and info["longest"] == int(a.lengths.max()) and not info["utf8"]
+    assert (engine.pairs(pa, pb, scope) == want).all()
+    for bound in (0, 3, 40):
+        assert (engine.pairs(pa, pb, scope, bound=bound) == np.minimum(want, bound + 1)).all()
+    lo, hi = count // 3, count // 3 + count // 2
+    assert (engine.pairs(pa[lo:hi], pb[lo:hi], scope) == want[lo:hi]).all()
+    assert engine.pairs(pa[5:5], pb[9:9], scope).size == 0
+    da, db = a.to_device(scope), b.to_device(scope)                         # device tapes are used in place
+    qa, qb = sw.PreparedTape(scope, da), sw.PreparedTape(scope, db)
+    assert (engine.pairs(qa, qb, scope) == want).all()
+    with pytest.raises(TypeError):
+        engine.pairs(pa, b, scope)                                          # both prepared, or neither
+    u32a = sw.PreparedTape(scope, a.with_offsets(np.uint32))
+    with pytest.raises(sw.StringWarsError):
+        engine.pairs(u32a, pb, scope)                                       # one offset width per call
+    u32b = sw.PreparedTape(scope, b.with_offsets(np.uint32))
+    assert (engine.pairs(u32a, u32b, scope) == want).all()
+
+
+def test_prepared_utf8_tapes(sw, orc, scope):
+    """UTF-8 is validated and decoded once, at prepare time (`CharsTapeView::try_from`, bench.rs:303-306)."""
+    a, b = sw.generate_pairs("utf8_lines", 1500, seed=11)
+    want = orc.levenshtein_pairs(a, b, utf8=True)
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    pa, pb = sw.PreparedTape(scope, a, utf8=True), sw.PreparedTape(scope, b, utf8=True)
+    info = pa.info
+    assert info["utf8"] and not info["ascii"] and info["symbols"] == sum(len(a[i].decode()) for i in range(1500))
+    assert info["longest"] == max(len(a[i].decode()) for i in range(1500))
+    assert (engine.pairs(pa, pb, scope) == want).all()
+    for bound in (0, 7, 32, 63, 500):
+        assert (engine.pairs(pa, pb, scope, bound=bound) == np.minimum(want, bound + 1)).all()
+    assert (engine.pairs(pa[100:900], pb[100:900], scope, bound=32) == np.minimum(want[100:900], 33)).all()
+    for algorithm in ("wavefront", "bitparallel", "tiled"):
+        other = sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm=algorithm)
+        assert (other.pairs(pa[:300], pb[:300], scope) == want[:300]).all()
+    with pytest.raises(ValueError):
+        sw.LevenshteinDistances(capabilities=scope).pairs(pa, pb, scope)    # byte engine, code-point tapes
+    with pytest.raises(sw.StringWarsError) as info:
+        sw.PreparedTape(scope, sw.Strs([b"ok", b"\xe2\x82", b"fine"]), utf8=True)
+    assert info.value.status == "invalid_utf8"
+    # pure ASCII prepared as UTF-8: code points are bytes, the byte kernels run
+    ta, tb = sw.generate_pairs("tokens64", 20_000, seed=3)
+    xa, xb = sw.PreparedTape(scope, ta, utf8=True), sw.PreparedTape(scope, tb, utf8=True)
+    assert xa.info["ascii"] and xa.info["symbols"] == xa.info["bytes"]
+    assert (engine.pairs(xa, xb, scope) == orc.levenshtein_pairs(ta, tb, algo="hyyro")).all()
+    mixed = engine.pairs(xa[:1500], pb, scope)                              # ASCII against non-ASCII: code points
+    assert (mixed == orc.levenshtein_pairs(ta.subview(0, 1500), b, utf8=True)).all()
+
+
+def test_prepared_cross_product_and_alignment(sw, orc, scope):
+    rng = np.random.default_rng(5)
+    items_a, items_b = random_pairs(rng, 70, list(range(0, 50)) + [90, 130], 20)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    want = np.array([[orc.levenshtein(x, y) for y in items_b] for x in items_a], dtype=np.uint64)
+    assert (engine(pa, pb, scope) == want).all()
+    assert (engine(pa[10:30], pb[40:70], scope) == want[10:30, 40:70]).all()
+    self_product = engine(pa, None, scope)
+    assert (self_product == np.array([[orc.levenshtein(x, y) for y in items_a] for x in items_a], dtype=np.uint64)).all()
+    matrix = np.minimum(rng.integers(-6, 9, (256, 256)), rng.integers(-6, 9, (256, 256)).T).astype(np.int8)
+    for cls, local in ((sw.NeedlemanWunschScores, False), (sw.SmithWatermanScores, True)):
+        for gaps in ((-3, -3), (-7, -1)):
+            scorer = cls(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope)
+            expected = np.array([orc.nw_score(x, y, matrix, gaps[0], gaps[1], local=local) for x, y in zip(items_a, items_b)])
+            assert (scorer.pairs(pa, pb, scope) == expected).all()
+            assert (scorer.pairs(a, b, scope) == expected).all()
+            grid = scorer(pa[:8], pb[:9], scope)
+            assert grid.tolist() == [[orc.nw_score(x, y, matrix, gaps[0], gaps[1], local=local) for y in items_b[:9]] for x in items_a[:8]]
+
+
+def test_tiled_kernel_every_block_count(sw, orc, scope):
+    """The tiled kernel forced onto strings of 1 .. 2048 symbols (classes G = 1 .. 64 inside one tile, left-overs moving
+    up a class, partly filled items), bytes and code points, bounded and not."""
+    rng = np.random.default_rng(31)
+    lengths = list(range(1, 70)) + [95, 96, 97, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 1024, 1025, 1500, 2047, 2048]
+    items_a, items_b = random_pairs(rng, 2600, lengths, 5)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    engine = sw.LevenshteinDistances(capabilities=scope, algorithm="tiled")
+    assert (engine.pairs(a, b, scope) == want).all()
+    assert (engine.pairs(b, a, scope) == want).all()
+    pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
+    assert (engine.pairs(pa, pb, scope) == want).all()
+    for bound in (0, 5, 33, 200):
+        assert (engine.pairs(pa, pb, scope, bound=bound) == np.minimum(want, bound + 1)).all()
+    chars = sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm="tiled")
+    ua, ub = sw.generate_pairs("utf8_lines", 700, seed=13)
+    assert (chars.pairs(ua, ub, scope) == orc.levenshtein_pairs(ua, ub, utf8=True)).all()
+
+
+def test_plan_free_route_falls_back_when_lengths_grow(sw, orc):
+    """Raw tapes: the scope believes the next batch looks like the last one and skips the pre-pass; the kernels verify
+    the belief per pair, and a batch that breaks it (both strings beyond 2048 symbols, or words turned into lines) is
+    redone on the planned path -- same results either way."""
+    scope = sw.DeviceScope(gpu_device=0)
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    rng = np.random.default_rng(37)
+    words_a, words_b = sw.generate_pairs("short_words", 40_000, seed=2)
+    tokens_a, tokens_b = sw.generate_pairs("tokens64", 30_000, seed=2)
+    long_a, long_b = random_pairs(rng, 40, [5, 60, 2100, 2500, 3000, 5000], 4)
+    long_a, long_b = sw.Strs(long_a), sw.Strs(long_b)
+    batches = [(words_a, words_b), (words_a, words_b), (tokens_a, tokens_b), (tokens_a, tokens_b), (long_a, long_b),
+               (long_a, long_b), (words_a, words_b), (tokens_a, tokens_b), (long_a, long_b), (words_a, words_b)]
+    for a, b in batches:
+        assert (engine.pairs(a, b, scope) == orc.levenshtein_pairs(a, b, algo="hyyro")).all()
+        da, db = a.to_device(scope), b.to_device(scope)
+        assert (engine.pairs(da, db, scope, bound=9) == np.minimum(orc.levenshtein_pairs(a, b, algo="hyyro"), 10)).all()
+    # forced tiled with a pair beyond its reach: flagged, redone
+    tiled = sw.LevenshteinDistances(capabilities=scope, algorithm="tiled")
+    assert (tiled.pairs(long_a, long_b, scope) == orc.levenshtein_pairs(long_a, long_b, algo="hyyro")).all()
+
+
+def test_prepared_tapes_in_asynchronous_and_pipelined_scopes(sw, orc):
+    import torch
+    scope = sw.DeviceScope(gpu_device=0, stream=torch.cuda.current_stream().cuda_stream)
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    work = []
+    for seed, workload, count in ((1, "tokens64", 50_000), (2, "words16", 30_000), (3, "short_words", 200_000), (4, "tokens64", 9_000)):
+        a, b = sw.generate_pairs(workload, count, seed=seed)
+        work.append((sw.PreparedTape(scope, a), sw.PreparedTape(scope, b), orc.levenshtein_pairs(a, b, algo="hyyro"),
+                     torch.zeros(count, dtype=torch.int32, device="cuda")))
+    for pipelined in (False, True):
+        scope.set_async(True)
+        scope.set_pipelined(pipelined)
+        for _ in range(3):
+            for pa, pb, _, out in work:
+                out.zero_()
+                engine.pairs(pa, pb, scope, out=out)
+            scope.synchronize()
+            for _, _, want, out in work:
+                assert (out.cpu().numpy().astype(np.uint32) == want).all()
+        scope.set_pipelined(False)
+        scope.set_async(False)
 
 
 BAD_UTF8 = [b"\xff", b"\xc0\x80", b"\xc1\xbf", b"\xe0\x80\x80", b"\xe0\x9f\xbf", b"\xed\xa0\x80", b"\xed\xbf\xbf",

@@ -357,7 +357,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 const bool band_pays = spec.bound <= 63 && longest > 32;   // plan_key(): the banded kernel wins from ~6 blocks at k = 32
                 if (forced) route = (!guaranteed || shorter_side <= 2048) ? kRouteTiled : kRoutePlanned;
                 else if (!band_pays && longest <= tiled_longest_limit())
-                    route = (longest <= 32 && sym_bytes == 1 && direct_short_preferred()) ? kRouteDirectShort : kRouteTiled;
+                    route = (longest <= 32 && !utf8 && direct_short_preferred()) ? kRouteDirectShort : kRouteTiled;
             }
         }
 

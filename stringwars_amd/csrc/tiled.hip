@@ -17,6 +17,9 @@
 // `violation` flag (host-mapped memory) and is left alone: the host only picks this kernel when tape statistics or the
 // previous call say no such pair exists, checks the flag after the call and falls back to the planned path if it is
 // set (api.hip).
+#include <cstdio>
+#include <cstdlib>
+
 #include "bp_item.hpp"
 
 namespace swh {
@@ -47,6 +50,20 @@ template <typename Sym> constexpr size_t tiled_lds_bytes() {
     return (size_t)BpTraits<Sym>::kWaves * (bp_table_words<Sym>() + 64) * 4 + sizeof(TileLds);
 }
 
+#ifdef SWH_TILE_PROFILE
+// Diagnostic build only (make EXTRA=-DSWH_TILE_PROFILE): wave cycles per phase of k_bitparallel_tiled, summed over waves.
+__device__ unsigned long long g_tile_phase[8];
+extern "C" void swh_debug_tile_phases(unsigned long long *out) {
+    unsigned long long zero[8] = {};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_phase), sizeof(zero));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_phase), zero, sizeof(zero));
+}
+#define TILE_STAMP(slot) do { const unsigned long long now__ = __builtin_readcyclecounter(); phase_acc[slot] += now__ - phase_t; phase_t = now__; } while (0)
+#else
+#define TILE_STAMP(slot) do {} while (0)
+#endif
+
 struct TiledArgs {
     KernelArgs k;
     uint32_t tile;          // pairs per tile
@@ -69,6 +86,9 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
     TileLds &tl = *(TileLds *)(smem + (size_t)kWaves * (kTableWords + 64) * 4);
     unsigned long long cells = 0, syms = 0;
     uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
+#ifdef SWH_TILE_PROFILE
+    unsigned long long phase_acc[4] = {0, 0, 0, 0}, phase_t = __builtin_readcyclecounter(), items_done = 0;
+#endif
 
     for (uint32_t tile = blockIdx.x; tile < targs.tiles; tile += gridDim.x) {
         const uint64_t base = (uint64_t)tile * targs.tile;
@@ -200,6 +220,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
             }
         }
         __syncthreads();
+        TILE_STAMP(0);   // planning the tile
         // ---- G: work items, heaviest first (high class, long text), dealt by an LDS ticket --------------------------------
         {
             const uint32_t items_total = tl.item_prefix[64];
@@ -226,10 +247,22 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                     else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
                 }
                 bp_item<Sym, kWide>(args, wv, G, have, p, a0, la, b0, lb);
+#ifdef SWH_TILE_PROFILE
+                ++items_done;
+#endif
             }
         }
+        TILE_STAMP(1);   // work items
         __syncthreads();   // the next tile rewrites the lists
+        TILE_STAMP(2);   // waiting for the workgroup's other waves
     }
+#ifdef SWH_TILE_PROFILE
+    if (lane == 0) {
+        for (int q = 0; q < 3; ++q) atomicAdd(&g_tile_phase[q], phase_acc[q]);
+        atomicAdd(&g_tile_phase[3], 1ull);
+        atomicAdd(&g_tile_phase[4], items_done);
+    }
+#endif
     {
         TileTail &tail = *(TileTail *)tl.bins;   // the tile loop ended with a barrier
         unsigned long long &lcells = tail.cells, &lsyms = tail.syms;
@@ -308,6 +341,13 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
     t.done_counter = scope->done_counter;
     t.summary = scope->summary_dev;
     opt_in_dynamic_lds(scope, (const void *)k_bitparallel_tiled<Sym>, lds);
+    static const bool debug = getenv("STRINGWARS_AMD_DEBUG") != nullptr;
+    if (debug) {
+        int per_cu = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bitparallel_tiled<Sym>, kWaves * 64, lds);
+        fprintf(stderr, "[swh] tiled: pairs %llu tile %u tiles %u blocks %u shift %u lds %zu -> %d workgroups per CU\n",
+                (unsigned long long)pairs, tp.tile, tp.tiles, tp.blocks, tp.shift, lds, per_cu);
+    }
     StampGuard guard(scope, sizeof(Sym) == 1 ? "bitparallel_tiled" : "bitparallel_tiled_u32");
     hipLaunchKernelGGL(k_bitparallel_tiled<Sym>, dim3(tp.blocks), dim3(kWaves * 64), lds, scope->stream, t);
     SWH_HIP_CHECK(hipGetLastError());

@@ -42,52 +42,49 @@ def get_env_bool(name: str) -> bool:
     return value is not None and value.lower() in ("1", "true", "yes", "on")
 
 
-def scale_si(value: float):
-    for threshold, prefix in ((1e9, "G"), (1e6, "M"), (1e3, "k")):
-        if value >= threshold:
-            return value / threshold, prefix
-    return value, ""
+# ---- reporter ---------------------------------------------------------------------------------------------
+# One formatter for every column of the report line. The LINE is the contract (utils.py:291-336 prints
+# "<name padded to 42> <col> | <col> ..." with two decimals, decimal k/M/G prefixes and ns/µs/ms/s latencies);
+# how it is produced is this module's own: a ladder of (threshold, suffix) steps walked from the top.
+_DECIMAL_STEPS = ((1e9, "G"), (1e6, "M"), (1e3, "k"))          # the reference stops at G: 1500.00 GCUPS, never 1.50 T
+_TIME_STEPS = ((1.0, 1.0, "s"), (1e-3, 1e3, "ms"), (1e-6, 1e6, "µs"))
+# report kind -> (unit, "space between prefix and unit")
+_RATE_UNITS = {"cups": ("CUPS", False), "hashes": ("hashes/s", True), "bits": ("bits/s", True), "comparisons": ("cmp/s", True),
+               "bytes": ("B/s", False)}
 
 
-def format_si_rate(rate: float, unit: str, space_before_unit: bool = False) -> str:
-    value, prefix = scale_si(rate)
-    if not prefix:
-        return f"{value:.2f} {unit}"
-    return f"{value:.2f} {prefix} {unit}" if space_before_unit else f"{value:.2f} {prefix}{unit}"
-
-
-def format_byte_rate(rate: float) -> str:
-    value, prefix = scale_si(rate)
-    return f"{value:.2f} {prefix}B/s"
+def _scaled(amount: float, unit: str, spaced: bool = False) -> str:
+    for threshold, prefix in _DECIMAL_STEPS:
+        if amount >= threshold:
+            return f"{amount / threshold:.2f} {prefix}{' ' if spaced else ''}{unit}"
+    return f"{amount:.2f} {unit}"
 
 
 def format_seconds(seconds: float) -> str:
-    if seconds < 1e-6:
-        return f"{seconds * 1e9:.2f} ns"
-    if seconds < 1e-3:
-        return f"{seconds * 1e6:.2f} µs"
-    if seconds < 1.0:
-        return f"{seconds * 1e3:.2f} ms"
-    return f"{seconds:.2f} s"
+    for threshold, factor, suffix in _TIME_STEPS:
+        if seconds >= threshold:
+            return f"{seconds * factor:.2f} {suffix}"
+    return f"{seconds * 1e9:.2f} ns"
+
+
+def _quantile(ordered: Sequence[float], q: float) -> float:
+    return ordered[min(round(q * (len(ordered) - 1)), len(ordered) - 1)]
 
 
 def stats_line(name: str, report: str, elapsed_seconds: float, elements: int, total_bytes: int,
                latencies_seconds: Optional[Sequence[float]] = None) -> str:
-    seconds = max(elapsed_seconds, 1e-12)
-    units = {"cups": ("CUPS", False), "hashes": ("hashes/s", True), "bits": ("bits/s", True), "comparisons": ("cmp/s", True)}
-    columns: List[str] = []
-    if report == "bytes":
-        columns.append(format_byte_rate(total_bytes / seconds))
-    elif report in units:
-        columns.append(format_si_rate(elements / seconds, *units[report]))
-    else:
+    """The report line for one variant: primary rate, byte rate (when bytes were counted), p50 / p99."""
+    if report not in _RATE_UNITS:
         raise ValueError(f"Unknown report unit: {report!r}")
-    if report != "bytes" and total_bytes > 0:
-        columns.append(format_byte_rate(total_bytes / seconds))
+    seconds = max(elapsed_seconds, 1e-12)
+    columns: List[str] = []
+    if report != "bytes":
+        columns.append(_scaled(elements / seconds, *_RATE_UNITS[report]))
+    if report == "bytes" or total_bytes > 0:
+        columns.append(_scaled(total_bytes / seconds, *_RATE_UNITS["bytes"]))
     if latencies_seconds:
         ordered = sorted(latencies_seconds)
-        pick = lambda q: ordered[min(round(q * (len(ordered) - 1)), len(ordered) - 1)]
-        columns.append(f"p50 {format_seconds(pick(0.5))} p99 {format_seconds(pick(0.99))}")
+        columns.append(f"p50 {format_seconds(_quantile(ordered, 0.5))} p99 {format_seconds(_quantile(ordered, 0.99))}")
     return f"{name:<{REPORT_NAME_WIDTH}} {' | '.join(columns)}"
 
 

@@ -47,6 +47,32 @@ def _worker(rank, world, port, queue):
         if rank == 0:
             out[name] = got.numpy()
             out[name + "_ranges"] = ranges
+    # config C5's shape: ranges balanced on per-block cell sums (no rank sees all lengths), results gathered in three
+    # pieces straight into their place on the root, every shard's checksum verified there (bench.py --config c5)
+    total, block = 7003, 500
+    lo, hi = sharding.shard_range(total, rank, world)
+    ga, gb = sw.generate_pairs("short_words", hi - lo, seed=seed, first=lo)
+    cells = (ga.lengths * gb.lengths).astype(np.int64)
+    first_block, last_block = lo // block, (hi - 1) // block
+    mine = np.zeros((total + block - 1) // block, dtype=np.int64)
+    for k in range(first_block, last_block + 1):
+        mine[k] = cells[max(k * block, lo) - lo:min((k + 1) * block, hi) - lo].sum()
+    summed = torch.from_numpy(mine)
+    dist.all_reduce(summed)
+    ranges = sharding.shard_ranges_by_block_cells(summed.numpy(), block, total, world)
+    lo, hi = ranges[rank]
+    ga, gb = sw.generate_pairs("short_words", hi - lo, seed=seed, first=lo)
+    local = torch.from_numpy(oracle.levenshtein_pairs(ga, gb, algo="hyyro").astype(np.int32))
+    gather = sharding.ChunkedGather(ranges, 3, torch.int32, "cpu")
+    for j in range(3):
+        gather.send_chunk(local, j)
+    full = gather.wait()
+    sums = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sums, local.to(torch.int64).sum().reshape(1))
+    if rank == 0:
+        out["c5"] = full.numpy()
+        out["c5_ranges"] = ranges
+        out["c5_sums_ok"] = all(int(full[l:h].to(torch.int64).sum()) == int(sums[r]) for r, (l, h) in enumerate(ranges))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
@@ -74,6 +100,12 @@ def test_two_rank_gloo_gather_matches_single_process(sw, orc):
     assert lo0 == 0 and hi0 == lo1 and hi1 == 5001
     cells = fa.lengths * fb.lengths
     assert abs(int(cells[lo0:hi0].sum()) - int(cells[lo1:hi1].sum())) <= int(cells.max())
+    ga, gb = sw.generate_pairs("short_words", 7003, seed=42)
+    assert (out["c5"] == orc.levenshtein_pairs(ga, gb, algo="hyyro").astype(np.int32)).all() and out["c5_sums_ok"]
+    (lo0, hi0), (lo1, hi1) = out["c5_ranges"]
+    cells = (ga.lengths * gb.lengths).astype(np.int64)
+    assert lo0 == 0 and hi0 == lo1 and hi1 == 7003
+    assert abs(int(cells[lo0:hi0].sum()) - int(cells[lo1:hi1].sum())) < 0.02 * int(cells.sum())
 
 
 def test_shard_helpers():
@@ -83,5 +115,9 @@ def test_shard_helpers():
             ranges = [sharding.shard_range(total, r, world) for r in range(world)]
             assert ranges[0][0] == 0 and ranges[-1][1] == total
             assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    assert sharding.chunk_ranges(10, 4) == [(0, 2), (2, 5), (5, 7), (7, 10)] and sharding.chunk_ranges(2, 4) == [(0, 1), (1, 2)]
+    assert sharding.chunk_ranges(0, 4) == [(0, 0)]
+    assert sharding.shard_ranges_by_block_cells([10, 10, 10, 10], 100, 400, 2) == [(0, 200), (200, 400)]
+    assert sharding.shard_ranges_by_block_cells([30, 10], 100, 150, 2) == [(0, 67), (67, 150)]
     la = np.array([1, 100, 1, 1, 100, 1]); lb = np.array([1, 100, 1, 1, 100, 1])
     assert sharding.shard_ranges_by_cells(la, lb, 2) == [(0, 2), (2, 6)] or sharding.shard_ranges_by_cells(la, lb, 2)[0][1] in (2, 3, 4)

@@ -39,7 +39,8 @@ typedef enum swh_status_t {
     swh_unsupported_length_k = 4,  /* "the engine may decline inputs beyond its supported length" bench.rs:394 */
     swh_no_device_k = 5,           /* no gfx950 device / HIP runtime unavailable */
     swh_device_error_k = 6,        /* a HIP call failed; message carries hipGetErrorString */
-    swh_not_implemented_k = 7
+    swh_not_implemented_k = 7,
+    swh_rccl_error_k = 8           /* RCCL could not be loaded, or a collective failed; message carries ncclGetErrorString */
 } swh_status_t;
 
 #define SWH_UNBOUNDED UINT32_MAX
@@ -62,6 +63,13 @@ swh_status_t swh_scope_init_gpu_stream(int device, void *hip_stream, swh_scope_t
 /* `DeviceScope::cpu_cores(n)` (bench.rs:376-378). This backend has no CPU path: always returns
  * swh_not_implemented_k so a harness prints SKIPPED instead of silently running a fallback. */
 swh_status_t swh_scope_init_cpu(size_t cores, swh_scope_t *scope, const char **error);
+/* Several GPUs of ONE node behind one scope (single process): a member scope per device and an RCCL communicator
+ * (`ncclCommInitAll`); the `<Ngpu>` rows beside the reference's `<1gpu>` ones (bench.rs:581-606). Ordinary engine calls on
+ * such a scope run on its first device; the `*_sharded` calls below split a batch over all of them. `devices` may name one
+ * device several times (members then share it and exchange by copies instead of RCCL -- a testing arrangement). */
+swh_status_t swh_device_count(int *count);
+swh_status_t swh_scope_init_gpus(const int *devices, int count, swh_scope_t *scope, const char **error);
+swh_status_t swh_scope_device_count(swh_scope_t scope, size_t *devices);
 swh_status_t swh_scope_free(swh_scope_t scope);
 /* Compute-unit count for `auto_batch_size` (utils.rs:815-819, :826-836: one SM == one core). */
 swh_status_t swh_scope_compute_units(swh_scope_t scope, size_t *compute_units);
@@ -184,6 +192,32 @@ swh_status_t swh_levenshtein_pairs_prepared(swh_levenshtein_t engine, swh_scope_
 swh_status_t swh_levenshtein_cross_prepared(swh_levenshtein_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
                                             const swh_prepared_view_t *b, size_t *out, size_t row_stride_bytes,
                                             const char **error);
+
+/* ---- One batch over the GPUs of a multi-device scope (BASELINE config 5). --------------------------------
+ * `swh_sharded_prepare_*`: HOST tapes of equal count are cut into contiguous shards balanced on the prefix sum of
+ * len(a_i)*len(b_i) (DP cells, not pair counts); shard r is uploaded to and prepared on device r. The handle is the steady
+ * state: every `swh_levenshtein_pairs_sharded` call scores each shard on its device (no exchange during the DP), gathers
+ * the u32 distances to the first device with one ncclSend / ncclRecv group over xGMI and copies them to `out` (host or
+ * first-device memory, pair order). `swh_scope_shard_timing`: slowest shard and the gather of the last call. */
+typedef struct swh_sharded_s *swh_sharded_t;
+swh_status_t swh_sharded_prepare_u32tape(swh_scope_t scope, const swh_tape_u32_t *a, const swh_tape_u32_t *b, int utf8,
+                                         swh_sharded_t *sharded, const char **error);
+swh_status_t swh_sharded_prepare_u64tape(swh_scope_t scope, const swh_tape_u64_t *a, const swh_tape_u64_t *b, int utf8,
+                                         swh_sharded_t *sharded, const char **error);
+swh_status_t swh_sharded_free(swh_sharded_t sharded);
+/* the `devices + 1` pair indices where the shards begin / end */
+swh_status_t swh_sharded_cuts(swh_sharded_t sharded, size_t *cuts, size_t capacity);
+swh_status_t swh_levenshtein_pairs_sharded(swh_levenshtein_t engine, swh_scope_t scope, swh_sharded_t sharded, uint32_t bound,
+                                           uint32_t *out, const char **error);
+/* one-shot: shard + upload + score + gather + free */
+swh_status_t swh_levenshtein_pairs_sharded_u64tape(swh_levenshtein_t engine, swh_scope_t scope, const swh_tape_u64_t *a,
+                                                   const swh_tape_u64_t *b, uint32_t bound, uint32_t *out, const char **error);
+typedef struct swh_shard_timing_t {
+    double compute_ms;   /* slowest shard, first kernel start to last kernel end on its device */
+    double gather_ms;    /* the RCCL gather on the first device's stream */
+    uint64_t cells, pairs;
+} swh_shard_timing_t;
+swh_status_t swh_scope_shard_timing(swh_scope_t scope, swh_shard_timing_t *timing);
 
 /* ---- Needleman-Wunsch: `NeedlemanWunschScores::new(&scope, &byte_to_class, &class_costs,
  *      open, extend)` (bench.rs:658-670, :985-997); scores are max-plus, gaps usually negative. */

@@ -48,6 +48,11 @@ void swh_synth_matrix(uint64_t seed, const char *alphabet, int8_t *matrix_256x25
 /* `unary_class_costs(match, mismatch)` (bench.rs:95-108): byte -> class = byte % 32. */
 void swh_unary_class_costs(int8_t match, int8_t mismatch, uint8_t *byte_to_class_256, int8_t *class_costs_32x32);
 
+/* Cells-balanced contiguous cuts of a pairwise batch in HOST tapes: `cuts[0..shards]`, shard r = pairs
+ * [cuts[r], cuts[r+1]), balanced on the prefix sum of len(a_i)*len(b_i). What `swh_sharded_prepare_*` uses. */
+void swh_shard_cuts_u32tape(const swh_tape_u32_t *a, const swh_tape_u32_t *b, size_t shards, size_t *cuts);
+void swh_shard_cuts_u64tape(const swh_tape_u64_t *a, const swh_tape_u64_t *b, size_t shards, size_t *cuts);
+
 /* `crossproduct_side(budget, tape_len)` (bench.rs:113-117). */
 size_t swh_crossproduct_side(size_t budget, size_t tape_len);
 /* `auto_batch_size(cores, default_base)` (utils.rs:815-819) with STRINGWARS_BATCH_PER_CORE. */

@@ -44,7 +44,7 @@ lib = C.CDLL(LIBRARY_PATH)
 SUCCESS = 0
 STATUS_NAMES = {
     0: "success", 1: "bad_alloc", 2: "invalid_argument", 3: "invalid_utf8", 4: "unsupported_length",
-    5: "no_device", 6: "device_error", 7: "not_implemented",
+    5: "no_device", 6: "device_error", 7: "not_implemented", 8: "rccl_error",
 }
 UNBOUNDED = 0xFFFFFFFF
 ALGORITHM_AUTO, ALGORITHM_WAVEFRONT, ALGORITHM_BITPARALLEL, ALGORITHM_TILED = 0, 1, 2, 3
@@ -62,6 +62,11 @@ class PreparedInfo(C.Structure):
     """``swh_prepared_info_t``"""
     _fields_ = [("count", C.c_size_t), ("bytes", C.c_uint64), ("symbols", C.c_uint64), ("longest", C.c_uint32),
                 ("utf8", C.c_int), ("ascii", C.c_int)]
+
+
+class ShardTiming(C.Structure):
+    """``swh_shard_timing_t``"""
+    _fields_ = [("compute_ms", C.c_double), ("gather_ms", C.c_double), ("cells", C.c_uint64), ("pairs", C.c_uint64)]
 
 
 class PreparedView(C.Structure):
@@ -97,6 +102,9 @@ SIGNATURES = {
     "swh_scope_init_gpu": (C.c_int, [C.c_int, C.POINTER(_P), _ERR]),
     "swh_scope_init_gpu_stream": (C.c_int, [C.c_int, _P, C.POINTER(_P), _ERR]),
     "swh_scope_init_cpu": (C.c_int, [C.c_size_t, C.POINTER(_P), _ERR]),
+    "swh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "swh_scope_init_gpus": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P), _ERR]),
+    "swh_scope_device_count": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
     "swh_scope_free": (C.c_int, [_P]),
     "swh_scope_compute_units": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
     "swh_scope_set_async": (C.c_int, [_P, C.c_int]),
@@ -121,6 +129,13 @@ SIGNATURES = {
     "swh_levenshtein_utf8_pairs_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), C.c_uint32, _P, C.c_size_t, _ERR]),
     "swh_levenshtein_cross_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), _P, C.c_size_t, _ERR]),
     "swh_levenshtein_utf8_cross_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), _P, C.c_size_t, _ERR]),
+    "swh_sharded_prepare_u32tape": (C.c_int, [_P, C.POINTER(TapeU32), C.POINTER(TapeU32), C.c_int, C.POINTER(_P), _ERR]),
+    "swh_sharded_prepare_u64tape": (C.c_int, [_P, C.POINTER(TapeU64), C.POINTER(TapeU64), C.c_int, C.POINTER(_P), _ERR]),
+    "swh_sharded_free": (C.c_int, [_P]),
+    "swh_sharded_cuts": (C.c_int, [_P, C.POINTER(C.c_size_t), C.c_size_t]),
+    "swh_levenshtein_pairs_sharded": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _ERR]),
+    "swh_levenshtein_pairs_sharded_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), C.c_uint32, _P, _ERR]),
+    "swh_scope_shard_timing": (C.c_int, [_P, C.POINTER(ShardTiming)]),
     "swh_nw_init": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P), _ERR]),
     "swh_nw_init_classes": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(_P), _ERR]),
     "swh_nw_free": (C.c_int, [_P]),
@@ -150,6 +165,8 @@ SIGNATURES = {
     "swh_synth_free": (None, [C.POINTER(Synth)]),
     "swh_synth_matrix": (None, [C.c_uint64, C.c_char_p, _P]),
     "swh_unary_class_costs": (None, [C.c_int8, C.c_int8, _P, _P]),
+    "swh_shard_cuts_u32tape": (None, [C.POINTER(TapeU32), C.POINTER(TapeU32), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "swh_shard_cuts_u64tape": (None, [C.POINTER(TapeU64), C.POINTER(TapeU64), C.c_size_t, C.POINTER(C.c_size_t)]),
     "swh_crossproduct_side": (C.c_size_t, [C.c_size_t, C.c_size_t]),
     "swh_auto_batch_size": (C.c_size_t, [C.c_size_t, C.c_size_t]),
     "swh_format_si_rate": (C.c_size_t, [C.c_double, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),

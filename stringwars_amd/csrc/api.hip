@@ -596,7 +596,7 @@ using namespace swh;
 extern "C" {
 
 const char *swh_version(void) { return "0.1.0"; }
-const char *swh_capabilities(void) { return "gfx950,hip,wavefront,bitparallel,tiled,banded,utf8,bounded,nw-linear,nw-affine,sw-linear,sw-affine,cross,prepared"; }
+const char *swh_capabilities(void) { return "gfx950,hip,wavefront,bitparallel,tiled,banded,utf8,bounded,nw-linear,nw-affine,sw-linear,sw-affine,cross,prepared,multi-gpu-rccl"; }
 
 static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_t *out, const char **error) {
     if (!out) return fail(error, swh_invalid_argument_k, "null scope pointer");
@@ -663,6 +663,7 @@ swh_status_t swh_scope_free(swh_scope_t handle) {
     if (!scope) return swh_success_k;
     for (Scope *&lane : scope->lanes)
         if (lane) { swh_scope_free((swh_scope_t)lane); lane = nullptr; }
+    if (scope->multi) { free_multi_scope(scope->multi); scope->multi = nullptr; }
     (void)hipSetDevice(scope->device);
     (void)hipStreamSynchronize(scope->stream);
     if (scope->lane_done) (void)hipEventDestroy(scope->lane_done);

@@ -299,6 +299,7 @@ struct Scope {
     // process-wide flag would leave a second device without the opt-in)
     std::unordered_map<const void *, size_t> lds_opt_in;
     Scope *last_lane = nullptr;       // (on the parent) lane that took the latest call
+    void *multi = nullptr;             // swh_scope_init_gpus: the per-device member scopes + RCCL communicators (sharded.hip)
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
     bool stamps_pending = false;       // recorded by an asynchronous call, not read yet (api.hip: harvest_timing)
@@ -306,6 +307,8 @@ struct Scope {
     swh_timing_t last_timing{};
     std::string error;
 };
+
+void free_multi_scope(void *multi);   // sharded.hip
 
 struct Engine {
     int kind;  // 0 = levenshtein, 1 = needleman-wunsch (global), 2 = smith-waterman (local)

@@ -23,7 +23,7 @@ import numpy as np
 from . import _native as N
 
 __all__ = [
-    "DeviceScope", "Strs", "DeviceTape", "PreparedTape", "LevenshteinDistances", "LevenshteinDistancesUTF8",
+    "DeviceScope", "Strs", "DeviceTape", "PreparedTape", "ShardedPairs", "shard_cuts", "LevenshteinDistances", "LevenshteinDistancesUTF8",
     "NeedlemanWunschScores", "SmithWatermanScores", "edit_distance", "StringWarsError", "UNBOUNDED",
 ]
 
@@ -54,10 +54,17 @@ class DeviceScope:
     ``stream`` may be a raw ``hipStream_t`` address (e.g. ``torch.cuda.current_stream().cuda_stream``).
     """
 
-    def __init__(self, gpu_device: Optional[int] = None, cpu_cores: Optional[int] = None, stream: Optional[int] = None):
+    def __init__(self, gpu_device: Optional[int] = None, cpu_cores: Optional[int] = None, stream: Optional[int] = None,
+                 gpu_devices: Optional[Sequence[int]] = None):
         handle = C.c_void_p()
         err = C.c_char_p()
-        if cpu_cores is not None and gpu_device is None:
+        if gpu_devices is not None:
+            # several GPUs of one node behind one scope (`swh_scope_init_gpus`): batches are split over them by the
+            # `*_sharded` calls, distances gathered with RCCL inside the library
+            devices = (C.c_int * len(gpu_devices))(*[int(d) for d in gpu_devices])
+            status = N.lib.swh_scope_init_gpus(devices, len(gpu_devices), C.byref(handle), C.byref(err))
+            gpu_device = gpu_devices[0] if len(gpu_devices) else 0
+        elif cpu_cores is not None and gpu_device is None:
             status = N.lib.swh_scope_init_cpu(int(cpu_cores), C.byref(handle), C.byref(err))
         elif stream is not None:
             status = N.lib.swh_scope_init_gpu_stream(int(gpu_device or 0), C.c_void_p(int(stream)), C.byref(handle), C.byref(err))
@@ -76,6 +83,17 @@ class DeviceScope:
         value = C.c_size_t()
         N.lib.swh_scope_compute_units(self._handle, C.byref(value))
         return int(value.value)
+
+    @property
+    def device_count(self) -> int:
+        value = C.c_size_t()
+        N.lib.swh_scope_device_count(self._handle, C.byref(value))
+        return int(value.value)
+
+    def shard_timing(self) -> dict:
+        timing = N.ShardTiming()
+        N.lib.swh_scope_shard_timing(self._handle, C.byref(timing))
+        return {"compute_ms": timing.compute_ms, "gather_ms": timing.gather_ms, "cells": int(timing.cells), "pairs": int(timing.pairs)}
 
     def set_async(self, enabled: bool) -> None:
         N.lib.swh_scope_set_async(self._handle, int(bool(enabled)))
@@ -282,6 +300,55 @@ class PreparedTape:
             pass
 
 
+def shard_cuts(a: Strs, b: Strs, shards: int) -> list:
+    """Cells-balanced contiguous cuts of a pairwise batch (`swh_shard_cuts_*`): shard r = pairs [cuts[r], cuts[r+1])."""
+    ta, a64, keep_a = _c_tape(a)
+    tb, b64, keep_b = _c_tape(b, want64=a64 or None)
+    if a64 != b64:
+        ta, a64, keep_a = _c_tape(a, want64=True)
+        tb, b64, keep_b = _c_tape(b, want64=True)
+    cuts = (C.c_size_t * (shards + 1))()
+    (N.lib.swh_shard_cuts_u64tape if a64 else N.lib.swh_shard_cuts_u32tape)(C.byref(ta), C.byref(tb), shards, cuts)
+    return [int(c) for c in cuts]
+
+
+class ShardedPairs:
+    """A pairwise batch made resident on every device of a multi-GPU scope (`swh_sharded_prepare_*`): contiguous
+    cells-balanced shards, shard r uploaded to and prepared on device r. The steady state of the `<Ngpu>` rows:
+    ``engine.pairs_sharded(batch, scope)`` scores all shards and gathers the distances with RCCL."""
+
+    def __init__(self, scope: DeviceScope, a: Strs, b: Strs, utf8: bool = False):
+        if not isinstance(a, Strs) or not isinstance(b, Strs):
+            raise TypeError("sharding reads host tapes (Strs)")
+        ta, a64, keep_a = _c_tape(a)
+        tb, b64, keep_b = _c_tape(b, want64=a64 or None)
+        if a64 != b64:
+            ta, a64, keep_a = _c_tape(a, want64=True)
+            tb, b64, keep_b = _c_tape(b, want64=True)
+        handle, err = C.c_void_p(), C.c_char_p()
+        fn = N.lib.swh_sharded_prepare_u64tape if a64 else N.lib.swh_sharded_prepare_u32tape
+        N.check(fn(scope.handle, C.byref(ta), C.byref(tb), int(bool(utf8)), C.byref(handle), C.byref(err)), err)
+        self._handle, self.count, self.utf8, self._scope = handle, len(a), bool(utf8), scope
+
+    @property
+    def cuts(self) -> list:
+        n = self._scope.device_count + 1
+        cuts = (C.c_size_t * n)()
+        N.lib.swh_sharded_cuts(self._handle, cuts, n)
+        return [int(c) for c in cuts]
+
+    def free(self) -> None:
+        if getattr(self, "_handle", None) and getattr(N, "lib", None) is not None:
+            N.lib.swh_sharded_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 TapeLike = Union[Strs, DeviceTape, PreparedTape, Sequence[Union[bytes, str]]]
 
 
@@ -411,6 +478,18 @@ class LevenshteinDistances(_Engine):
         else:
             fns = (N.lib.swh_levenshtein_pairs_u32tape, N.lib.swh_levenshtein_pairs_u64tape)
         return self._pairs(fns[0], fns[1], a, b, scope, out, np.uint32, extra=(C.c_uint32(bound_value),))
+
+    def pairs_sharded(self, batch: "ShardedPairs", scope: DeviceScope, bound: Optional[int] = None, out=None):
+        """One batch over every GPU of a multi-device scope; the distances come back gathered, in pair order."""
+        if self._utf8 != batch.utf8:
+            raise ValueError("engine and sharded batch disagree on UTF-8")
+        if out is None:
+            out = np.zeros(batch.count, dtype=np.uint32)
+        err = C.c_char_p()
+        status = N.lib.swh_levenshtein_pairs_sharded(self._handle, scope.handle, batch._handle,
+                                                     N.UNBOUNDED if bound is None else int(bound), C.c_void_p(_pointer(out)), C.byref(err))
+        N.check(status, err)
+        return out
 
     def __del__(self):
         if getattr(self, "_handle", None) and getattr(N, "lib", None) is not None:   # module globals go first at exit

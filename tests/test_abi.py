@@ -30,6 +30,27 @@ def test_binding_table_matches_header(sw):
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
 
 
+def test_rust_crate_declares_the_c_abi():
+    """stringwars_amd/rust (north-star: "exposed from a new Rust crate through a thin extern "C" FFI") cannot be compiled
+    here, so its extern block is at least held to the header: every symbol of include/stringwars_amd.h is declared in
+    src/lib.rs with the same number of parameters, and the patch for the reference's bench.rs / Cargo.toml is present."""
+    crate = os.path.join(ROOT, "stringwars_amd", "rust")
+    for name in ("Cargo.toml", "build.rs", os.path.join("src", "lib.rs"), "bench.rs.patch"):
+        assert os.path.exists(os.path.join(crate, name)), name
+    rust = open(os.path.join(crate, "src", "lib.rs")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "stringwars_amd.h")).read(), flags=re.S)
+    for name in declared_symbols("stringwars_amd.h"):
+        c_decl = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, header, flags=re.S)
+        r_decl = re.search(r"\bfn %s\s*\(([^;]*?)\)\s*(->[^;]*)?;" % name, rust, flags=re.S)
+        assert c_decl and r_decl, f"{name} is not declared in the Rust crate"
+        c_args = [p for p in c_decl.group(1).split(",") if p.strip() and p.strip() != "void"]
+        r_args = [p for p in r_decl.group(1).split(",") if p.strip()]
+        assert len(c_args) == len(r_args), (name, c_args, r_args)
+    patch = open(os.path.join(crate, "bench.rs.patch")).read()
+    assert "similarities/bench.rs" in patch and "Cargo.toml" in patch and "stringwars_amd::levenshtein_pairs<" in patch
+    assert "verify-rapidfuzz" in open(os.path.join(crate, "Cargo.toml")).read() and "assert_eq!" in rust
+
+
 def test_no_oracle_in_product():
     """The product path must never touch oracle/ (tier rule 3)."""
     for base, _, files in os.walk(os.path.join(ROOT, "stringwars_amd")):

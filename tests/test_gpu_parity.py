@@ -709,6 +709,43 @@ def test_prepared_tapes_in_asynchronous_and_pipelined_scopes(sw, orc):
         scope.set_async(False)
 
 
+def test_multi_device_scope_on_one_gpu(sw, orc):
+    """`swh_scope_init_gpus` + `swh_sharded_prepare_*` + `swh_levenshtein_pairs_sharded` with the members sharing device
+    0 (N scopes on one GPU: the whole sharding / per-member scoring / gather-in-place path except RCCL itself, which
+    needs distinct GPUs), and a one-member scope (communicator-free by construction)."""
+    a, b = sw.generate_pairs("tokens64", 60_000, seed=21)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    for devices in ([0], [0, 0], [0, 0, 0, 0, 0]):
+        scope = sw.DeviceScope(gpu_devices=devices)
+        assert scope.device_count == len(devices) and scope.compute_units == 256
+        engine = sw.LevenshteinDistances(capabilities=scope)
+        batch = sw.ShardedPairs(scope, a, b)
+        cuts = batch.cuts
+        assert cuts == sw.shard_cuts(a, b, len(devices))
+        assert (engine.pairs_sharded(batch, scope) == want).all()
+        assert (engine.pairs_sharded(batch, scope, bound=5) == np.minimum(want, 6)).all()
+        timing = scope.shard_timing()
+        assert timing["pairs"] == 60_000 and timing["cells"] == int((a.lengths * b.lengths).sum()) and timing["compute_ms"] > 0
+        assert (engine.pairs(a, b, scope) == want).all()                      # ordinary calls run on the first device
+        import torch
+        out = torch.zeros(60_000, dtype=torch.int32, device="cuda")           # first-device memory as the destination
+        engine.pairs_sharded(batch, scope, out=out)
+        assert (out.cpu().numpy().astype(np.uint32) == want).all()
+        batch.free()
+    ua, ub = sw.generate_pairs("utf8_lines", 900, seed=21)
+    scope = sw.DeviceScope(gpu_devices=[0, 0, 0])
+    chars = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    batch = sw.ShardedPairs(scope, ua, ub, utf8=True)
+    assert (chars.pairs_sharded(batch, scope, bound=32) == orc.levenshtein_pairs(ua, ub, utf8=True, bound=32)).all()
+    ragged = sw.Strs([b"x" * 3000, b"", b"ab", b"c"] + [b"w"] * 50)       # one pair holds nearly all the cells
+    other = sw.Strs([b"y" * 2900, b"q", b"", b"c"] + [b"w"] * 50)
+    batch = sw.ShardedPairs(scope, ragged, other)
+    assert (sw.LevenshteinDistances(capabilities=scope).pairs_sharded(batch, scope) == orc.levenshtein_pairs(ragged, other)).all()
+    with pytest.raises(sw.StringWarsError):
+        sw.NeedlemanWunschScores(*sw.unary_class_costs(2, -1), open=-2, extend=-2, capabilities=scope)  # engines are fine ...
+        sw.ShardedPairs(sw.DeviceScope(gpu_device=0), a, b)                   # ... but a single-device scope does not shard
+
+
 BAD_UTF8 = [b"\xff", b"\xc0\x80", b"\xc1\xbf", b"\xe0\x80\x80", b"\xe0\x9f\xbf", b"\xed\xa0\x80", b"\xed\xbf\xbf",
             b"\xf0\x8f\xbf\xbf", b"\xf4\x90\x80\x80", b"\xf5\x80\x80\x80", b"\xf8\x88\x80\x80\x80", b"\xe2\x82", b"\xf0\x9f\x98",
             b"\xc3", b"\x80", b"\xbf\xbf", b"\xc3\x28", b"\xe2\x28\xa1", b"\xe2\x82\x28", b"\xf0\x28\x8c\xbc", b"\xf0\x90\x28\xbc",

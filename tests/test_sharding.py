@@ -121,3 +121,20 @@ def test_shard_helpers():
     assert sharding.shard_ranges_by_block_cells([30, 10], 100, 150, 2) == [(0, 67), (67, 150)]
     la = np.array([1, 100, 1, 1, 100, 1]); lb = np.array([1, 100, 1, 1, 100, 1])
     assert sharding.shard_ranges_by_cells(la, lb, 2) == [(0, 2), (2, 6)] or sharding.shard_ranges_by_cells(la, lb, 2)[0][1] in (2, 3, 4)
+
+
+def test_c_abi_shard_cuts_match_the_python_partition(sw):
+    """`swh_shard_cuts_*` (what `swh_sharded_prepare_*` cuts a batch with inside the library) == the Python reference
+    partition, u32 and u64 offsets, degenerate batches included."""
+    from stringwars_amd import sharding
+    for workload, count in (("words16", 5001), ("tokens64", 777), ("short_words", 20_000)):
+        a, b = sw.generate_pairs(workload, count, seed=9)
+        for shards in (1, 2, 3, 8, 16):
+            want = sharding.shard_ranges_by_cells(a.lengths, b.lengths, shards)
+            want = [r[0] for r in want] + [count]
+            assert sw.shard_cuts(a, b, shards) == want
+            assert sw.shard_cuts(a.with_offsets(np.uint32), b.with_offsets(np.uint32), shards) == want
+    empty = sw.Strs([b"", b"", b"", b""])
+    assert sw.shard_cuts(empty, empty, 2) == [0, 2, 4]                      # no cells at all: equal counts
+    one = sw.Strs([b"abc"])
+    assert sw.shard_cuts(one, one, 4) in ([0, 0, 0, 0, 1], [0, 1, 1, 1, 1], [0, 0, 0, 1, 1], [0, 0, 1, 1, 1])

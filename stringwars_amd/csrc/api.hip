@@ -522,6 +522,14 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         if (invalid_dev)
             SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, scope->side_stream));
         SWH_HIP_CHECK(hipStreamSynchronize(scope->side_stream));
+        if (plan.fused_failed) {
+            // the one-launch planner could not gather its grid (a device shared with long-running foreign kernels): the DP
+            // kernels found an empty plan; plan again with the three passes, now and from here on
+            SWH_HIP_CHECK(hipStreamSynchronize(stream));
+            scope->fused_disabled = true;
+            scope->stamps_pending = false;
+            return run_call_on(scope, engine, spec, error);
+        }
         // enqueue k_direct_short next time only if short pairs are a real share of the batch (it sweeps all offsets)
         scope->hint_short = (uint64_t)plan.short_pairs * 4 >= pairs;
         scope->hint_lengths = true;
@@ -623,6 +631,7 @@ static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_
             Carver measure{nullptr, 0, 0};
             measure.take<uint32_t>(kKeys); measure.take<uint32_t>(kKeys); measure.take<PlanPartial>(2 * kMaxPartials);
             measure.take<uint32_t>(8); measure.take<Plan>(1);
+            measure.take<uint32_t>(kKeys); measure.take<uint32_t>(kKeys); measure.take<uint32_t>(4);
             SWH_HIP_CHECK(hipMalloc((void **)&scope->plan_area, measure.used));
             SWH_HIP_CHECK(hipMemset(scope->plan_area, 0, measure.used));
             Carver pa{scope->plan_area, 0, measure.used};
@@ -632,6 +641,9 @@ static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_
             scope->plan_leftover = pa.take<uint32_t>(8);
             scope->done_counter = scope->plan_leftover + 4;
             scope->plan_dev = pa.take<Plan>(1);
+            scope->plan_hist2[0] = pa.take<uint32_t>(kKeys);
+            scope->plan_hist2[1] = pa.take<uint32_t>(kKeys);
+            scope->plan_barrier = pa.take<uint32_t>(4);
         }
         // summary of plan-free calls: pinned, mapped, coherent -- the kernels write it, the host reads it after synchronising
         SWH_HIP_CHECK(hipHostMalloc((void **)&scope->summary_host, 256, hipHostMallocMapped | hipHostMallocCoherent));

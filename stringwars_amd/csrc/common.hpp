@@ -128,6 +128,7 @@ struct Plan {
     uint32_t max_la, max_lb;
     uint32_t invalid_utf8;                   // index+1 of the first pair with invalid UTF-8, else 0
     uint32_t short_pairs;                    // pairs with both sides <= 32 symbols (hint: run k_direct_short next time)
+    uint32_t fused_failed;                   // k_plan_fused gave up at its grid barrier: the plan is empty, redo with the three passes
 };
 
 struct PlanPartial { unsigned long long cells, symbols; uint32_t max_la, max_lb, short_pairs, pad; };
@@ -268,6 +269,12 @@ struct Scope {
     uint32_t *plan_hist = nullptr, *plan_cursor = nullptr, *plan_leftover = nullptr;   // carved from plan_area at scope creation
     PlanPartial *plan_partials = nullptr;
     Plan *plan_dev = nullptr;
+    // fused planning kernel (prepass.hip: k_plan_fused): double-buffered key histogram, grid barrier counter + its target
+    uint32_t *plan_hist2[2] = {nullptr, nullptr};
+    uint32_t *plan_barrier = nullptr;
+    uint32_t plan_barrier_target = 0, plan_parity = 0;
+    int fused_per_cu = -1;          // planning workgroups a compute unit holds (occupancy query, once)
+    bool fused_disabled = false;    // the fused planner once failed to gather its grid on this scope
     hipStream_t side_stream = nullptr;  // plan read-back overlaps the first DP kernel
     hipEvent_t plan_ready = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;   // second tape's UTF-8 decode runs on side_stream beside the first's

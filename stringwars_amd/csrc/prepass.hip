@@ -72,11 +72,21 @@ __device__ __forceinline__ bool short_pair(const PairInfo &info) {
     return !info.trivial && info.la <= kDirectMax && info.lb <= kDirectMax;
 }
 
+// The part of pair_info that needs only the two lengths (already in `info`).
+__device__ __forceinline__ void classify_trivial(const PrepassArgs &args, PairInfo &info, int gap_open, int gap_extend,
+                                                 bool levenshtein_unit);
+
 template <typename Off>
 __device__ __forceinline__ PairInfo pair_info(const PrepassArgs &args, uint64_t p, int gap_open, int gap_extend,
                                               bool levenshtein_unit) {
     PairInfo info;
     pair_extent<Off>(args.job, p, info.a0, info.la, info.b0, info.lb);
+    classify_trivial(args, info, gap_open, gap_extend, levenshtein_unit);
+    return info;
+}
+
+__device__ __forceinline__ void classify_trivial(const PrepassArgs &args, PairInfo &info, int gap_open, int gap_extend,
+                                                 bool levenshtein_unit) {
     info.trivial = false;
     info.trivial_value = 0;
     uint32_t la = info.la, lb = info.lb;
@@ -89,7 +99,6 @@ __device__ __forceinline__ PairInfo pair_info(const PrepassArgs &args, uint64_t 
         uint32_t diff = la > lb ? la - lb : lb - la;
         if (diff > args.job.bound) { info.trivial = true; info.trivial_value = -(int64_t)(args.job.bound + 1); }
     }
-    return info;
 }
 
 // Sixteen waves share one 24.6 KB counter array, so a CU holds enough waves to cover the serial key computation
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *hist, uint32_t *cu
     if (threadIdx.x == 0) {
         plan->cells = rcells[0]; plan->symbols = rsyms[0]; plan->max_la = rmaxa[0]; plan->max_lb = rmaxb[0];
         plan->invalid_utf8 = 0; plan->short_pairs = rshort[0];
+        plan->fused_failed = 0;
         *leftover = 0;   // every reader of this call's value is upstream of this kernel or has read it above
     }
     for (int off = 1; off < 1024; off <<= 1) {
@@ -275,6 +285,226 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_scatter(PrepassArgs args)
             if (keys[k] != 0xFFFFFFFFu) args.perm[lcount[keys[k]] + ranks[k]] = (uint32_t)p;
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The three planning passes in ONE launch, for batches that fit (<= kFusedPer pairs per thread of a grid that is
+// resident as a whole: one 1024-thread workgroup per compute unit). Every workgroup classifies a contiguous slice
+// of the batch once, keeping keys and in-key ranks in registers; its per-key counts are added to the global
+// histogram with the atomic's RETURN value as the workgroup's offset inside the key; a grid-wide barrier later
+// every workgroup scans the 6144 key totals for itself and writes its slice of `perm`. No key array, no second
+// look at the offsets, no cursor array, two launch gaps fewer (k_plan_hist / k_plan_scan / k_plan_scatter: 14 + 6 + 12
+// us + gaps on 1 M pairs; this: ~15). The histogram is double-buffered: a call zeroes the buffer of the next one.
+// The barrier is an ever-growing counter compared against a per-call target (no reset, wrap-safe); it cannot deadlock
+// as long as the grid fits the device, because workgroups waiting at it never keep the missing ones from being placed.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kFusedPer = 4;
+struct FusedArgs {
+    uint32_t *ghist;        // kKeys counters, zero on entry
+    uint32_t *ghist_next;   // the other buffer: zeroed here for the next call
+    uint32_t *barrier;      // monotonic arrival counter
+    uint32_t target;        // value it reaches when every workgroup of THIS launch has arrived
+    uint32_t chunk;         // pairs per workgroup
+    uint32_t dblocks;       // k_direct_short's workgroups (their partial sums sit at partials[kMaxPartials ..])
+};
+
+template <typename Off>
+__global__ __launch_bounds__(kPlanThreads) void k_plan_fused(PrepassArgs args, FusedArgs fused) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ uint32_t lhist[kKeys];   // counts -> this workgroup's base inside each key -> final output base
+    __shared__ unsigned long long lcells, lsyms;
+    __shared__ uint32_t lmaxa, lmaxb, lshorts, wave_sum[kPlanThreads / 64];
+    const bool planned = !(args.direct_short && *args.leftover == 0);   // k_direct_short finished every pair: nothing to sort
+    for (int i = threadIdx.x; i < kKeys; i += blockDim.x) lhist[i] = 0;
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; }
+    __syncthreads();
+    uint32_t keys[kFusedPer], ranks[kFusedPer];
+    const uint64_t first = (uint64_t)blockIdx.x * fused.chunk;
+    const uint64_t last = first + fused.chunk < args.job.pairs ? first + fused.chunk : args.job.pairs;
+    if (planned) {
+        unsigned long long cells = 0, syms = 0;
+        uint32_t maxa = 0, maxb = 0, shorts = 0;
+        // every extent this thread needs is requested before the first key is derived (indices clamped into the batch,
+        // so no branch sits between the loads): one memory round trip per thread instead of one per pair
+        uint32_t las[kFusedPer], lbs[kFusedPer];
+#pragma unroll
+        for (int k = 0; k < kFusedPer; ++k) {
+            const uint64_t p = first + (uint64_t)k * kPlanThreads + threadIdx.x;
+            uint64_t a0, b0;
+            pair_extent<Off>(args.job, p < args.job.pairs ? p : args.job.pairs - 1, a0, las[k], b0, lbs[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kFusedPer; ++k) {
+            const uint64_t p = first + (uint64_t)k * kPlanThreads + threadIdx.x;
+            keys[k] = 0xFFFFFFFFu;
+            if (p < last) {
+                PairInfo info;
+                info.la = las[k]; info.lb = lbs[k]; info.a0 = 0; info.b0 = 0;
+                classify_trivial(args, info, args.gap_open, args.gap_extend, args.unit_costs != 0);
+                const bool is_short = short_pair(info);
+                shorts += is_short ? 1u : 0u;
+                cells += (unsigned long long)info.la * info.lb;
+                syms += (unsigned long long)info.la + info.lb;
+                maxa = info.la > maxa ? info.la : maxa;
+                maxb = info.lb > maxb ? info.lb : maxb;
+                uint32_t key;
+                if (info.trivial) {
+                    key = kClassTrivial * kBuckets;
+                    int64_t v = info.trivial_value;
+                    if (args.job.negate) v = (int64_t)clamp_bound((uint32_t)(-v), args.job.bound);
+                    if (!args.direct_short) store_result(args.job, p, v);   // (k_direct_short has stored it already)
+                } else if (is_short && args.direct_short) {
+                    key = kClassTrivial * kBuckets;   // scored by k_direct_short
+                } else {
+                    key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
+                }
+                keys[k] = key;
+                ranks[k] = atomicAdd(&lhist[key], 1u);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            cells += __shfl_xor(cells, off);
+            syms += __shfl_xor(syms, off);
+            shorts += __shfl_xor(shorts, off);
+            const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+            maxa = oa > maxa ? oa : maxa;
+            maxb = ob > maxb ? ob : maxb;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&lcells, cells);
+            atomicAdd(&lsyms, syms);
+            atomicMax(&lmaxa, maxa);
+            atomicMax(&lmaxb, maxb);
+            atomicAdd(&lshorts, shorts);
+        }
+    }
+    __syncthreads();
+    // my counts join the global histogram; what was there before is my offset inside the key
+    for (int i = threadIdx.x; i < kKeys; i += blockDim.x) {
+        const uint32_t c = lhist[i];
+        lhist[i] = c ? atomicAdd(&fused.ghist[i], c) : 0u;
+        if (blockIdx.x == 0) fused.ghist_next[i] = 0;
+    }
+    __syncthreads();   // every thread's atomics have returned before the workgroup reports its arrival
+    if (threadIdx.x == 0) {
+        PlanPartial part{lcells, lsyms, lmaxa, lmaxb, lshorts, 0};
+        if (args.direct_short) part = PlanPartial{0, 0, 0, 0, 0, 0};   // the sums are k_direct_short's
+        args.partials[blockIdx.x] = part;
+        __threadfence();
+        atomicAdd(fused.barrier, 1u);
+        // Wait for the rest of the grid. The launch is sized to be resident as a whole, but a device shared with
+        // somebody else's long-running kernels could still keep workgroups out: after ~2 s the launch gives up, the
+        // host falls back to the three-pass planner and never uses this kernel on the scope again.
+        const unsigned long long spin_start = __builtin_readcyclecounter();
+        bool gave_up = false;
+        while ((int32_t)(__hip_atomic_load(fused.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fused.target) < 0) {
+            if (__hip_atomic_load(fused.barrier + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { gave_up = true; break; }
+            if (__builtin_readcyclecounter() - spin_start > 5000000000ull) {
+                __hip_atomic_store(fused.barrier + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!gave_up && __hip_atomic_load(fused.barrier + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) gave_up = true;
+        wave_sum[0] = gave_up ? 1u : 0u;
+        __threadfence();
+    }
+    __syncthreads();
+    if (wave_sum[0]) {   // an empty plan with the failure mark: the DP kernels find nothing to do, the host redoes the call
+        if (blockIdx.x == 0) {
+            for (int c = threadIdx.x; c <= kMaxClasses; c += blockDim.x) {
+                args.plan->class_start[c] = 0;
+                if (c < kMaxClasses) args.plan->class_count[c] = 0;
+            }
+            if (threadIdx.x == 0) { args.plan->fused_failed = 1; *args.leftover = 0; }
+        }
+        return;
+    }
+    __syncthreads();
+    // every workgroup scans the key totals for itself: kKeys / 1024 consecutive keys per thread
+    constexpr int kPerThread = (kKeys + kPlanThreads - 1) / kPlanThreads;
+    uint32_t totals[kPerThread], sum = 0;
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const int i = threadIdx.x * kPerThread + q;
+        totals[q] = i < kKeys ? __hip_atomic_load(&fused.ghist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        sum += totals[q];
+    }
+    const uint32_t incl = wave_inclusive_sum_u32(sum);
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += wave_sum[w];
+    if (blockIdx.x == 0) {
+        // the plan: class ranges from the key prefixes, work units folded from the partial sums
+#pragma unroll
+        for (int q = 0; q < kPerThread; ++q) {
+            const int i = threadIdx.x * kPerThread + q;
+            if (i < kKeys && i % kBuckets == 0) args.plan->class_start[i / kBuckets] = run + [&] { uint32_t before = 0; for (int r = 0; r < q; ++r) before += totals[r]; return before; }();
+        }
+        if (threadIdx.x == kPlanThreads - 1) args.plan->class_start[kMaxClasses] = run + sum;
+    }
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const int i = threadIdx.x * kPerThread + q;
+        if (i < kKeys) lhist[i] += run;
+        run += totals[q];
+    }
+    __syncthreads();
+    if (planned) {
+#pragma unroll
+        for (int k = 0; k < kFusedPer; ++k) {
+            const uint64_t p = first + (uint64_t)k * kPlanThreads + threadIdx.x;
+            if (keys[k] != 0xFFFFFFFFu) args.perm[lhist[keys[k]] + ranks[k]] = (uint32_t)p;
+        }
+    }
+    if (blockIdx.x != 0) return;
+    // ---- workgroup 0 finishes the plan ------------------------------------------------------------------------------
+    __syncthreads();
+    if (threadIdx.x < kMaxClasses) {
+        const uint32_t s0 = args.plan->class_start[threadIdx.x], s1 = args.plan->class_start[threadIdx.x + 1];
+        args.plan->class_count[threadIdx.x] = s1 - s0;
+    }
+    unsigned long long c = 0, sy = 0;
+    uint32_t ma = 0, mb = 0, sh = 0;
+    for (uint32_t i = threadIdx.x; i < gridDim.x + fused.dblocks; i += blockDim.x) {
+        const bool from_plan = i < gridDim.x;
+        const unsigned long long *q = (const unsigned long long *)&args.partials[from_plan ? i : kMaxPartials + (i - gridDim.x)];
+        c += __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sy += __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ma = (uint32_t)w2 > ma ? (uint32_t)w2 : ma;
+        mb = (uint32_t)(w2 >> 32) > mb ? (uint32_t)(w2 >> 32) : mb;
+        sh += (uint32_t)w3;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        c += __shfl_xor(c, off);
+        sy += __shfl_xor(sy, off);
+        sh += __shfl_xor(sh, off);
+        const uint32_t oa = __shfl_xor(ma, off), ob = __shfl_xor(mb, off);
+        ma = oa > ma ? oa : ma;
+        mb = ob > mb ? ob : mb;
+    }
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&lcells, c);
+        atomicAdd(&lsyms, sy);
+        atomicMax(&lmaxa, ma);
+        atomicMax(&lmaxb, mb);
+        atomicAdd(&lshorts, sh);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        args.plan->cells = lcells; args.plan->symbols = lsyms; args.plan->max_la = lmaxa; args.plan->max_lb = lmaxb;
+        args.plan->invalid_utf8 = 0; args.plan->short_pairs = lshorts;
+        args.plan->fused_failed = 0;
+        *args.leftover = 0;
     }
 }
 
@@ -554,11 +784,46 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     int dblocks = 0;
+    // the planning passes as one launch when the batch fits a grid that is resident as a whole
+    static const bool fused_off = [] { const char *e = getenv("STRINGWARS_AMD_PLAN"); return e && !strcmp(e, "split"); }();
+    if (scope->fused_per_cu < 0) {   // how many 1024-thread planning workgroups one compute unit holds (asked once)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_plan_fused<uint32_t>, kPlanThreads, 0) != hipSuccess) per_cu = 0;
+        (void)hipGetLastError();
+        scope->fused_per_cu = per_cu > 2 ? 2 : per_cu;
+    }
+    const uint32_t fused_slots = (uint32_t)scope->fused_per_cu * (uint32_t)scope->compute_units;
+    const uint64_t fused_capacity = (uint64_t)fused_slots * kPlanThreads * kFusedPer;
+    const bool fused = !fused_off && !scope->fused_disabled && fused_slots > 0 && fused_slots <= (uint32_t)kMaxPartials && pairs <= fused_capacity;
     if (args.direct_short) {
         StampGuard guard(scope, "direct_short");
         dblocks = direct_short_blocks(scope, pairs);
         if (args.off64) hipLaunchKernelGGL(k_direct_short<uint64_t>, dim3(dblocks), dim3(256), 0, stream, args);
         else hipLaunchKernelGGL(k_direct_short<uint32_t>, dim3(dblocks), dim3(256), 0, stream, args);
+    }
+    if (fused) {
+        // two workgroups per compute unit at most (32 waves, 49 KB of LDS: resident together on an idle device; next to
+        // another lane's DP kernel they take turns, which the barrier tolerates); small batches use fewer, >= 2048 pairs each
+        uint32_t nb = (uint32_t)((pairs + 2047) / 2048);
+        if (nb > fused_slots) nb = fused_slots;
+        // test hook: a grid four times larger than the device holds, to exercise the barrier's give-up path
+        static const bool oversubscribe = getenv("STRINGWARS_AMD_FUSED_OVERSUBSCRIBE") != nullptr;
+        if (oversubscribe) nb = 4 * fused_slots <= (uint32_t)kMaxPartials ? 4 * fused_slots : (uint32_t)kMaxPartials;
+        if (nb < 1) nb = 1;
+        FusedArgs f{};
+        f.chunk = (uint32_t)((pairs + nb - 1) / nb);
+        f.ghist = scope->plan_hist2[scope->plan_parity];
+        f.ghist_next = scope->plan_hist2[scope->plan_parity ^ 1];
+        scope->plan_parity ^= 1;
+        f.barrier = scope->plan_barrier;
+        scope->plan_barrier_target += nb;
+        f.target = scope->plan_barrier_target;
+        f.dblocks = (uint32_t)dblocks;
+        StampGuard guard(scope, "plan_fused");
+        if (args.off64) hipLaunchKernelGGL(k_plan_fused<uint64_t>, dim3(nb), dim3(kPlanThreads), 0, stream, args, f);
+        else hipLaunchKernelGGL(k_plan_fused<uint32_t>, dim3(nb), dim3(kPlanThreads), 0, stream, args, f);
+        SWH_HIP_CHECK(hipGetLastError());
+        return;
     }
     {
         StampGuard guard(scope, "plan_hist");

@@ -984,3 +984,25 @@ def test_config5_short_words_large(sw, orc, scope):
     got = sw.LevenshteinDistances(capabilities=scope).pairs(a, b, scope)
     want = orc.levenshtein_pairs(a, b, algo="hyyro")
     assert (got == want).all()
+
+
+def test_fused_planner_gives_up_instead_of_hanging():
+    """The one-launch planner waits at a grid-wide barrier; if its grid cannot be resident as a whole (forced here by
+    oversubscribing it) it must give up after its time-out, and the call must be redone with the three-pass planner --
+    same results, a couple of seconds late, never a hang."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, time, oracle, stringwars_amd as sw\n"
+        "scope = sw.DeviceScope(gpu_device=0)\n"
+        "a, b = sw.generate_pairs('tokens64', 700000, seed=5)\n"
+        "engine = sw.LevenshteinDistances(capabilities=scope, algorithm='bitparallel')\n"
+        "t = time.time(); got = engine.pairs(a, b, scope); first = time.time() - t\n"
+        "t = time.time(); again = engine.pairs(a, b, scope); second = time.time() - t\n"
+        "want = oracle.levenshtein_pairs(a, b, algo='hyyro', count=20000)\n"
+        "assert (got[:20000] == want).all() and (got == again).all()\n"
+        "assert second < 1.0, second\n"
+        "print('gave-up ok', round(first, 2), round(second, 3))\n")
+    env = dict(os.environ, STRINGWARS_AMD_FUSED_OVERSUBSCRIBE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0 and "gave-up ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--algorithm", default="auto")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--offsets", default="u64", choices=["u32", "u64"])
     ap.add_argument("--prepared", action="store_true", help="prepare the tapes once (swh_tape_prepare_*) outside the timed calls")
     args = ap.parse_args()
     scope = sw.DeviceScope(gpu_device=0)
@@ -45,6 +46,8 @@ def main():
         t0 = time.perf_counter()
         a, b = sw.generate_pairs(cfg["workload"], pairs, seed=42)
         gen_s = time.perf_counter() - t0
+        if args.offsets == "u32":
+            a, b = a.with_offsets(np.uint32), b.with_offsets(np.uint32)
         da, db = a.to_device(scope), b.to_device(scope)
         if args.prepared:
             utf8 = cfg["kind"] == "lev_utf8"
@@ -76,7 +79,7 @@ def main():
         cells = timings[-1]["cells"]
         wall, comp = min(walls), min(t["compute_ms"] for t in timings) * 1e-3
         print(json.dumps({
-            "config": name, **{k: v for k, v in cfg.items() if k != "gaps"}, "prepared": args.prepared, "algorithm": args.algorithm,
+            "config": name, **{k: v for k, v in cfg.items() if k != "gaps"}, "prepared": args.prepared, "algorithm": args.algorithm, "offsets": args.offsets,
             "pairs": pairs, "cells": cells,
             "gcups_call": round(cells / wall / 1e9, 1), "gcups_kernels": round(cells / comp / 1e9, 1),
             "call_ms": round(wall * 1e3, 3), "compute_ms": round(comp * 1e3, 3),

@@ -250,9 +250,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
     const bool utf8 = prepared ? (spec.pa->utf8 && !(spec.pa->ascii && spec.pb->ascii)) : spec.utf8;
     if (prepared && !utf8 && spec.pa->off64 != spec.pb->off64)
         return fail(error, swh_invalid_argument_k, "prepared byte tapes must share one offset width");
-    const bool unit_utf8_only = utf8 && engine->scoring.matrix;
-    if (unit_utf8_only)
-        return fail(error, swh_not_implemented_k, "affine or matrix scoring over UTF-8 code points");
+    if (utf8 && engine->scoring.matrix)
+        return fail(error, swh_not_implemented_k, "substitution-matrix scoring over UTF-8 code points (the matrix is indexed by bytes)");
     try {
         SWH_HIP_CHECK(hipSetDevice(scope->device));
         hipStream_t stream = scope->stream;
@@ -553,7 +552,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         for (int c = kClassWf16; c <= kClassWfMulti; ++c) {
             if (!plan.class_count[c]) continue;
             any_wf = true;
-            if (c == kClassWfMulti || (k.affine && c >= kClassWf64 + 8)) multi = true;  // (class-table affine needs it from 64 columns/lane up)
+            if (c == kClassWfMulti || (k.affine && c >= kClassWf64 + 8)) multi = true;  // (affine strips are capped: the widest classes take several passes)
             if (wavefront_strip_cap() && c >= kClassWf64 && wide_w(c - kClassWf64 < kNumWideW ? c - kClassWf64 : kNumWideW - 1) > wavefront_strip_cap()) multi = true;
         }
         if (any_wf) {
@@ -938,15 +937,7 @@ swh_status_t swh_levenshtein_init(swh_scope_t handle, int match, int mismatch, i
     engine->algorithm = swh_algorithm_auto_k;
     // max-plus core: distances are negated scores
     engine->scoring = Scoring{-match, -mismatch, -open, -extend, nullptr, nullptr};
-    if (open != extend) {
-        // affine gaps run on the matrix kernels: expand the uniform costs into a 256x256 table
-        static thread_local int8_t table[65536];
-        for (int i = 0; i < 256; ++i)
-            for (int j = 0; j < 256; ++j) table[i * 256 + j] = (int8_t)(i == j ? -match : -mismatch);
-        (void)hipSetDevice(scope->device);
-        swh_status_t st = upload_matrix(engine, table, error);
-        if (st != swh_success_k) { delete engine; return st; }
-    }
+    // affine gaps (open != extend) run on the wavefront kernels' uniform-cost Gotoh model, bytes and code points alike
     *out = (swh_levenshtein_t)engine;
     return swh_success_k;
 }

@@ -23,7 +23,8 @@ namespace swh {
 
 enum WfModel : int {
     kUniformLinear = 0, kMatrixLinear = 1, kMatrixAffine = 2, kMatrixLinearLocal = 3, kMatrixAffineLocal = 4,
-    kClassLinear = 5, kClassAffine = 6  // <= 32 symbol classes: cost rows live in registers, bytes picked by v_perm_b32
+    kClassLinear = 5, kClassAffine = 6,  // <= 32 symbol classes: cost rows live in registers, bytes picked by v_perm_b32
+    kUniformAffine = 7                   // match / mismatch by comparison (any symbol width), Gotoh gaps: general-cost Levenshtein
 };
 constexpr size_t kClassLds = 32 * 32 + 256;  // 32x32 i8 class costs, then the byte -> class map
 
@@ -122,8 +123,8 @@ __device__ __forceinline__ void store_score(const Job &job, uint64_t p, int scor
 template <typename Sym, int G, int W, int MODEL, int PQ = 4>
 __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls) {
     constexpr bool kClass = MODEL == kClassLinear || MODEL == kClassAffine;
-    constexpr bool kMatrix = MODEL != kUniformLinear && !kClass;   // per-cell LDS gather from the 256x256 table
-    constexpr bool kAffine = MODEL == kMatrixAffine || MODEL == kMatrixAffineLocal || MODEL == kClassAffine;
+    constexpr bool kMatrix = MODEL != kUniformLinear && MODEL != kUniformAffine && !kClass;   // per-cell LDS gather from the 256x256 table
+    constexpr bool kAffine = MODEL == kMatrixAffine || MODEL == kMatrixAffineLocal || MODEL == kClassAffine || MODEL == kUniformAffine;
     static_assert(!kClass || W % 4 == 0, "class model handles columns four at a time");
     // Smith-Waterman (local) on the same tiles: boundaries and every cell are floored at 0 and the result is the
     // maximum over all cells (`SmithWatermanScores`, bench.rs:882-963).
@@ -429,7 +430,7 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
     constexpr int kGroups = 64 / G;
     uint32_t chunks = (count + kGroups - 1) / kGroups;
     uint32_t blocks = (chunks + 3) / 4;
-    size_t lds = MODEL == kUniformLinear ? 0 : (MODEL == kClassLinear || MODEL == kClassAffine ? kClassLds : kMatrixLds);
+    size_t lds = (MODEL == kUniformLinear || MODEL == kUniformAffine) ? 0 : (MODEL == kClassLinear || MODEL == kClassAffine ? kClassLds : kMatrixLds);
     // persistent-ish grid: enough blocks to fill the chip several times over, waves stride over chunks
     uint32_t max_blocks = (uint32_t)scope->compute_units * (lds > 4096 ? 2 : 8);
     if (blocks > max_blocks) blocks = max_blocks;
@@ -472,7 +473,7 @@ static void launch_model(Scope *scope, const KernelArgs &args, const Plan &plan)
     }
     SWH_WF64(0, 3) SWH_WF64(1, 4) SWH_WF64(2, 6) SWH_WF64(3, 8) SWH_WF64(4, 12) SWH_WF64(5, 16)
     SWH_WF64(6, 24) SWH_WF64(7, 32)
-    if constexpr (MODEL != kMatrixAffine && MODEL != kMatrixAffineLocal) {
+    if constexpr (MODEL != kMatrixAffine && MODEL != kMatrixAffineLocal && MODEL != kUniformAffine) {
         SWH_WF64(8, 48) SWH_WF64(9, 64) SWH_WF64(10, 80) SWH_WF64(11, 96)
     } else {
         // affine keeps two state rows per column: cap the strip at 32 columns, wider pairs go multi-pass
@@ -548,9 +549,12 @@ void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan) {
 static void launch_wavefront_classes(Scope *scope, const KernelArgs &args, const Plan &plan) {
     bool matrix = args.scoring.matrix != nullptr;
     if (args.sym_bytes == 4) {
-        launch_model<uint32_t, kUniformLinear>(scope, args, plan);
+        // code points: uniform match / mismatch costs only (`LevenshteinDistancesUtf8::new(&scope, m, x, o, e)`, bench.rs:386-389)
+        if (!args.affine) launch_model<uint32_t, kUniformLinear>(scope, args, plan);
+        else launch_model<uint32_t, kUniformAffine>(scope, args, plan);
     } else if (!matrix) {
-        launch_model<uint8_t, kUniformLinear>(scope, args, plan);
+        if (!args.affine) launch_model<uint8_t, kUniformLinear>(scope, args, plan);
+        else launch_model<uint8_t, kUniformAffine>(scope, args, plan);
     } else if (args.scoring.class_table && !args.local) {
         // one v_perm per group of four columns and per 8 classes the matrix distinguishes
         const uint32_t classes = args.scoring.classes ? args.scoring.classes : 32;

@@ -389,6 +389,32 @@ def test_general_cost_levenshtein_bounded(sw, orc, scope, costs):
         assert (engine.pairs(a, b, scope, bound=bound) == np.minimum(full, bound + 1)).all()
 
 
+@pytest.mark.parametrize("costs", [(0, 1, 2, 1), (1, 3, 4, 2), (0, 2, 3, 3), (0, 1, 1, 1)])
+def test_general_cost_levenshtein_over_code_points(sw, orc, scope, costs):
+    """`LevenshteinDistancesUtf8::new(&scope, match, mismatch, open, extend)` (bench.rs:386-389) with non-unit and affine
+    costs: the distance depends on the symbols only through equality, so the byte oracle scores the same strings with
+    every distinct code point renamed to a byte."""
+    rng = np.random.default_rng(41)
+    alphabet = [chr(c) for c in (0x41, 0x7A, 0xE9, 0x416, 0x4E2D, 0x1F600, 0x10FFFF, 0x800, 0x7FF)]
+    def text(n):
+        return "".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), n))
+    items_a = [text(int(rng.integers(0, 60))) for _ in range(700)] + [text(150), text(300), ""]
+    items_b = [s[: int(rng.integers(0, len(s) + 1))] + text(int(rng.integers(0, 6))) if rng.random() < 0.6 else text(int(rng.integers(0, 60)))
+               for s in items_a]
+    rename = {ch: bytes([65 + i]) for i, ch in enumerate(alphabet)}
+    as_bytes = lambda items: sw.Strs([b"".join(rename[ch] for ch in s) for s in items])
+    want = orc.levenshtein_costs_pairs(as_bytes(items_a), as_bytes(items_b), *costs)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    engine = sw.LevenshteinDistancesUTF8(*costs, capabilities=scope)
+    assert (engine.pairs(a, b, scope) == want).all()
+    assert (engine.pairs(a, b, scope, bound=6) == np.minimum(want, 7)).all()
+    pa, pb = sw.PreparedTape(scope, a, utf8=True), sw.PreparedTape(scope, b, utf8=True)
+    assert (engine.pairs(pa, pb, scope) == want).all()
+    grid = engine(a.subview(0, 20), b.subview(0, 25), scope)
+    wide = orc.levenshtein_costs_pairs(as_bytes([x for x in items_a[:20] for _ in range(25)]), as_bytes(items_b[:25] * 20), *costs)
+    assert (grid.reshape(-1) == wide).all()
+
+
 def test_scores_beyond_int32_are_refused(sw, scope):
     """Gap costs at the accepted limit times long strings leave the wavefront kernels' 32-bit score range: the call is
     refused (unsupported_length) instead of returning wrapped scores."""

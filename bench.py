@@ -58,7 +58,8 @@ def parse_args():
     p.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     p.add_argument("--workload", default=None, help="override the config's synthetic workload")
     p.add_argument("--pairs", type=int, default=None, help="pairs per GPU (weak configs) / in total (strong configs)")
-    p.add_argument("--chunks", type=int, default=4, help="pieces a shard is scored and gathered in (strong configs)")
+    p.add_argument("--chunks", type=int, default=0,
+                   help="pieces a shard is scored and gathered in (strong configs); 0 = 4 when there is a gather to overlap, 1 on one GPU")
     p.add_argument("--algorithm", default="auto", choices=["auto", "wavefront", "bitparallel", "tiled"])
     p.add_argument("--seed", type=int, default=int(os.environ.get("STRINGWARS_SEED", "42")))
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,7 +83,8 @@ def roofline_of(kernel, kernel_ms, cells, algorithmic_bytes, workload, pairs, co
     VALU peak. SURVEY 8d's nominal 5-ops-per-cell model is carried separately (a bit-parallel kernel executes ~1.2
     lane-ops per cell, so that figure exceeds the peak by construction and is not a roofline fraction)."""
     seconds = kernel_ms * 1e-3
-    entry = constants.get("kernels", {}).get(f"{kernel}|{workload}|{pairs}")
+    entry = constants.get("kernels", {}).get(f"{kernel}|{workload}")
+    scale = pairs / entry["pairs_per_launch"] if entry else 1.0   # the counters were taken on launches of pairs_per_launch pairs
     hbm_gbs = algorithmic_bytes / seconds / 1e9 if seconds > 0 else 0.0
     roof = {
         "bound": "valu", "kernel": kernel, "kernel_ms": round(kernel_ms, 4), "unit": "Tint32op/s", "peak": round(PEAK_VALU_TOPS, 1),
@@ -92,20 +94,20 @@ def roofline_of(kernel, kernel_ms, cells, algorithmic_bytes, workload, pairs, co
                 "algorithmic_bytes": algorithmic_bytes},
     }
     if entry and seconds > 0:
-        lane_ops = entry["valu_insts"] * 64
+        lane_ops = entry["valu_insts"] * scale * 64
         roof["achieved"] = round(lane_ops / seconds / 1e12, 3)
         roof["frac"] = round(lane_ops / seconds / 1e12 / PEAK_VALU_TOPS, 4)
-        roof["valu_wave_insts_per_launch"] = entry["valu_insts"]
+        roof["valu_wave_insts_per_launch"] = round(entry["valu_insts"] * scale, 1)
         roof["lane_ops_per_cell"] = round(lane_ops / max(cells, 1), 3)
         if entry.get("fetch_kb") is not None and entry.get("write_kb") is not None:
             # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of the bytes
             # of wide reads (128-B requests tallied at 64 B) -> doubled; WRITE_SIZE as is. Infinity-Cache hits are counted.
-            roof["traffic"] = int(entry["fetch_kb"] * 1024 * 2 + entry["write_kb"] * 1024)
-            roof["traffic_detail"] = {"fetch_kb_raw": entry["fetch_kb"], "write_kb_raw": entry["write_kb"],
+            roof["traffic"] = int((entry["fetch_kb"] * 1024 * 2 + entry["write_kb"] * 1024) * scale)
+            roof["traffic_detail"] = {"fetch_kb_raw": round(entry["fetch_kb"] * scale, 1), "write_kb_raw": round(entry["write_kb"] * scale, 1),
                                       "fetch_correction": 2, "vs_algorithmic": round(roof["traffic"] / max(algorithmic_bytes, 1), 2)}
-        roof["pmc_source"] = entry.get("source")
+        roof["pmc_source"] = f"{entry.get('source')}; launches of {entry['pairs_per_launch']} pairs"
     else:
-        roof["note"] = f"no PMC constants for {kernel}|{workload}|{pairs} in profiles/r2/pmc_constants.json"
+        roof["note"] = f"no PMC constants for {kernel}|{workload} in profiles/r2/pmc_constants.json"
     if extra:
         roof.update(extra)
     return roof
@@ -225,6 +227,8 @@ def main():
     outs = [torch.zeros(max(pairs, 1), dtype=torch.int32, device=device) for _ in range(2)]
     counter = [0]
     if strong:
+        if args.chunks <= 0:
+            args.chunks = 4 if world > 1 else 1
         pieces = sharding.chunk_ranges(pairs, args.chunks)
         gathers = [None, None]
 
@@ -351,6 +355,12 @@ def main():
                                pairs // (len(pieces) if strong else 1), constants,
                                extra={"all_kernels_ms": round(totals["total_ms"] / calls, 4), "launches_timed": totals["calls"],
                                       "measured": "hipEvents inside the library over a repeat of the timed region"})
+        if roofline.get("achieved") is not None:
+            # two launches overlap in the pipelined region (each then takes about twice as long as alone): per launch the
+            # fraction above halves, per DEVICE it is the work of one launch over the step time
+            step_s = elapsed / args.steps / (len(pieces) if strong else 1)
+            roofline["frac_device"] = round(roofline["valu_wave_insts_per_launch"] * 64 / step_s / 1e12 / PEAK_VALU_TOPS, 4)
+            roofline["frac_device_is"] = "executed lane-ops of one launch / time per launch of the timed region (launches of two lanes overlap)"
         roofline["sync_call"] = roofline_of(sync_timing["dominant_name"], sync_timing["compute_ms"], sync_timing["cells"], sync_timing["bytes"],
                                             workload, pairs, constants, extra={"measured": "one synchronous call on an idle GPU"})
         parity = None

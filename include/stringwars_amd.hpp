@@ -73,6 +73,16 @@ public:
         check(status__, err);
         return s;
     }
+    /// Every listed GPU behind one scope (`swh_scope_init_gpus`): the `<Ngpu>` rows; batches are split by `ShardedPairs`.
+    static DeviceScope gpu_devices(const std::vector<int> &devices) {
+        DeviceScope s; const char *err = nullptr;
+        swh_status_t status__ = swh_scope_init_gpus(devices.data(), (int)devices.size(), &s.handle_, &err);
+        check(status__, err);
+        return s;
+    }
+    static int visible_devices() { int n = 0; swh_device_count(&n); return n; }
+    size_t device_count() const { size_t n = 1; swh_scope_device_count(handle_, &n); return n; }
+    swh_shard_timing_t shard_timing() const { swh_shard_timing_t t{}; swh_scope_shard_timing(handle_, &t); return t; }
     DeviceScope() = default;
     DeviceScope(DeviceScope &&o) noexcept : handle_(o.handle_) { o.handle_ = nullptr; }
     DeviceScope &operator=(DeviceScope &&o) noexcept { std::swap(handle_, o.handle_); return *this; }
@@ -84,6 +94,46 @@ public:
     void set_profiling(bool on) const { swh_scope_set_profiling(handle_, on); }
     swh_timing_t last_timing() const { swh_timing_t t{}; swh_scope_last_timing(handle_, &t); return t; }
     swh_timing_totals_t timing_totals() const { swh_timing_totals_t t{}; swh_scope_timing_totals(handle_, &t); return t; }
+};
+
+/// A tape made ready once (`swh_tape_prepare_u64`): resident, measured, UTF-8 validated + decoded -- what the reference does
+/// when it builds `BytesTapeView` / `CharsTapeView` once outside its timed closures (bench.rs:292-306). `subview` is O(1).
+class PreparedTape {
+    swh_prepared_t handle_ = nullptr;
+    size_t first_ = 0, count_ = 0;
+    bool owner_ = false;
+    PreparedTape(swh_prepared_t h, size_t first, size_t count) : handle_(h), first_(first), count_(count) {}
+public:
+    PreparedTape(const DeviceScope &scope, const BytesTapeView &tape, bool utf8 = false) : count_(tape.count), owner_(true) {
+        const char *err = nullptr;
+        swh_tape_u64_t t = tape.c();
+        swh_status_t status__ = swh_tape_prepare_u64(scope.handle(), &t, utf8 ? 1 : 0, &handle_, &err);
+        check(status__, err);   // invalid UTF-8 surfaces here, as `try_into` does (bench.rs:303-306)
+    }
+    PreparedTape(PreparedTape &&o) noexcept : handle_(o.handle_), first_(o.first_), count_(o.count_), owner_(o.owner_) { o.owner_ = false; }
+    PreparedTape(const PreparedTape &) = delete;
+    ~PreparedTape() { if (owner_ && handle_) swh_prepared_free(handle_); }
+    PreparedTape subview(size_t lo, size_t hi) const { return PreparedTape(handle_, first_ + lo, hi - lo); }
+    size_t size() const { return count_; }
+    swh_prepared_info_t info() const { swh_prepared_info_t i{}; swh_prepared_info(handle_, &i); return i; }
+    swh_prepared_view_t c() const { return swh_prepared_view_t{handle_, first_, count_}; }
+};
+
+/// One pairwise batch resident on every GPU of a multi-device scope (`swh_sharded_prepare_u64tape`), cells-balanced shards.
+class ShardedPairs {
+    swh_sharded_t handle_ = nullptr;
+    size_t count_ = 0;
+public:
+    ShardedPairs(const DeviceScope &scope, const BytesTapeView &a, const BytesTapeView &b, bool utf8 = false) : count_(a.count) {
+        const char *err = nullptr;
+        swh_tape_u64_t ta = a.c(), tb = b.c();
+        swh_status_t status__ = swh_sharded_prepare_u64tape(scope.handle(), &ta, &tb, utf8 ? 1 : 0, &handle_, &err);
+        check(status__, err);
+    }
+    ShardedPairs(const ShardedPairs &) = delete;
+    ~ShardedPairs() { if (handle_) swh_sharded_free(handle_); }
+    swh_sharded_t handle() const { return handle_; }
+    size_t size() const { return count_; }
 };
 
 class LevenshteinDistances {
@@ -117,6 +167,27 @@ public:
         swh_tape_u64_t ta = a.c(), tb = b.c();
         auto fn = utf8_ ? swh_levenshtein_utf8_pairs_u64tape : swh_levenshtein_pairs_u64tape;
         swh_status_t status__ = fn(handle_, scope.handle(), &ta, &tb, bound, out, 4, &err);
+        check(status__, err);
+    }
+    /// The same on prepared tapes: no per-call decode, no planning pre-pass for word- and token-sized strings.
+    void pairs_into(const DeviceScope &scope, const PreparedTape &a, const PreparedTape &b, uint32_t *out,
+                    uint32_t bound = SWH_UNBOUNDED) const {
+        const char *err = nullptr;
+        swh_prepared_view_t va = a.c(), vb = b.c();
+        swh_status_t status__ = swh_levenshtein_pairs_prepared(handle_, scope.handle(), &va, &vb, bound, out, 4, &err);
+        check(status__, err);
+    }
+    void compute_into(const DeviceScope &scope, const PreparedTape &queries, const PreparedTape *candidates, size_t *matrix,
+                      size_t row_stride_bytes = 0) const {
+        const char *err = nullptr;
+        swh_prepared_view_t q = queries.c(), c = candidates ? candidates->c() : q;
+        swh_status_t status__ = swh_levenshtein_cross_prepared(handle_, scope.handle(), &q, candidates ? &c : nullptr, matrix, row_stride_bytes, &err);
+        check(status__, err);
+    }
+    /// One batch over every GPU of a multi-device scope, distances gathered with RCCL inside the library.
+    void pairs_into(const DeviceScope &scope, const ShardedPairs &batch, uint32_t *out, uint32_t bound = SWH_UNBOUNDED) const {
+        const char *err = nullptr;
+        swh_status_t status__ = swh_levenshtein_pairs_sharded(handle_, scope.handle(), batch.handle(), bound, out, &err);
         check(status__, err);
     }
 };

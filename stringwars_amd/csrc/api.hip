@@ -437,6 +437,10 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         job.out = out_dev; job.out_stride = dev_out_stride; job.row_stride = dev_row_stride;
         job.out_elem64 = spec.out64 ? 1 : 0;
         job.negate = engine->kind == 0 ? 1 : 0;
+        if (spec.cross) {
+            if (spec.b.count >= 0xFFFFFFFFull) return fail(error, swh_unsupported_length_k, "more than 2^32 candidates");
+            cross_divider((uint32_t)spec.b.count, job.div_magic, job.div_shift);
+        }
 
         PrepassArgs pre{};
         pre.job = job;

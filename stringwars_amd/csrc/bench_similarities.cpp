@@ -124,6 +124,46 @@ int main() {
             });
             uint64_t checksum = std::accumulate(out.begin(), out.end(), (uint64_t)0);
             std::fprintf(stderr, "  %s checksum=%" PRIu64 "\n", name, checksum);  // bench.py:272
+            // The same pairs on tapes prepared once, the way the reference builds its tape views once above its closures
+            // (bench.rs:292-306) and sub-views them inside (bench.rs:134-139).
+            const char *prepared_name = "uniform/stringwars_amd::levenshtein_pairs<prepared,1gpu>";
+            PreparedTape whole_a(gpu, tokens.a()), whole_b(gpu, tokens.synthetic ? tokens.b() : tokens.a());
+            std::vector<uint32_t> again(n);
+            measure_throughput(prepared_name, ReportAs::Cups, budget, [&] {
+                PreparedTape va = whole_a.subview(0, n), vb = tokens.synthetic ? whole_b.subview(0, n) : whole_b.subview(n, 2 * n);
+                engine.pairs_into(gpu, va, vb, again.data());
+                return WorkUnits{pcells, pbytes};
+            });
+            if (again != out) { std::fprintf(stderr, "error: prepared and raw tapes disagree\n"); return 2; }
+            // Every visible GPU behind one scope (STRINGWARS_AMD_GPUS=0,0 lists devices by hand -- a device may repeat, a
+            // testing arrangement): cells-balanced shards resident per device, RCCL gather inside the library.
+            std::vector<int> devices;
+            if (get_env("STRINGWARS_AMD_GPUS", tmp)) {
+                for (size_t at = 0; at < tmp.size();) {
+                    size_t comma = tmp.find(',', at);
+                    devices.push_back(std::atoi(tmp.substr(at, comma - at).c_str()));
+                    at = comma == std::string::npos ? tmp.size() : comma + 1;
+                }
+            } else {
+                for (int d = 0; d < DeviceScope::visible_devices(); ++d) devices.push_back(d);
+            }
+            if (devices.size() > 1) {
+                char multi_name[96];
+                std::snprintf(multi_name, sizeof multi_name, "uniform/stringwars_amd::levenshtein_pairs<%zugpu>", devices.size());
+                try {
+                    DeviceScope gpus = DeviceScope::gpu_devices(devices);
+                    LevenshteinDistances sharded_engine(gpus, 0, 1, 1, 1);
+                    ShardedPairs batch(gpus, pa, pb);
+                    std::vector<uint32_t> gathered(n);
+                    measure_throughput(multi_name, ReportAs::Cups, budget, [&] {
+                        sharded_engine.pairs_into(gpus, batch, gathered.data());
+                        return WorkUnits{pcells, pbytes};
+                    });
+                    swh_shard_timing_t st = gpus.shard_timing();
+                    std::fprintf(stderr, "  %s slowest shard %.3f ms, gather %.3f ms\n", multi_name, st.compute_ms, st.gather_ms);
+                    if (gathered != out) { std::fprintf(stderr, "error: sharded and single-GPU results disagree\n"); return 2; }
+                } catch (const Error &e) { skipped(multi_name, e.what()); }
+            }
         } catch (const Error &e) { skipped(name, e.what()); }
     }
 

@@ -35,13 +35,32 @@ struct Job {
     uint64_t row_stride;  // bytes between rows (cross)
     uint32_t out_elem64;  // 0: 32-bit results, 1: 64-bit results (size_t / ptrdiff_t)
     uint32_t negate;      // results are stored as -score (min-plus distances run on the max-plus core)
+    uint32_t div_magic, div_shift;   // cross-product mode: reciprocal of b_count (cross_divider / cross_split)
 };
+
+// Cross-product mode: pair p is (query p / b_count, candidate p % b_count). p < 2^32 (api.hip refuses larger batches) and
+// b_count < 2^32, so the split is a 32-bit division by an invariant: multiply-high by a precomputed reciprocal (the
+// round-up method of Granlund & Montgomery; five instructions against ~50 for the 64-bit division the compiler emits).
+__host__ __device__ __forceinline__ void cross_divider(uint32_t d, uint32_t &magic, uint32_t &shift) {
+    // d >= 1. shift = ceil(log2 d); magic = floor(2^32 * (2^shift - d) / d) + 1
+    uint32_t l = 0;
+    while (l < 32 && ((uint64_t)1 << l) < d) ++l;
+    magic = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+    shift = l;
+}
+__device__ __forceinline__ void cross_split(const Job &job, uint64_t p, uint64_t &ia, uint64_t &ib) {
+    const uint32_t n = (uint32_t)p;
+    const uint32_t t = __umulhi(job.div_magic, n);
+    const uint32_t q = job.div_shift ? (uint32_t)((((n - t) >> 1) + t) >> (job.div_shift - 1)) : n;   // shift 0: one candidate
+    ia = q;
+    ib = n - q * (uint32_t)job.b_count;
+}
 
 template <typename Off>
 __device__ __forceinline__ void pair_extent(const Job &job, uint64_t p, uint64_t &a0, uint32_t &la, uint64_t &b0,
                                             uint32_t &lb) {
     uint64_t ia = p, ib = p;
-    if (job.cross) { ia = p / job.b_count; ib = p - ia * job.b_count; }
+    if (job.cross) cross_split(job, p, ia, ib);
     const Off *oa = (const Off *)job.a.offsets, *ob = (const Off *)job.b.offsets;
     Off x0 = oa[ia], x1 = oa[ia + 1], y0 = ob[ib], y1 = ob[ib + 1];
     a0 = (uint64_t)x0; la = (uint32_t)(x1 - x0);
@@ -51,7 +70,8 @@ __device__ __forceinline__ void pair_extent(const Job &job, uint64_t p, uint64_t
 __device__ __forceinline__ void store_result(const Job &job, uint64_t p, int64_t value) {
     char *dst;
     if (job.cross) {
-        uint64_t ia = p / job.b_count, ib = p - ia * job.b_count;
+        uint64_t ia, ib;
+        cross_split(job, p, ia, ib);
         dst = job.out + ia * job.row_stride + ib * (job.out_elem64 ? 8 : 4);
     } else {
         dst = job.out + p * job.out_stride;

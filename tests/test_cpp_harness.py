@@ -47,8 +47,12 @@ def test_rows_are_measured_on_gpu():
     assert result.returncode == 0, result.stderr
     line = re.compile(r"^(\S+)\s+\d+\.\d\d [kMG]?CUPS \| \d+\.\d\d [kMG]?B/s \| p50 \d+\.\d\d (ns|µs|ms|s) p99 \d+\.\d\d (ns|µs|ms|s)$")
     measured = {m.group(1) for m in map(line.match, result.stdout.splitlines()) if m}
-    assert measured == set(ROWS), result.stdout
-    filtered = run({"STRINGWARS_TIME": "0.1", "STRINGWARS_FILTER": "uniform/.*pairs"})
+    assert measured == set(ROWS) | {"uniform/stringwars_amd::levenshtein_pairs<prepared,1gpu>"}, result.stdout
+    filtered = run({"STRINGWARS_TIME": "0.1", "STRINGWARS_FILTER": "uniform/.*pairs<1gpu"})
     names = {m.group(1) for m in map(line.match, filtered.stdout.splitlines()) if m}
     assert names == {"uniform/stringwars_amd::levenshtein_pairs<1gpu>"}
+    # the `<Ngpu>` row: three member scopes on device 0 (one-GPU box), results identical to the single-GPU row
+    multi = run({"STRINGWARS_TIME": "0.1", "STRINGWARS_AMD_GPUS": "0,0,0", "STRINGWARS_FILTER": "uniform/.*pairs"})
+    names = {m.group(1) for m in map(line.match, multi.stdout.splitlines()) if m}
+    assert multi.returncode == 0 and "uniform/stringwars_amd::levenshtein_pairs<3gpu>" in names, (multi.stdout, multi.stderr[-800:])
     assert "Skipping: linear/stringwars_amd::NeedlemanWunschScores<1gpu>" in filtered.stderr

@@ -55,12 +55,15 @@ def main():
         if not merged or "SQ_INSTS_VALU" not in merged:
             continue
         per = {c: merged[c] / counts[c] for c in merged}
-        entry = {"kernel_symbol": needle, "dispatches": int(counts["SQ_INSTS_VALU"]), "valu_insts": round(per["SQ_INSTS_VALU"], 1),
+        # Every dispatch of the profiled command scores `--pairs` pairs, so the averages are per launch of that size; the
+        # per-pair figures let bench.py price launches of another size of the same workload (work is linear in pairs).
+        entry = {"kernel_symbol": needle, "dispatches": int(counts["SQ_INSTS_VALU"]), "pairs_per_launch": args.pairs,
+                 "valu_insts": round(per["SQ_INSTS_VALU"], 1), "valu_insts_per_pair": per["SQ_INSTS_VALU"] / args.pairs,
                  "fetch_kb": round(per["FETCH_SIZE"], 1) if "FETCH_SIZE" in per else None,
                  "write_kb": round(per["WRITE_SIZE"], 1) if "WRITE_SIZE" in per else None,
                  "counters": {c: round(v, 1) for c, v in sorted(per.items())},
                  "source": args.source or f"tools/profile_pmc.sh -> {os.path.basename(os.path.normpath(args.outdir))}"}
-        book["kernels"][f"{stamp}|{args.workload}|{args.pairs}"] = entry
+        book["kernels"][f"{stamp}|{args.workload}"] = entry
         print(stamp, args.workload, args.pairs, "VALU wave-insts", entry["valu_insts"], "fetch KB", entry["fetch_kb"], "write KB", entry["write_kb"])
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(book, open(args.out, "w"), indent=1, sort_keys=True)

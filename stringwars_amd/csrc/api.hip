@@ -215,7 +215,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
 }
 
 // Which kernels a unit-cost Levenshtein call runs on.
-enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort };
+enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort, kRouteCrossShort };
 
 // Strings up to this many symbols (G <= 8 blocks) are scored by the tiled kernel when their lengths are known; beyond it
 // a tile holds too few pairs per block count and the global sort of the planned path packs the waves better.
@@ -356,7 +356,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 const bool band_pays = spec.bound <= 63 && longest > 32;   // plan_key(): the banded kernel wins from ~6 blocks at k = 32
                 if (forced) route = (!guaranteed || shorter_side <= 2048) ? kRouteTiled : kRoutePlanned;
                 else if (!band_pays && longest <= tiled_longest_limit())
-                    route = (longest <= 32 && !utf8 && direct_short_preferred()) ? kRouteDirectShort : kRouteTiled;
+                    route = (longest <= 32 && !utf8 && direct_short_preferred()) ? (spec.cross ? kRouteCrossShort : kRouteDirectShort) : kRouteTiled;
             }
         }
 
@@ -486,6 +486,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             // ---- no pre-pass: one DP launch; its summary (work units, longest strings, "a pair did not fit") arrives in
             // host-mapped memory with the kernel's completion ------------------------------------------------------------
             if (route == kRouteDirectShort) launch_direct_short_alone(scope, pre);
+            else if (route == kRouteCrossShort) launch_cross_short(scope, job, off64);
             else launch_bitparallel_tiled(scope, k, pairs, longest);
             if (invalid_dev) SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));
             copy_results_back();

@@ -315,6 +315,8 @@ TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text) {
     constexpr uint32_t kTileMin = 256;
     const uint64_t rounds = (pairs + (uint64_t)slots * kTileMax - 1) / ((uint64_t)slots * kTileMax);
     uint64_t tile = (pairs + slots * rounds - 1) / (slots * rounds);
+    static const uint32_t forced = [] { const char *e = getenv("STRINGWARS_AMD_TILE"); return e ? (uint32_t)atoi(e) : 0u; }();   // tuning knob
+    if (forced) tile = forced;
     if (tile < kTileMin) tile = kTileMin;
     if (tile > (uint64_t)kTileMax) tile = kTileMax;
     tp.tile = (uint32_t)tile;

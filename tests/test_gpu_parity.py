@@ -670,6 +670,44 @@ def test_prepared_cross_product_and_alignment(sw, orc, scope):
             assert grid.tolist() == [[orc.nw_score(x, y, matrix, gaps[0], gaps[1], local=local) for y in items_b[:9]] for x in items_a[:8]]
 
 
+def test_cross_product_of_words_shares_the_query_table(sw, orc, scope):
+    """The reference's own call shape on word-sized strings (`compute_into(queries, candidates, &mut matrix)`,
+    bench.rs:478-486): k_cross_short keeps 64 candidates in registers and builds each query's match table once per wave.
+    Lengths 0..32 on both sides, ragged counts, u64 matrix with a row stride, prepared and raw tapes; a string of more
+    than 32 bytes on either side sends the call back to the general path."""
+    rng = np.random.default_rng(43)
+    def words(count, longest):
+        return [rng.integers(97, 101, int(rng.integers(0, longest + 1)), dtype=np.uint8).tobytes() for _ in range(count)]
+    queries, candidates = words(130, 32), words(333, 32)
+    queries[7], candidates[11] = b"", b""
+    queries[9], candidates[12] = b"a" * 32, b"a" * 31 + b"b"
+    q, c = sw.Strs(queries), sw.Strs(candidates)
+    flat_q = sw.Strs([x for x in queries for _ in candidates])
+    flat_c = sw.Strs(candidates * len(queries))
+    want = orc.levenshtein_pairs(flat_q, flat_c, algo="hyyro").reshape(len(queries), len(candidates)).astype(np.uint64)
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    pq, pc = sw.PreparedTape(scope, q), sw.PreparedTape(scope, c)
+    scope.set_profiling(True)
+    got = engine(pq, pc, scope)
+    timing = scope.last_timing()
+    scope.set_profiling(False)
+    assert (got == want).all()
+    assert timing["dominant_name"] == "cross_short" and timing["cells"] == int(q.lengths.sum()) * int(c.lengths.sum())
+    assert (engine(pq[10:77], pc[100:333], scope) == want[10:77, 100:333]).all()
+    assert (engine(pc, None, scope) == orc.levenshtein_pairs(sw.Strs([x for x in candidates for _ in candidates]), sw.Strs(candidates * len(candidates)),
+                                                             algo="hyyro").reshape(len(candidates), len(candidates))).all()
+    dq, dc = q.to_device(scope), c.to_device(scope)
+    for _ in range(2):                                                       # raw tapes: the second call rides on the first one's lengths
+        assert (engine(dq, dc, scope) == want).all()
+    # a long string on either side: redone on the general path, same answers
+    long_q = sw.Strs(queries[:20] + [b"ab" * 40])
+    long_c = sw.Strs(candidates[:50] + [b"ba" * 300])
+    want_long = orc.levenshtein_pairs(sw.Strs([long_q[i] for i in range(len(long_q)) for _ in range(len(long_c))]),
+                                      sw.Strs([long_c[j] for _ in range(len(long_q)) for j in range(len(long_c))]), algo="hyyro")
+    assert (engine(long_q.to_device(scope), long_c.to_device(scope), scope).reshape(-1) == want_long).all()
+    assert (engine(sw.PreparedTape(scope, long_q), sw.PreparedTape(scope, long_c), scope).reshape(-1) == want_long).all()
+
+
 def test_tiled_kernel_every_block_count(sw, orc, scope):
     """The tiled kernel forced onto strings of 1 .. 2048 symbols (classes G = 1 .. 64 inside one tile, left-overs moving
     up a class, partly filled items), bytes and code points, bounded and not."""

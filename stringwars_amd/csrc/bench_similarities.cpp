@@ -129,6 +129,10 @@ int main() {
             const char *prepared_name = "uniform/stringwars_amd::levenshtein_pairs<prepared,1gpu>";
             PreparedTape whole_a(gpu, tokens.a()), whole_b(gpu, tokens.synthetic ? tokens.b() : tokens.a());
             std::vector<uint32_t> again(n);
+            {   // one call outside the (filterable) measurement, like the allocating `compute` of the other rows
+                PreparedTape va = whole_a.subview(0, n), vb = tokens.synthetic ? whole_b.subview(0, n) : whole_b.subview(n, 2 * n);
+                engine.pairs_into(gpu, va, vb, again.data());
+            }
             measure_throughput(prepared_name, ReportAs::Cups, budget, [&] {
                 PreparedTape va = whole_a.subview(0, n), vb = tokens.synthetic ? whole_b.subview(0, n) : whole_b.subview(n, 2 * n);
                 engine.pairs_into(gpu, va, vb, again.data());
@@ -155,6 +159,7 @@ int main() {
                     LevenshteinDistances sharded_engine(gpus, 0, 1, 1, 1);
                     ShardedPairs batch(gpus, pa, pb);
                     std::vector<uint32_t> gathered(n);
+                    sharded_engine.pairs_into(gpus, batch, gathered.data());
                     measure_throughput(multi_name, ReportAs::Cups, budget, [&] {
                         sharded_engine.pairs_into(gpus, batch, gathered.data());
                         return WorkUnits{pcells, pbytes};

@@ -221,6 +221,14 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         }
         __syncthreads();
         TILE_STAMP(0);   // planning the tile
+        // The key counters have done their work: keep the 64 class starts (class_thr is free since step D), then the
+        // 4 KB they occupied stage the tile's distances -- one coalesced sweep at the end instead of 4-byte stores
+        // scattered over the tile's window (which reached HBM as one 32-byte sector each: 6x the result bytes).
+        if (threadIdx.x < kTileClasses) tl.class_thr[threadIdx.x] = (uint16_t)(tl.bins[(threadIdx.x * kTileBuckets) >> 1] & 0xFFFFu);
+        __syncthreads();
+        uint32_t *const staged = tl.bins;
+        for (int i = threadIdx.x; i < kTileBins / 2; i += kThreads) staged[i] = 0xFFFFFFFFu;   // "no distance here" (trivial pairs are stored directly)
+        __syncthreads();
         // ---- G: work items, heaviest first (high class, long text), dealt by an LDS ticket --------------------------------
         {
             const uint32_t items_total = tl.item_prefix[64];
@@ -234,8 +242,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                 const uint32_t G = (uint32_t)__popcll(__ballot(my_prefix <= item));   // class = prefix entries <= item
                 const uint32_t per = 64 / G;
                 const uint32_t chunk = item - tl.item_prefix[G - 1];
-                const uint32_t cword = tl.bins[((G - 1) * kTileBuckets) >> 1];   // (even key: low half) start of class G
-                const uint32_t cstart = cword & 0xFFFFu, ccount = tl.class_count[G - 1];
+                const uint32_t cstart = tl.class_thr[G - 1], ccount = tl.class_count[G - 1];
                 const uint32_t slot = (uint32_t)lane / G;
                 const uint32_t pidx = chunk * per + slot;
                 const bool have = slot < per && pidx < ccount;
@@ -246,15 +253,20 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                     if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
                     else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
                 }
-                bp_item<Sym, kWide>(args, wv, G, have, p, a0, la, b0, lb);
+                bp_item<Sym, kWide>(args, wv, G, have, p, a0, la, b0, lb, staged, base);
 #ifdef SWH_TILE_PROFILE
                 ++items_done;
 #endif
             }
         }
         TILE_STAMP(1);   // work items
-        __syncthreads();   // the next tile rewrites the lists
+        __syncthreads();
         TILE_STAMP(2);   // waiting for the workgroup's other waves
+        for (uint32_t i = threadIdx.x; i < count; i += kThreads) {
+            const uint32_t d = staged[i];
+            if (d != 0xFFFFFFFFu) store_result(args.job, base + i, (int64_t)d);
+        }
+        __syncthreads();   // the next tile rewrites the lists
     }
 #ifdef SWH_TILE_PROFILE
     if (lane == 0) {

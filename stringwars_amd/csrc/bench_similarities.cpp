@@ -129,15 +129,23 @@ int main() {
             const char *prepared_name = "uniform/stringwars_amd::levenshtein_pairs<prepared,1gpu>";
             PreparedTape whole_a(gpu, tokens.a()), whole_b(gpu, tokens.synthetic ? tokens.b() : tokens.a());
             std::vector<uint32_t> again(n);
+            // results stay in device memory during the timed calls (the role `UnifiedMat` plays for the reference's GPU rows,
+            // bench.rs:466-476) and come back once, for the comparison below
+            void *out_device = nullptr;
+            const char *alloc_error = nullptr;
+            swh_status_t alloc_status = swh_device_alloc(gpu.handle(), n * sizeof(uint32_t) + 16, &out_device, &alloc_error);
+            check(alloc_status, alloc_error);
             {   // one call outside the (filterable) measurement, like the allocating `compute` of the other rows
                 PreparedTape va = whole_a.subview(0, n), vb = tokens.synthetic ? whole_b.subview(0, n) : whole_b.subview(n, 2 * n);
-                engine.pairs_into(gpu, va, vb, again.data());
+                engine.pairs_into(gpu, va, vb, (uint32_t *)out_device);
             }
             measure_throughput(prepared_name, ReportAs::Cups, budget, [&] {
                 PreparedTape va = whole_a.subview(0, n), vb = tokens.synthetic ? whole_b.subview(0, n) : whole_b.subview(n, 2 * n);
-                engine.pairs_into(gpu, va, vb, again.data());
+                engine.pairs_into(gpu, va, vb, (uint32_t *)out_device);
                 return WorkUnits{pcells, pbytes};
             });
+            swh_copy_to_host(gpu.handle(), again.data(), out_device, n * sizeof(uint32_t), nullptr);
+            swh_device_free(gpu.handle(), out_device);
             if (again != out) { std::fprintf(stderr, "error: prepared and raw tapes disagree\n"); return 2; }
             // Every visible GPU behind one scope (STRINGWARS_AMD_GPUS=0,0 lists devices by hand -- a device may repeat, a
             // testing arrangement): cells-balanced shards resident per device, RCCL gather inside the library.

@@ -400,6 +400,27 @@ class _Engine:
         N.check(status, err)
         return out
 
+    def bind_pairs(self, a: "PreparedTape", b: "PreparedTape", scope: DeviceScope, out, bound: Optional[int] = None):
+        """A pre-bound pairwise call on prepared views: every ctypes argument is built once, the returned callable
+        only crosses the FFI (what a compiled harness pays per call; `pairs()` re-derives views, pointers and strides
+        in Python each time, ~10 us). `out` must stay alive and in place."""
+        if not isinstance(a, PreparedTape) or not isinstance(b, PreparedTape) or len(a) != len(b):
+            raise TypeError("bind_pairs takes two prepared views of equal length")
+        if self._utf8 != a.utf8:
+            raise ValueError("engine and tapes disagree on UTF-8")
+        va, vb, err = a.view(), b.view(), C.c_char_p()
+        fn = getattr(N.lib, self._abi_prefix + "_pairs_prepared")
+        extra = (C.c_uint32(N.UNBOUNDED if bound is None else int(bound)),) if self._abi_prefix == "swh_levenshtein" else ()
+        args = (self._handle, scope.handle, C.byref(va), C.byref(vb), *extra, C.c_void_p(_pointer(out)),
+                out.strides[0] if isinstance(out, np.ndarray) and out.size > 1 else 0, C.byref(err))
+        keep = (va, vb, err, a, b, out)
+
+        def call(_fn=fn, _args=args, _keep=keep):
+            status = _fn(*_args)
+            if status != N.SUCCESS:
+                N.check(status, _keep[2])
+        return call
+
     def _pairs(self, fn32, fn64, a, b, scope, out, out_dtype, extra=()):
         a, b = _as_tape(a), _as_tape(b)
         if len(a) != len(b):

@@ -63,6 +63,7 @@ def main():
     piped = sw.DeviceScope(gpu_device=0)
     piped.set_async(True)
     piped.set_pipelined(True)
+    multi = sw.DeviceScope(gpu_devices=[0, 0, 0])
     t0, rounds, pairs_total = time.time(), 0, 0
     while time.time() - t0 < args.seconds:
         kind = str(rng.choice(["lev", "lev", "lev_utf8", "nw", "sw"]))
@@ -70,7 +71,7 @@ def main():
             utf8 = kind == "lev_utf8"
             a, b = random_batch(rng, utf8)
             bound = None if rng.random() < 0.5 else int(rng.integers(0, 80))
-            algorithm = str(rng.choice(["auto", "auto", "bitparallel", "wavefront"]))
+            algorithm = str(rng.choice(["auto", "auto", "bitparallel", "wavefront", "tiled"]))
             if algorithm == "wavefront" and oracle.cells(a, b, utf8=utf8) > 3e8:
                 algorithm = "auto"
             cls = sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances
@@ -80,6 +81,29 @@ def main():
                 got = engine.pairs(a, b, scope, bound=bound)
                 bad = np.nonzero(got != want)[0]
                 assert bad.size == 0, (kind, algorithm, bound, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+            # prepared tapes (resident, measured, UTF-8 decoded once): whole tapes and a random sub-view, same engine
+            pa, pb = sw.PreparedTape(scope, a, utf8=utf8), sw.PreparedTape(scope, b, utf8=utf8)
+            got = engine.pairs(pa, pb, scope, bound=bound)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, ("prepared", kind, algorithm, bound, bad[:5], got[bad[:5]], want[bad[:5]])
+            lo = int(rng.integers(0, len(a)))
+            hi = int(rng.integers(lo, len(a) + 1))
+            assert (engine.pairs(pa[lo:hi], pb[lo:hi], scope, bound=bound) == want[lo:hi]).all(), ("prepared sub-view", kind, algorithm, lo, hi)
+            if rounds % 3 == 0 and not utf8:   # the same batch split over a three-member scope on device 0
+                sharded_engine = sw.LevenshteinDistances(capabilities=multi)
+                batch = sw.ShardedPairs(multi, a, b)
+                got = sharded_engine.pairs_sharded(batch, multi, bound=bound)
+                assert (got == want).all(), ("sharded", bound)
+                batch.free()
+            if rounds % 5 == 0:   # a word-sized cross-product (k_cross_short) against the same oracle, pair by pair
+                words_q = [bytes(x) for x in (a[i][:int(rng.integers(0, 33))] for i in range(min(len(a), 40)))]
+                words_c = [bytes(x) for x in (b[i][:int(rng.integers(0, 33))] for i in range(min(len(b), 90)))]
+                if not utf8:
+                    q, c = sw.Strs(words_q), sw.Strs(words_c)
+                    flat = oracle.levenshtein_pairs(sw.Strs([x for x in words_q for _ in words_c]), sw.Strs(words_c * len(words_q)), algo="hyyro")
+                    byte_engine = sw.LevenshteinDistances(capabilities=scope)
+                    for tapes in ((q, c), (sw.PreparedTape(scope, q), sw.PreparedTape(scope, c))):
+                        assert (byte_engine(tapes[0], tapes[1], scope).reshape(-1) == flat).all(), "cross-product of words"
             if rounds % 4 == 0:   # the same batch through the pipelined lanes: device tapes, device outputs, 32-bit offsets
                 import torch
                 a32, b32 = a.with_offsets(np.uint32), b.with_offsets(np.uint32)

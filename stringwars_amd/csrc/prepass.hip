@@ -763,12 +763,19 @@ __global__ __launch_bounds__(256) void k_tape_longest(const Off *offsets, uint64
     }
     uint32_t v = best > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)best;
     v = wave_max_u32(v);
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(longest, v);
+    // one atomic per workgroup: thousands of waves hitting one word serialise (~88 per microsecond)
+    __shared__ uint32_t wave_best[4];
+    if ((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) v = wave_best[w] > v ? wave_best[w] : v;
+        if (v) atomicMax(longest, v);
+    }
 }
 void launch_tape_longest(Scope *scope, const void *offsets, uint32_t off64, uint64_t count, uint32_t *longest) {
     if (!count) return;
     uint64_t blocks64 = (count + 1023) / 1024;
-    const uint32_t blocks = (uint32_t)(blocks64 > (uint64_t)scope->compute_units * 8 ? (uint64_t)scope->compute_units * 8 : blocks64);
+    const uint32_t blocks = (uint32_t)(blocks64 > (uint64_t)scope->compute_units * 2 ? (uint64_t)scope->compute_units * 2 : blocks64);
     if (off64) hipLaunchKernelGGL(k_tape_longest<uint64_t>, dim3(blocks), dim3(256), 0, scope->stream, (const uint64_t *)offsets, count, longest);
     else hipLaunchKernelGGL(k_tape_longest<uint32_t>, dim3(blocks), dim3(256), 0, scope->stream, (const uint32_t *)offsets, count, longest);
     SWH_HIP_CHECK(hipGetLastError());

@@ -215,7 +215,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
 }
 
 // Which kernels a unit-cost Levenshtein call runs on.
-enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort, kRouteCrossShort };
+enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort, kRouteShortTiled, kRouteCrossShort };
 
 // Strings up to this many symbols (G <= 8 blocks) are scored by the tiled kernel when their lengths are known; beyond it
 // a tile holds too few pairs per block count and the global sort of the planned path packs the waves better.
@@ -223,9 +223,14 @@ static uint32_t tiled_longest_limit() {
     static const uint32_t limit = [] { const char *e = getenv("STRINGWARS_AMD_TILED_MAX"); return e ? (uint32_t)atoi(e) : 256u; }();
     return limit;
 }
-static bool direct_short_preferred() {   // STRINGWARS_AMD_SHORT=tiled sends word-sized batches to the tiled kernel instead
-    static const bool direct = [] { const char *e = getenv("STRINGWARS_AMD_SHORT"); return !(e && !strcmp(e, "tiled")); }();
-    return direct;
+// Word-sized batches: k_short_tiled (<= 16 bytes) / k_direct_short (<= 32). Comparison knob STRINGWARS_AMD_SHORT: `direct`
+// keeps k_direct_short for all of them, `tiled` sends them to the general tiled kernel.
+static int short_route_choice() {
+    static const int choice = [] {
+        const char *e = getenv("STRINGWARS_AMD_SHORT");
+        return !e ? 0 : (!strcmp(e, "direct") ? 1 : (!strcmp(e, "tiled") ? 2 : 0));
+    }();
+    return choice;
 }
 
 static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSpec &spec, const char **error) {
@@ -356,7 +361,9 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 const bool band_pays = spec.bound <= 63 && longest > 32;   // plan_key(): the banded kernel wins from ~6 blocks at k = 32
                 if (forced) route = (!guaranteed || shorter_side <= 2048) ? kRouteTiled : kRoutePlanned;
                 else if (!band_pays && longest <= tiled_longest_limit())
-                    route = (longest <= 32 && !utf8 && direct_short_preferred()) ? (spec.cross ? kRouteCrossShort : kRouteDirectShort) : kRouteTiled;
+                    route = (longest <= 32 && !utf8 && short_route_choice() != 2)
+                                ? (spec.cross ? kRouteCrossShort : (longest <= 16 && short_route_choice() == 0 ? kRouteShortTiled : kRouteDirectShort))
+                                : kRouteTiled;
             }
         }
 
@@ -486,6 +493,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             // ---- no pre-pass: one DP launch; its summary (work units, longest strings, "a pair did not fit") arrives in
             // host-mapped memory with the kernel's completion ------------------------------------------------------------
             if (route == kRouteDirectShort) launch_direct_short_alone(scope, pre);
+            else if (route == kRouteShortTiled) launch_short_tiled(scope, job, off64);
             else if (route == kRouteCrossShort) launch_cross_short(scope, job, off64);
             else launch_bitparallel_tiled(scope, k, pairs, longest);
             if (invalid_dev) SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));

@@ -399,6 +399,8 @@ TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text);
 void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text);
 // cross.hip: dense queries x candidates for word-sized strings, the query's match table shared by a wave
 void launch_cross_short(Scope *scope, const Job &job, uint32_t off64);
+// short.hip: pairwise batches of strings <= 16 bytes: chunks staged in LDS, affixes cut, sorted by what remains
+void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64);
 // prepass.hip: k_direct_short on its own (every pair known to be word-sized)
 void launch_direct_short_alone(Scope *scope, const PrepassArgs &args);
 // Longest string of a tape (in offsets units) -> *longest (device word, atomicMax; zero it first)

@@ -1,0 +1,537 @@
+// short.hip -- unit-cost Levenshtein for batches of WORD-SIZED byte strings (both sides <= 16 bytes), pairwise.
+//
+// BASELINE config C5 (100 M short-word pairs) and C1: a pair is ~43 DP cells, so everything around the cells decides the
+// rate. k_direct_short (prepass.hip) scores such pairs one per lane in tape order; a wave then walks to its LONGEST
+// pattern and text (15 rows and columns where the mean is 6), builds and clears a match table per pair, and fetches every
+// string with a scattered 16-byte load. Here a workgroup takes a CHUNK of <= 1024 consecutive pairs and
+//   A. copies the chunk's two tape segments -- consecutive pairs are consecutive bytes -- into LDS with coalesced 16-byte
+//      loads (the only global reads besides the offsets);
+//   B. per pair: cuts the common prefix and suffix (what rapidfuzz's Levenshtein does first, too; eight bytes of each are
+//      compared with two xor + find-first-bit), finishes the pairs with nothing left on one side, and counts the others
+//      by (text length, pattern length) of what remains;
+//   C-D. counting-sorts them in LDS (256 keys) as 8-byte descriptors;
+//   E. runs work items of 64 sorted pairs, heaviest first, one pair per lane: lanes of an item have (nearly) the same row
+//      and column counts, so the wave walks ~3 columns instead of ~15. Match tables are 16-bit (patterns <= 16 rows):
+//      lanes l and l + 32 share a dword -- they are never in the same LDS lane group -- 4 KB per wave;
+//   F. writes the chunk's distances in one coalesced sweep.
+// Strings longer than 16 bytes raise `violation` (the host redoes the call on another route), like tiled.hip.
+#include <cstdio>
+#include <cstdlib>
+
+#include "bp_window.hpp"
+
+namespace swh {
+
+constexpr int kShortThreads = 256, kShortWaves = 4, kShortPer = 4;
+constexpr int kShortChunk = kShortThreads * kShortPer;   // pairs per chunk
+constexpr int kShortMaxLen = 16;
+constexpr int kShortCap = 6912;      // bytes of one tape's segment a chunk may bring into LDS (432 units of 16; keeps the workgroup below 40 KB)
+constexpr int kShortPad = 16;        // before (tail windows reach back 8 bytes) and after (16-byte windows reach forward)
+constexpr int kShortKeys = 256;      // (text length - 1) * 16 + (pattern length - 1)
+
+struct __attribute__((aligned(4096))) ShortLds {
+    uint32_t tables[kShortWaves][1024];                 // per wave: Lo[16][32] | Hi[16][32]; 4 KB apart for NibbleTables16
+    uint8_t a[kShortPad + kShortCap + kShortPad];
+    uint8_t b[kShortPad + kShortCap + kShortPad];
+    union {
+        uint2 sorted[kShortChunk];                      // descriptors in key order
+        struct {                                        // after the last chunk: the workgroup's sums and the call summary
+            unsigned long long cells, syms;
+            uint32_t maxa, maxb, misfit;
+            SummaryLds summary;
+        } tail;
+    };
+    uint32_t hist[kShortKeys];                          // pairs per key, then exclusive starts
+    uint8_t staged[kShortChunk];                        // distances of the chunk (<= 16)
+    uint32_t total, ticket;
+};
+static_assert(sizeof(ShortLds) <= 40960, "four workgroups per compute unit");
+
+// NibbleTables (bp_window.hpp) for 16-row patterns: entry v of Lo sits at tbase + (v << 7), of Hi at tbase + 2048 + (v << 7),
+// tbase = the wave's table + 4 * (lane & 31); lanes >= 32 keep their bits in the upper half of the shared dword.
+struct NibbleTables16 {
+    uint32_t tbase, mask;
+    __device__ __forceinline__ void init(uint32_t *table, int lane) {
+        tbase = (uint32_t)(uintptr_t)(lds_u32 *)(table + (lane & 31));
+        if (tbase & 0x780u) __builtin_trap();   // the layout assumption above: fail loudly
+        mask = 0x780u;
+        asm volatile("" : "+v"(mask));
+    }
+    template <int U> __device__ __forceinline__ uint32_t lo_addr(uint32_t x) const {   // x holds the symbol in byte U
+        uint32_t s;
+        if constexpr (U == 0) s = x << 7;
+        else s = x >> (8 * U - 7);
+        return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask, (int)tbase, 0xEA);
+    }
+    template <int U> __device__ __forceinline__ uint32_t hi_addr(uint32_t x) const {
+        uint32_t s;
+        if constexpr (U == 0) s = x << 3;
+        else s = x >> (8 * U - 3);
+        return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask, (int)tbase, 0xEA);
+    }
+    template <int U> __device__ __forceinline__ uint32_t lookup(uint32_t x) const {
+        return *(const lds_u32 *)(uintptr_t)lo_addr<U>(x) & *(const lds_u32 *)(uintptr_t)(hi_addr<U>(x) + 2048);
+    }
+    template <int U> __device__ __forceinline__ void insert(uint32_t x, uint32_t bit) const {
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)lo_addr<U>(x), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(hi_addr<U>(x) + 2048), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+// one wave's DS instructions execute in issue order: the compiler just must not move them across each other
+__device__ __forceinline__ void short_lds_order() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+#ifdef SWH_SHORT_PROFILE
+// Diagnostic build only (make EXTRA=-DSWH_SHORT_PROFILE): wave cycles per phase of k_short_tiled, summed over waves.
+__device__ unsigned long long g_short_phase[10];
+extern "C" void swh_debug_short_phases(unsigned long long *out) {
+    unsigned long long zero[10] = {};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_short_phase), sizeof(zero));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_short_phase), zero, sizeof(zero));
+}
+#define SHORT_STAMP(slot) do { const unsigned long long now__ = __builtin_readcyclecounter(); phase_acc[slot] += now__ - phase_t; phase_t = now__; } while (0)
+#else
+#define SHORT_STAMP(slot) do {} while (0)
+#endif
+
+struct ShortArgs {
+    Job job;
+    uint32_t tile, tiles;   // pairs per workgroup visit (a multiple of 64, <= kShortChunk)
+    PlanPartial *partials;
+    uint32_t *done_counter;
+    CallSummary *summary;
+};
+
+// Wide LDS reads are fast only when naturally aligned (a misaligned ds_read_b64 / b128 is served lane by lane: 65 LDS
+// cycles against 7-11, tools/lds_ops.hip), so windows at string addresses are read as aligned dwords and realigned with
+// v_alignbyte (which takes the byte shift from the low two bits of the address itself).
+__device__ __forceinline__ unsigned long long lds_window8(const uint8_t *array, uint32_t at) {
+    const uint32_t *p = (const uint32_t *)(array + (at & ~3u));
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    return (unsigned long long)__builtin_amdgcn_alignbyte(d1, d0, at) | ((unsigned long long)__builtin_amdgcn_alignbyte(d2, d1, at) << 32);
+}
+
+// What a thread requests from global memory for one chunk: the offsets of its four pairs and its share of the two tape
+// segments. Requested for chunk i + 1 before the work items of chunk i run, consumed after them.
+template <typename Off> struct ShortRequest {
+    Off oa0[kShortPer], oa1[kShortPer], ob0[kShortPer], ob1[kShortPer];
+    uint4 va[2], vb[2];
+};
+struct ShortChunk {
+    bool any;
+    uint64_t base;        // first pair
+    uint32_t len;         // pairs
+    uint64_t a_lo, b_lo;  // where its segments start in the tapes
+    uint32_t bytes_a, bytes_b;
+};
+
+// kWide: both tapes hold at least 16 bytes, so every 16-byte unit of a segment can be requested with ONE unconditional load
+// whose address is clamped into the tape (a guard per load would put a memory wait behind each of them); the one unit that
+// straddles the end of a tape is repaired byte by byte afterwards. Tapes shorter than that go byte by byte altogether.
+template <typename Off, bool kWide>
+__device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Job &job = args.job;
+    const Off *off_a = (const Off *)job.a.offsets, *off_b = (const Off *)job.b.offsets;
+    const uint8_t *a_data = (const uint8_t *)job.a.data, *b_data = (const uint8_t *)job.b.data;
+    const uint64_t a_total = (uint64_t)off_a[job.a.count], b_total = (uint64_t)off_b[job.b.count];
+    NibbleTables16 nib;
+    nib.init(lds.tables[wave], lane);
+    const uint32_t half_shift = lane >= 32 ? 16u : 0u;
+    {   // tables start clean
+        uint4 *t = (uint4 *)lds.tables[wave];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+    }
+    uint32_t cells = 0, syms = 0, maxa = 0, maxb = 0, misfit = 0;
+    const uint32_t bound = job.bound;
+#ifdef SWH_SHORT_PROFILE
+    unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_t = __builtin_readcyclecounter(), items_done = 0;
+#endif
+
+    // ---- the workgroup's chunks, in order: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; a tile is one chunk when its
+    // segments fit the LDS arrays, else it is halved until they do ---------------------------------------------------------------
+    uint32_t tile = blockIdx.x, done = 0;   // where the next chunk starts
+    auto candidate = [&](uint64_t &base, uint32_t &len) -> bool {   // the rest of the current tile, without taking it
+        while (tile < args.tiles) {
+            const uint64_t tile_base = (uint64_t)tile * args.tile;
+            const uint32_t count = (uint32_t)(job.pairs - tile_base < args.tile ? job.pairs - tile_base : args.tile);
+            if (done < count) { base = tile_base + done; len = count - done; return true; }
+            tile += gridDim.x; done = 0;
+        }
+        return false;
+    };
+    // the four offsets that bound a candidate's segments, as ONE vector load (lanes 0..3): it is consumed much later, and a
+    // scalar load would be waited for at the next LDS wait (both count on lgkmcnt)
+    auto bounds_request = [&](bool any, uint64_t base, uint32_t len) -> Off {
+        const Off *src = ((lane & 2) ? off_b : off_a) + (any ? base + ((lane & 1) ? len : 0u) : 0);
+        return *src;
+    };
+    auto lane_value = [&](Off v, int l) -> uint64_t {
+        if constexpr (sizeof(Off) == 8)
+            return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l) << 32);
+        else
+            return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, l);
+    };
+    // takes the next chunk: `hint` holds the bounds of the candidate (base0, len0) if hinted
+    auto next_chunk = [&](bool hinted, uint64_t base0, uint32_t len0, Off hint) -> ShortChunk {
+        ShortChunk c{};
+        uint64_t base; uint32_t len;
+        while (candidate(base, len)) {
+            uint64_t a_lo, a_hi, b_lo, b_hi;
+            if (hinted && base == base0 && len == len0) {
+                a_lo = lane_value(hint, 0); a_hi = lane_value(hint, 1); b_lo = lane_value(hint, 2); b_hi = lane_value(hint, 3);
+            } else {
+                a_lo = (uint64_t)off_a[base]; a_hi = (uint64_t)off_a[base + len]; b_lo = (uint64_t)off_b[base]; b_hi = (uint64_t)off_b[base + len];
+            }
+            hinted = false;
+            bool fits;
+            for (;;) {
+                fits = a_hi - a_lo <= (uint64_t)kShortCap && b_hi - b_lo <= (uint64_t)kShortCap;
+                if (fits || len <= 64) break;
+                len = ((len >> 1) + 63u) & ~63u;
+                a_hi = (uint64_t)off_a[base + len]; b_hi = (uint64_t)off_b[base + len];
+            }
+            done += len;
+            if (fits) {
+                c.any = true; c.base = base; c.len = len; c.a_lo = a_lo; c.b_lo = b_lo;
+                c.bytes_a = (uint32_t)(a_hi - a_lo); c.bytes_b = (uint32_t)(b_hi - b_lo);
+                return c;
+            }
+            misfit = 1;   // 64 pairs beyond the capacity: some string is longer than 16 bytes
+        }
+        return c;
+    };
+    auto request = [&](const ShortChunk &c, ShortRequest<Off> &r) {
+        const Off *pa = off_a + c.base, *pb = off_b + c.base;   // uniform bases, 32-bit lane offsets
+#pragma unroll
+        for (int k = 0; k < kShortPer; ++k) {
+            uint32_t q = (uint32_t)k * kShortThreads + threadIdx.x;
+            q = q < c.len ? q : c.len - 1;
+            r.oa0[k] = pa[q]; r.oa1[k] = pa[q + 1];
+            r.ob0[k] = pb[q]; r.ob1[k] = pb[q + 1];
+        }
+        if constexpr (kWide) {
+            // unit u of a segment starts 16 u bytes into it; units that would reach past the tape are read from its last 16 bytes
+            // instead (and repaired below); units past the segment are harmless slack
+            const uint8_t *sa = a_data + c.a_lo, *sb = b_data + c.b_lo;
+            const int64_t room_a = (int64_t)(a_total - c.a_lo) - 16, room_b = (int64_t)(b_total - c.b_lo) - 16;
+            const int lim_a = (int)(room_a > 0x10000 ? 0x10000 : room_a), lim_b = (int)(room_b > 0x10000 ? 0x10000 : room_b);
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const int at = 16 * (u2 * kShortThreads + (int)threadIdx.x);
+                if (at < kShortCap) {   // (the arrays hold kShortCap / 16 units)
+                    __builtin_memcpy(&r.va[u2], sa + (at < lim_a ? at : lim_a), 16);
+                    __builtin_memcpy(&r.vb[u2], sb + (at < lim_b ? at : lim_b), 16);
+                }
+            }
+        }
+    };
+
+    uint64_t cand_base = 0; uint32_t cand_len = 0;
+    ShortChunk cur = next_chunk(false, 0, 0, (Off)0);
+    ShortRequest<Off> req;
+    if (cur.any) request(cur, req);
+    while (cur.any) {
+        const uint64_t base = cur.base;
+        const uint32_t len = cur.len;
+        // ---- A: the chunk's segments into LDS (requested while the previous chunk's work items ran) ---------------------------
+        const bool cand = candidate(cand_base, cand_len);
+        const Off cand_bounds = bounds_request(cand, cand_base, cand_len);
+        lds.hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0) lds.ticket = 0;
+        if constexpr (kWide) {
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {   // (units past the segment are harmless slack)
+                const uint32_t u = (uint32_t)u2 * kShortThreads + threadIdx.x;
+                if (16 * u < (uint32_t)kShortCap) {
+                    *(uint4 *)(lds.a + kShortPad + 16 * u) = req.va[u2];
+                    *(uint4 *)(lds.b + kShortPad + 16 * u) = req.vb[u2];
+                }
+            }
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const uint32_t at = 16u * ((uint32_t)u2 * kShortThreads + threadIdx.x);
+                if (__builtin_expect(at < cur.bytes_a && cur.a_lo + at + 16 > a_total, 0))
+                    for (uint64_t g = cur.a_lo + at; g < a_total; ++g) lds.a[kShortPad + (uint32_t)(g - cur.a_lo)] = a_data[g];
+                if (__builtin_expect(at < cur.bytes_b && cur.b_lo + at + 16 > b_total, 0))
+                    for (uint64_t g = cur.b_lo + at; g < b_total; ++g) lds.b[kShortPad + (uint32_t)(g - cur.b_lo)] = b_data[g];
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < cur.bytes_a; i += kShortThreads) lds.a[kShortPad + i] = a_data[cur.a_lo + i];
+            for (uint32_t i = threadIdx.x; i < cur.bytes_b; i += kShortThreads) lds.b[kShortPad + i] = b_data[cur.b_lo + i];
+        }
+        SHORT_STAMP(0);   // A: copy
+        __syncthreads();
+        SHORT_STAMP(1);   // barrier after A
+        // ---- B: cut the common affixes, finish what is trivial, count the rest by (text, pattern) length -------------
+        // (the LDS windows of two pairs are requested before the first one is used, no branch in between; all four at once
+        // hold 48 dwords in flight and spill)
+        uint32_t d0[kShortPer], d1[kShortPer], key[kShortPer], rank[kShortPer];
+#pragma unroll
+        for (int k0 = 0; k0 < kShortPer; k0 += 2) {
+            uint32_t ra0s[2], rb0s[2], las[2], lbs[2];
+            unsigned long long heads[2], tails[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + j;
+                const uint32_t ra0 = (uint32_t)(req.oa0[k] - (Off)cur.a_lo), ra1 = (uint32_t)(req.oa1[k] - (Off)cur.a_lo);
+                const uint32_t rb0 = (uint32_t)(req.ob0[k] - (Off)cur.b_lo), rb1 = (uint32_t)(req.ob1[k] - (Off)cur.b_lo);
+                const bool valid = (uint32_t)k * kShortThreads + threadIdx.x < len;
+                ra0s[j] = ra0; rb0s[j] = rb0;
+                las[j] = valid ? ra1 - ra0 : 0u;    // lanes past the chunk repeat its last pair: they count as two empty strings
+                lbs[j] = valid ? rb1 - rb0 : 0u;
+                heads[j] = lds_window8(lds.a + kShortPad, ra0) ^ lds_window8(lds.b + kShortPad, rb0);
+                tails[j] = lds_window8(lds.a + kShortPad - 8, ra1) ^ lds_window8(lds.b + kShortPad - 8, rb1);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + j;
+                const uint32_t q = (uint32_t)k * kShortThreads + threadIdx.x;
+                uint32_t la = las[j], lb = lbs[j];
+                cells += la * lb;
+                syms += la + lb;
+                maxa = la > maxa ? la : maxa;
+                maxb = lb > maxb ? lb : maxb;
+                const uint32_t longer = la > lb ? la : lb, mn = la < lb ? la : lb;
+                uint32_t pre = heads[j] ? (uint32_t)__builtin_ctzll(heads[j]) >> 3 : 8u;
+                pre = pre < mn ? pre : mn;
+                uint32_t suf = tails[j] ? (uint32_t)__builtin_clzll(tails[j]) >> 3 : 8u;
+                suf = suf < mn - pre ? suf : mn - pre;
+                const uint32_t cut = pre + suf;
+                const uint32_t m = longer - cut, n = mn - cut;
+                const uint32_t pa = (uint32_t)offsetof(ShortLds, a) + kShortPad + ra0s[j] + pre, pb = (uint32_t)offsetof(ShortLds, b) + kShortPad + rb0s[j] + pre;
+                const bool a_is_pattern = la >= lb;
+                const uint32_t pat = a_is_pattern ? pa : pb, txt = a_is_pattern ? pb : pa;
+                const bool cut_off = bound != 0xFFFFFFFFu && m - n > bound;
+                key[k] = 0xFFFFFFFFu; rank[k] = 0;
+                d0[k] = pat | (txt << 16);
+                d1[k] = m | (n << 8) | (q << 16);
+                if (q < len && longer <= (uint32_t)kShortMaxLen) {
+                    if (cut_off || n == 0) {
+                        lds.staged[q] = (uint8_t)(cut_off ? bound + 1 : clamp_bound(m, bound));
+                    } else {
+                        key[k] = (n - 1) * 16 + (m - 1);
+                        rank[k] = __hip_atomic_fetch_add(&lds.hist[key[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        SHORT_STAMP(2);   // B
+        __syncthreads();
+        // ---- C: exclusive scan of the 256 key counts (wave 0, four keys per lane) -------------------------------------
+        if (wave == 0) {
+            const uint4 c = ((const uint4 *)lds.hist)[lane];
+            const uint32_t sum = c.x + c.y + c.z + c.w;
+            const uint32_t incl = wave_inclusive_sum_u32(sum);
+            const uint32_t e0 = incl - sum;
+            ((uint4 *)lds.hist)[lane] = make_uint4(e0, e0 + c.x, e0 + c.x + c.y, e0 + c.x + c.y + c.z);
+            if (lane == 63) lds.total = incl;
+        }
+        __syncthreads();
+        // ---- D: descriptors into key order -----------------------------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < kShortPer; ++k)
+            if (key[k] != 0xFFFFFFFFu) lds.sorted[lds.hist[key[k]] + rank[k]] = make_uint2(d0[k], d1[k]);
+        __syncthreads();
+        SHORT_STAMP(3);   // C, D and their barriers
+        // ---- the next chunk's global reads go out now and come back while this chunk's work items run -----------------------
+        const ShortChunk nxt = next_chunk(cand, cand_base, cand_len, cand_bounds);
+        ShortRequest<Off> req_next;
+        if (nxt.any) request(nxt, req_next);
+        // ---- E: work items of 64 sorted pairs, heaviest (last) first, dealt by an LDS ticket ----------------------------
+        {
+            const uint32_t total = lds.total, items = (total + 63u) >> 6;
+            for (;;) {
+                uint32_t t = 0;
+                if (lane == 0) t = __hip_atomic_fetch_add(&lds.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t >= items) break;
+                const uint32_t item = items - 1 - t;
+                const uint32_t e = item * 64 + (uint32_t)lane;
+                const bool active = e < total;
+                uint2 d = lds.sorted[active ? e : item * 64];
+                if (!active) d = make_uint2(d.x, 0u);   // no rows, no columns
+                const uint32_t pat = d.x & 0xFFFFu, txt = d.x >> 16;
+                const uint32_t m = d.y & 0xFFu, n = (d.y >> 8) & 0xFFu, q = d.y >> 16;
+                const uint32_t last = total - item * 64 - 1 < 63u ? total - item * 64 - 1 : 63u;
+                const uint32_t n_max = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)last);   // sorted by text length first
+                const uint32_t m_max = wave_max_u32(m);
+                // the strings as aligned dwords, realigned in registers; bytes 8..15 only when some lane has that many
+                uint32_t pw[4], tw[4];
+                {
+                    const uint32_t *pp = (const uint32_t *)((const uint8_t *)&lds + (pat & ~3u)), *tp = (const uint32_t *)((const uint8_t *)&lds + (txt & ~3u));
+                    const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    pw[0] = __builtin_amdgcn_alignbyte(p1, p0, pat); pw[1] = __builtin_amdgcn_alignbyte(p2, p1, pat);
+                    tw[0] = __builtin_amdgcn_alignbyte(t1, t0, txt); tw[1] = __builtin_amdgcn_alignbyte(t2, t1, txt);
+                    pw[2] = pw[3] = tw[2] = tw[3] = 0;
+                    if (m_max > 8) {
+                        const uint32_t p3 = pp[3], p4 = pp[4];
+                        pw[2] = __builtin_amdgcn_alignbyte(p3, p2, pat); pw[3] = __builtin_amdgcn_alignbyte(p4, p3, pat);
+                    }
+                    if (n_max > 8) {
+                        const uint32_t t3 = tp[3], t4 = tp[4];
+                        tw[2] = __builtin_amdgcn_alignbyte(t3, t2, txt); tw[3] = __builtin_amdgcn_alignbyte(t4, t3, txt);
+                    }
+                }
+                const uint32_t rows = ((1u << m) - 1u) << half_shift;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    // rows past a lane's pattern OR in a zero: no branch per lane, one scalar test per row
+                    if ((uint32_t)w * 4 + 0 >= m_max) break;
+                    nib.template insert<0>(pw[w], rows & (0x00010001u << (w * 4 + 0)));
+                    if ((uint32_t)w * 4 + 1 >= m_max) break;
+                    nib.template insert<1>(pw[w], rows & (0x00010001u << (w * 4 + 1)));
+                    if ((uint32_t)w * 4 + 2 >= m_max) break;
+                    nib.template insert<2>(pw[w], rows & (0x00010001u << (w * 4 + 2)));
+                    if ((uint32_t)w * 4 + 3 >= m_max) break;
+                    nib.template insert<3>(pw[w], rows & (0x00010001u << (w * 4 + 3)));
+                }
+                short_lds_order();
+                // the recurrence runs in the low 16 bits of every lane (the looked-up word is shifted down); what a lane
+                // < 32 sees above bit 15 are its partner's rows, and nothing ever moves down across bit 16
+                uint32_t pv = 0xFFFFFFFFu, mv = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if ((uint32_t)w * 4 >= n_max) break;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if ((uint32_t)(w * 4 + u) >= n_max) break;
+                        if ((uint32_t)(w * 4 + u) < n) {
+                            const uint32_t x = tw[w];
+                            const uint32_t both = u == 0 ? nib.template lookup<0>(x) : (u == 1 ? nib.template lookup<1>(x) : (u == 2 ? nib.template lookup<2>(x) : nib.template lookup<3>(x)));
+                            const uint32_t eq = both >> half_shift;
+                            const uint32_t xv = eq | mv;
+                            const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                            uint32_t ph = mv | ~(xh | pv);
+                            const uint32_t mh = pv & xh;
+                            ph = (ph << 1) | 1u;
+                            pv = (mh << 1) | ~(xv | ph);
+                            mv = ph & xv;
+                        }
+                    }
+                }
+                if (active) {
+                    const uint32_t mask = (1u << m) - 1u;
+                    const uint32_t dist = n + __popc(pv & mask) - __popc(mv & mask);
+                    lds.staged[q] = (uint8_t)clamp_bound(dist, bound);
+                }
+                short_lds_order();
+                {
+                    uint4 *tb = (uint4 *)lds.tables[wave];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) tb[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+                }
+                short_lds_order();
+#ifdef SWH_SHORT_PROFILE
+                ++items_done;
+#endif
+            }
+        }
+        SHORT_STAMP(4);   // E
+        __syncthreads();
+        SHORT_STAMP(5);   // waiting for the other waves' items
+        // ---- F: the chunk's distances, one coalesced sweep ------------------------------------------------------------------
+        if (job.out_stride == 4 && !job.out_elem64) {
+            uint32_t *dst = (uint32_t *)job.out + base;
+#pragma unroll
+            for (int k = 0; k < kShortPer; ++k) {
+                const uint32_t q = (uint32_t)k * kShortThreads + threadIdx.x;
+                if (q < len) dst[q] = lds.staged[q];
+            }
+        } else {
+            char *chunk_out = job.out + base * job.out_stride;
+#pragma unroll
+            for (int k = 0; k < kShortPer; ++k) {
+                const uint32_t q = (uint32_t)k * kShortThreads + threadIdx.x;
+                if (q < len) {
+                    char *dst = chunk_out + (uint64_t)q * job.out_stride;
+                    const uint32_t v = lds.staged[q];
+                    if (job.out_elem64) *(int64_t *)dst = (int64_t)v;
+                    else *(uint32_t *)dst = v;
+                }
+            }
+        }
+        SHORT_STAMP(6);   // F
+        // no barrier here: the next chunk rewrites `staged` in its step B, behind its first barrier, and what its step A
+        // rewrites (segments, counters, ticket) nobody reads after step E
+        cur = nxt;
+        req = req_next;
+    }
+#ifdef SWH_SHORT_PROFILE
+    if (lane == 0) {
+        for (int q = 0; q < 7; ++q) atomicAdd(&g_short_phase[q], phase_acc[q]);
+        atomicAdd(&g_short_phase[7], 1ull);
+        atomicAdd(&g_short_phase[8], items_done);
+    }
+#endif
+    // ---- the workgroup's work units -> the call summary (common.hpp) -------------------------------------------------------------
+    if (threadIdx.x == 0) { lds.tail.cells = 0; lds.tail.syms = 0; lds.tail.maxa = 0; lds.tail.maxb = 0; lds.tail.misfit = 0; }
+    __syncthreads();
+    unsigned long long wcells = cells, wsyms = syms;
+    misfit |= (maxa > (uint32_t)kShortMaxLen || maxb > (uint32_t)kShortMaxLen) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        wcells += __shfl_xor(wcells, off);
+        wsyms += __shfl_xor(wsyms, off);
+        misfit |= __shfl_xor(misfit, off);
+        const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+        maxa = oa > maxa ? oa : maxa;
+        maxb = ob > maxb ? ob : maxb;
+    }
+    if (lane == 0) {
+        atomicAdd(&lds.tail.cells, wcells);
+        atomicAdd(&lds.tail.syms, wsyms);
+        atomicMax(&lds.tail.maxa, maxa);
+        atomicMax(&lds.tail.maxb, maxb);
+        atomicOr(&lds.tail.misfit, misfit);
+    }
+    __syncthreads();
+    // every pair this kernel accepts is "short" (both sides <= 32): the count is the number of pairs this workgroup visited
+    uint32_t visited = 0;
+    for (uint32_t t = blockIdx.x; t < args.tiles; t += gridDim.x) {
+        const uint64_t tile_base = (uint64_t)t * args.tile;
+        visited += (uint32_t)(job.pairs - tile_base < args.tile ? job.pairs - tile_base : args.tile);
+    }
+    report_call_summary(PlanPartial{lds.tail.cells, lds.tail.syms, lds.tail.maxa, lds.tail.maxb, visited, lds.tail.misfit}, args.partials, args.done_counter,
+                        args.summary, lds.tail.summary);
+}
+
+template <typename Off>
+__global__ __launch_bounds__(kShortThreads, 4) void k_short_tiled(ShortArgs args) {
+    __shared__ ShortLds lds;
+    const Off *off_a = (const Off *)args.job.a.offsets, *off_b = (const Off *)args.job.b.offsets;
+    if ((uint64_t)off_a[args.job.a.count] >= 16 && (uint64_t)off_b[args.job.b.count] >= 16) short_run<Off, true>(args, lds);
+    else short_run<Off, false>(args, lds);
+}
+
+void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64) {
+    int per_cu = 4;
+    uint32_t slots = (uint32_t)scope->compute_units * (uint32_t)per_cu;
+    if (slots > (uint32_t)kMaxPartials) slots = kMaxPartials;
+    // every workgroup slot gets the same number of tiles; small batches use fewer workgroups, not tiles below 256 pairs
+    const uint64_t rounds = (job.pairs + (uint64_t)slots * kShortChunk - 1) / ((uint64_t)slots * kShortChunk);
+    uint64_t tile = (job.pairs + slots * rounds - 1) / (slots * rounds);
+    tile = (tile + 63) & ~(uint64_t)63;
+    if (tile < 256) tile = 256;
+    if (tile > (uint64_t)kShortChunk) tile = kShortChunk;
+    ShortArgs args{};
+    args.job = job;
+    args.tile = (uint32_t)tile;
+    args.tiles = (uint32_t)((job.pairs + tile - 1) / tile);
+    args.partials = scope->plan_partials;
+    args.done_counter = scope->done_counter;
+    args.summary = scope->summary_dev;
+    const uint32_t blocks = args.tiles < slots ? args.tiles : slots;
+    StampGuard guard(scope, "short_tiled");
+    if (off64) hipLaunchKernelGGL(k_short_tiled<uint64_t>, dim3(blocks), dim3(kShortThreads), 0, scope->stream, args);
+    else hipLaunchKernelGGL(k_short_tiled<uint32_t>, dim3(blocks), dim3(kShortThreads), 0, scope->stream, args);
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace swh

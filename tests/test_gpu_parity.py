@@ -728,6 +728,110 @@ def test_tiled_kernel_every_block_count(sw, orc, scope):
     assert (chars.pairs(ua, ub, scope) == orc.levenshtein_pairs(ua, ub, utf8=True)).all()
 
 
+def test_pairs_with_common_affixes(sw, orc, scope):
+    """Kernels may cut what a pair shares at both ends before the DP (k_short_tiled does, up to 8 bytes each): distances
+    must not notice. Pairs built around every interesting shape -- shared prefix / suffix of 0..70 symbols, identical
+    strings, one string a prefix / suffix / infix of the other, repeats that let prefix and suffix compete for the same
+    symbols -- as bytes and as code points, bounded and not, raw and prepared."""
+    rng = np.random.default_rng(47)
+    def word(n, alphabet="ab"):
+        return "".join(rng.choice(list(alphabet), n))
+    items_a, items_b = [], []
+    for pre in (0, 1, 3, 4, 5, 7, 8, 15, 16, 17, 47, 48, 49, 70):
+        for suf in (0, 1, 3, 4, 5, 8, 16, 47, 48, 49, 70):
+            head, tail = word(pre, "abcd"), word(suf, "abcd")
+            items_a.append(head + word(int(rng.integers(0, 20))) + tail)
+            items_b.append(head + word(int(rng.integers(0, 20))) + tail)
+    for n in (1, 2, 5, 31, 32, 33, 64, 100):
+        s = word(n, "abc")
+        items_a += [s, s, s + "x", "x" + s, s, s * 2, "a" * n, "a" * n, "ab" * n]
+        items_b += [s, s + word(7), s, s, s[: n // 2], s, "a" * (n + 3), "a" * max(n - 1, 0), "ba" * n]
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    engine = sw.LevenshteinDistances(capabilities=scope, algorithm="tiled")
+    for tapes in ((a, b), (b, a), (sw.PreparedTape(scope, a), sw.PreparedTape(scope, b))):
+        assert (engine.pairs(tapes[0], tapes[1], scope) == want).all()
+        for bound in (0, 2, 9):
+            assert (engine.pairs(tapes[0], tapes[1], scope, bound=bound) == np.minimum(want, bound + 1)).all()
+    accents = str.maketrans({"a": "\u00e9", "b": "\u4e2d", "c": "\U0001f600", "d": "z"})
+    ua, ub = sw.Strs([s.translate(accents) for s in items_a]), sw.Strs([s.translate(accents) for s in items_b])
+    chars = sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm="tiled")
+    assert (chars.pairs(ua, ub, scope) == want).all()
+    assert (chars.pairs(sw.PreparedTape(scope, ua, utf8=True), sw.PreparedTape(scope, ub, utf8=True), scope, bound=4) == np.minimum(want, 5)).all()
+    grid = engine(a.subview(0, 40), b.subview(100, 150), scope)             # cross-product: an affix per (query, candidate)
+    flat = orc.levenshtein_pairs(sw.Strs([items_a[i] for i in range(40) for _ in range(50)]), sw.Strs(items_b[100:150] * 40), algo="hyyro")
+    assert (grid.reshape(-1) == flat).all()
+
+
+def test_word_sized_batches_on_the_chunked_kernel(sw, orc, scope):
+    """k_short_tiled (strings <= 16 bytes, pairwise): chunks of the tapes staged in LDS, common affixes cut, pairs sorted by
+    what remains. Every shape that steers it: affixes of every length around every residue, the 8-byte compare window,
+    empty strings, 16-byte strings back to back (segments beyond the LDS capacity: the chunk is halved), chunk and tile
+    edges, both offset widths, strided outputs, bounds, sub-views that start in the middle of a tape, and a
+    batch that stops being word-sized (the kernel reports it, the call is redone on another route)."""
+    rng = np.random.default_rng(53)
+    letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
+    def word(n, k=26):
+        return letters[rng.integers(0, k, n)].tobytes()
+    items_a, items_b = [], []
+    for pre in range(0, 12):
+        for suf in range(0, 12):
+            for ra, rb in ((0, 0), (1, 0), (0, 2), (1, 1), (2, 3), (4, 4), (3, 1)):
+                if pre + suf + max(ra, rb) > 16:
+                    continue
+                head, tail = word(pre, 3), word(suf, 3)
+                items_a.append(head + word(ra, 2) + tail)
+                items_b.append(head + word(rb, 2) + tail)
+    for _ in range(3000):                       # unrelated words, every length 0..16, tiny alphabets (accidental affixes)
+        items_a.append(word(int(rng.integers(0, 17)), int(rng.choice([1, 2, 26]))))
+        items_b.append(word(int(rng.integers(0, 17)), int(rng.choice([1, 2, 26]))))
+    items_a += [b"", b"", b"a", b"abcdefghijklmnop", b"abcdefghijklmnop", b"abcdefghijklmnop", b"aaaaaaaaaaaaaaaa"]
+    items_b += [b"", b"abc", b"", b"abcdefghijklmnop", b"bcdefghijklmnopq", b"", b"aaaaaaaaaaaaaaa"]
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    for offsets in (np.uint64, np.uint32):
+        pa, pb = sw.PreparedTape(scope, a.with_offsets(offsets)), sw.PreparedTape(scope, b.with_offsets(offsets))
+        assert pa.info["longest"] <= 16
+        assert (engine.pairs(pa, pb, scope) == want).all()
+        assert (engine.pairs(pb, pa, scope) == want).all()
+        for bound in (0, 1, 3, 15, 16, 40):
+            assert (engine.pairs(pa, pb, scope, bound=bound) == np.minimum(want, bound + 1)).all()
+        for lo, hi in ((1, 2), (7, 1031), (1000, 1001 + 1024), (len(items_a) - 3, len(items_a))):
+            assert (engine.pairs(pa[lo:hi], pb[lo:hi], scope) == want[lo:hi]).all()
+    strided = np.full((len(items_a), 3), 0xDEADBEEF, dtype=np.uint32)
+    engine.pairs(pa, pb, scope, out=strided[:, 1])
+    assert (strided[:, 1] == want).all() and (strided[:, 0] == 0xDEADBEEF).all() and (strided[:, 2] == 0xDEADBEEF).all()
+    # raw tapes: the scope learns the lengths from its first call, the second call takes the chunked kernel
+    fresh = sw.DeviceScope(gpu_device=0)
+    da, db = a.to_device(fresh), b.to_device(fresh)
+    for _ in range(2):
+        assert (engine.pairs(da, db, fresh) == want).all()
+    # 16-byte strings only: 1024 pairs are 16 KB per tape, twice what a chunk may hold
+    full_a, full_b = sw.Strs([word(16, 4) for _ in range(5000)]), sw.Strs([word(16, 4) for _ in range(5000)])
+    fa, fb = sw.PreparedTape(scope, full_a), sw.PreparedTape(scope, full_b)
+    assert (engine.pairs(fa, fb, scope) == orc.levenshtein_pairs(full_a, full_b, algo="hyyro")).all()
+    # tapes shorter than one 16-byte load
+    ta, tb = sw.Strs([b"ab", b"", b"xyz"]), sw.Strs([b"b", b"q", b"xyz"])
+    assert engine.pairs(sw.PreparedTape(scope, ta), sw.PreparedTape(scope, tb), scope).tolist() == [1, 1, 0]
+    # the belief breaks: words, then a batch with a 40-byte string in the middle of the words
+    for _ in range(2):
+        assert (engine.pairs(da, db, fresh) == want).all()
+    longer_a = sw.Strs(items_a[:700] + [word(40, 5)] + items_a[700:1500])
+    longer_b = sw.Strs(items_b[:700] + [word(33, 5)] + items_b[700:1500])
+    assert (engine.pairs(longer_a.to_device(fresh), longer_b.to_device(fresh), fresh) == orc.levenshtein_pairs(longer_a, longer_b, algo="hyyro")).all()
+    # full-size shapes: every pair of two workloads against the oracle
+    for workload, count in (("short_words", 300_000), ("words16", 100_000)):
+        wa, wb = sw.generate_pairs(workload, count, seed=11)
+        wpa, wpb = sw.PreparedTape(scope, wa.with_offsets(np.uint32)), sw.PreparedTape(scope, wb.with_offsets(np.uint32))
+        full = orc.levenshtein_pairs(wa, wb, algo="hyyro")
+        assert (engine.pairs(wpa, wpb, scope) == full).all()
+        assert (engine.pairs(wpa, wpb, scope, bound=2) == np.minimum(full, 3)).all()
+        timing = scope.last_timing() if hasattr(scope, "last_timing") else None
+        if timing and timing.get("cells"):
+            assert timing["cells"] == int((wa.lengths.astype(np.int64) * wb.lengths.astype(np.int64)).sum())
+
+
 def test_plan_free_route_falls_back_when_lengths_grow(sw, orc):
     """Raw tapes: the scope believes the next batch looks like the last one and skips the pre-pass; the kernels verify
     the belief per pair, and a batch that breaks it (both strings beyond 2048 symbols, or words turned into lines) is

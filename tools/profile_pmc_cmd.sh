@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift; local counters=("$@"); timeout 900 rocprofv3 --pmc "${counters[@]}" --kernel-trace --output-format csv -d "$OUT" -o "$name" -- python3 $CMD > "$OUT/$name.log" 2>&1; }
 CMD="$*"
 run pmc_sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY
-run pmc_sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+run pmc_sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 python3 - "$OUT" <<'PY'
 import csv,glob,collections,sys,json
 out={}

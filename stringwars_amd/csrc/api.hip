@@ -105,6 +105,7 @@ static void harvest_timing(Scope *scope, bool complete) {
         if (!sm.violation) {
             scope->hint_lengths = true;
             scope->hint_max_la = sm.max_la; scope->hint_max_lb = sm.max_lb;
+            scope->hint_mean_x16 = scope->summary_pairs ? (uint32_t)std::min<uint64_t>(sm.symbols * 8 / scope->summary_pairs, 0xFFFFFFu) : 0u;
             scope->hint_short = (uint64_t)sm.short_pairs * 4 >= scope->summary_pairs;
         }
     }
@@ -223,8 +224,14 @@ static uint32_t tiled_longest_limit() {
     static const uint32_t limit = [] { const char *e = getenv("STRINGWARS_AMD_TILED_MAX"); return e ? (uint32_t)atoi(e) : 256u; }();
     return limit;
 }
-// Word-sized batches: k_short_tiled (<= 16 bytes) / k_direct_short (<= 32). Comparison knob STRINGWARS_AMD_SHORT: `direct`
+// Word-sized batches: k_short_tiled (<= 16 bytes, batches large enough to give every workgroup a chunk worth sorting) /
+// k_direct_short (<= 32 bytes, small batches). Comparison knob STRINGWARS_AMD_SHORT: `direct`
 // keeps k_direct_short for all of them, `tiled` sends them to the general tiled kernel.
+// (STRINGWARS_AMD_SHORT_MIN_PAIRS, read per call: the tests send small batches to the chunked kernel with it)
+static uint64_t short_tiled_min_pairs() {
+    const char *e = getenv("STRINGWARS_AMD_SHORT_MIN_PAIRS");
+    return e ? (uint64_t)atoll(e) : (uint64_t)1 << 16;
+}
 static int short_route_choice() {
     static const int choice = [] {
         const char *e = getenv("STRINGWARS_AMD_SHORT");
@@ -362,7 +369,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 if (forced) route = (!guaranteed || shorter_side <= 2048) ? kRouteTiled : kRoutePlanned;
                 else if (!band_pays && longest <= tiled_longest_limit())
                     route = (longest <= 32 && !utf8 && short_route_choice() != 2)
-                                ? (spec.cross ? kRouteCrossShort : (longest <= 16 && short_route_choice() == 0 ? kRouteShortTiled : kRouteDirectShort))
+                                ? (spec.cross ? kRouteCrossShort : (longest <= 16 && pairs >= short_tiled_min_pairs() && short_route_choice() == 0 ? kRouteShortTiled : kRouteDirectShort))
                                 : kRouteTiled;
             }
         }
@@ -493,7 +500,16 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             // ---- no pre-pass: one DP launch; its summary (work units, longest strings, "a pair did not fit") arrives in
             // host-mapped memory with the kernel's completion ------------------------------------------------------------
             if (route == kRouteDirectShort) launch_direct_short_alone(scope, pre);
-            else if (route == kRouteShortTiled) launch_short_tiled(scope, job, off64);
+            else if (route == kRouteShortTiled) {
+                // mean string length, for the chunk size: exact for prepared tapes (their totals), else what the last call saw
+                uint32_t mean_x16 = scope->hint_mean_x16;
+                if (prepared) {
+                    const uint64_t ma = spec.pa->bytes.count ? spec.pa->total_bytes * 16 / spec.pa->bytes.count : 0;
+                    const uint64_t mb = spec.pb->bytes.count ? spec.pb->total_bytes * 16 / spec.pb->bytes.count : 0;
+                    mean_x16 = (uint32_t)std::min<uint64_t>(std::max(ma, mb), 0xFFFFFFu);
+                }
+                launch_short_tiled(scope, job, off64, mean_x16);
+            }
             else if (route == kRouteCrossShort) launch_cross_short(scope, job, off64);
             else launch_bitparallel_tiled(scope, k, pairs, longest);
             if (invalid_dev) SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));

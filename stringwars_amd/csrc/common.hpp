@@ -308,6 +308,7 @@ struct Scope {
     // without a planning pre-pass; the kernels verify it per pair and raise CallSummary::violation if it no longer holds.
     bool hint_lengths = false;
     uint32_t hint_max_la = 0, hint_max_lb = 0;
+    uint32_t hint_mean_x16 = 0;   // mean string length of the previous call, x16 (both tapes together)
     CallSummary *summary_host = nullptr;   // pinned, mapped: written by kernels, read by the host after a synchronisation
     CallSummary *summary_dev = nullptr;    // the same memory as the device sees it
     uint32_t *done_counter = nullptr;      // device: workgroups finished (self-resetting), for "last one reports"
@@ -400,7 +401,8 @@ void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pai
 // cross.hip: dense queries x candidates for word-sized strings, the query's match table shared by a wave
 void launch_cross_short(Scope *scope, const Job &job, uint32_t off64);
 // short.hip: pairwise batches of strings <= 16 bytes: chunks staged in LDS, affixes cut, sorted by what remains
-void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64);
+// `mean_bytes`: mean string length of the longer tape, x16 (0: unknown); sizes the chunks so that their segments fit the LDS arrays
+void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64, uint32_t mean_bytes_x16);
 // prepass.hip: k_direct_short on its own (every pair known to be word-sized)
 void launch_direct_short_alone(Scope *scope, const PrepassArgs &args);
 // Longest string of a tape (in offsets units) -> *longest (device word, atomicMax; zero it first)

@@ -510,16 +510,25 @@ __global__ __launch_bounds__(kShortThreads, 4) void k_short_tiled(ShortArgs args
     else short_run<Off, false>(args, lds);
 }
 
-void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64) {
+void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64, uint32_t mean_bytes_x16) {
     int per_cu = 4;
     uint32_t slots = (uint32_t)scope->compute_units * (uint32_t)per_cu;
     if (slots > (uint32_t)kMaxPartials) slots = kMaxPartials;
+    // A chunk's segments must fit the LDS arrays: with strings of `mean` bytes a chunk holds kShortCap / mean pairs, less a
+    // margin (a chunk that does not fit is halved by the kernel: correct, but the sort then works on half as many pairs).
+    uint64_t chunk = kShortChunk;
+    if (mean_bytes_x16) {
+        const uint64_t fit = (uint64_t)kShortCap * 16 * 15 / 16 / mean_bytes_x16;
+        if (fit < chunk) chunk = fit;
+    }
+    chunk &= ~(uint64_t)63;
+    if (chunk < 256) chunk = 256;
     // every workgroup slot gets the same number of tiles; small batches use fewer workgroups, not tiles below 256 pairs
-    const uint64_t rounds = (job.pairs + (uint64_t)slots * kShortChunk - 1) / ((uint64_t)slots * kShortChunk);
+    const uint64_t rounds = (job.pairs + (uint64_t)slots * chunk - 1) / ((uint64_t)slots * chunk);
     uint64_t tile = (job.pairs + slots * rounds - 1) / (slots * rounds);
     tile = (tile + 63) & ~(uint64_t)63;
     if (tile < 256) tile = 256;
-    if (tile > (uint64_t)kShortChunk) tile = kShortChunk;
+    if (tile > chunk) tile = chunk;
     ShortArgs args{};
     args.job = job;
     args.tile = (uint32_t)tile;

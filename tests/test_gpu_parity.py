@@ -763,12 +763,13 @@ def test_pairs_with_common_affixes(sw, orc, scope):
     assert (grid.reshape(-1) == flat).all()
 
 
-def test_word_sized_batches_on_the_chunked_kernel(sw, orc, scope):
+def test_word_sized_batches_on_the_chunked_kernel(sw, orc, scope, monkeypatch):
     """k_short_tiled (strings <= 16 bytes, pairwise): chunks of the tapes staged in LDS, common affixes cut, pairs sorted by
     what remains. Every shape that steers it: affixes of every length around every residue, the 8-byte compare window,
     empty strings, 16-byte strings back to back (segments beyond the LDS capacity: the chunk is halved), chunk and tile
     edges, both offset widths, strided outputs, bounds, sub-views that start in the middle of a tape, and a
     batch that stops being word-sized (the kernel reports it, the call is redone on another route)."""
+    monkeypatch.setenv("STRINGWARS_AMD_SHORT_MIN_PAIRS", "1")     # batches below 64 K pairs take k_direct_short otherwise
     rng = np.random.default_rng(53)
     letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
     def word(n, k=26):
@@ -825,11 +826,12 @@ def test_word_sized_batches_on_the_chunked_kernel(sw, orc, scope):
         wa, wb = sw.generate_pairs(workload, count, seed=11)
         wpa, wpb = sw.PreparedTape(scope, wa.with_offsets(np.uint32)), sw.PreparedTape(scope, wb.with_offsets(np.uint32))
         full = orc.levenshtein_pairs(wa, wb, algo="hyyro")
+        scope.set_profiling(True)
         assert (engine.pairs(wpa, wpb, scope) == full).all()
+        timing = scope.last_timing()
+        scope.set_profiling(False)
+        assert timing["dominant_name"] == "short_tiled" and timing["cells"] == int((wa.lengths.astype(np.int64) * wb.lengths.astype(np.int64)).sum())
         assert (engine.pairs(wpa, wpb, scope, bound=2) == np.minimum(full, 3)).all()
-        timing = scope.last_timing() if hasattr(scope, "last_timing") else None
-        if timing and timing.get("cells"):
-            assert timing["cells"] == int((wa.lengths.astype(np.int64) * wb.lengths.astype(np.int64)).sum())
 
 
 def test_plan_free_route_falls_back_when_lengths_grow(sw, orc):

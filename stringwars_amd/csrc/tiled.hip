@@ -24,7 +24,8 @@
 
 namespace swh {
 
-constexpr int kTileMax = 1024;     // pairs per tile: u16 indices, and tiles must outnumber the workgroups
+constexpr int kTileMax = 1024;     // pairs per tile: 10 bits of the u16 index list (the other six: common prefix / suffix)
+constexpr uint32_t kAffixCap = 7;  // symbols cut off at either end (three bits each)
 constexpr int kTileBuckets = 32;   // text-length buckets per class
 constexpr int kTileClasses = 64;
 constexpr int kTileBins = kTileClasses * kTileBuckets;
@@ -69,6 +70,7 @@ struct TiledArgs {
     uint32_t tile;          // pairs per tile
     uint32_t tiles;
     uint32_t shift;         // text-length bucket = min(n >> shift, kTileBuckets - 1)
+    uint32_t cut_affixes;   // byte strings: cut what a pair shares at both ends before classifying it
     PlanPartial *partials;  // per-workgroup work-unit sums (cells, symbols, maxima, "met a pair that does not fit")
     uint32_t *done_counter;
     CallSummary *summary;   // host-mapped: the last workgroup reports (common.hpp: report_call_summary)
@@ -99,23 +101,66 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         if (threadIdx.x == 0) tl.ticket = 0;
         __syncthreads();
         // ---- B: classify my pairs ---------------------------------------------------------------------------------
-        uint32_t cls[kPer], txt[kPer], rank[kPer];
+        // Every load a thread needs here is requested in two batches (indices clamped into the batch, no branch between the
+        // loads): the extents of its pairs, then -- byte strings -- the first and last eight bytes of both strings of every
+        // pair. What a pair shares at both ends is cut off before it is classified (the first thing rapidfuzz's Levenshtein
+        // does, too): up to kAffixCap symbols each, which is what fits the spare bits of the tile's index list.
+        uint32_t cls[kPer], txt[kPer], rank[kPer], affix[kPer];
+        uint64_t a0s[kPer], b0s[kPer];
+        uint32_t las[kPer], lbs[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint64_t p = base + (uint32_t)k * kThreads + threadIdx.x;
+            const uint64_t pc = p < args.job.pairs ? p : args.job.pairs - 1;
+            if (args.off64) pair_extent<uint64_t>(args.job, pc, a0s[k], las[k], b0s[k], lbs[k]);
+            else pair_extent<uint32_t>(args.job, pc, a0s[k], las[k], b0s[k], lbs[k]);
+            affix[k] = 0;
+        }
+        if constexpr (sizeof(Sym) == 1 && kWide) {
+            if (targs.cut_affixes) {
+                unsigned long long heads[kPer], tails[kPer];
+                bool inside[kPer];
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) {
+                    // windows that would leave the tapes (the first / last strings) are read at the tapes' start and not used
+                    const uint64_t ea = a0s[k] + las[k], eb = b0s[k] + lbs[k];
+                    inside[k] = a0s[k] + 8 <= a_total && b0s[k] + 8 <= b_total && ea >= 8 && eb >= 8;
+                    const uint8_t *ah = (const uint8_t *)args.job.a.data + (inside[k] ? a0s[k] : 0), *bh = (const uint8_t *)args.job.b.data + (inside[k] ? b0s[k] : 0);
+                    const uint8_t *at = (const uint8_t *)args.job.a.data + (inside[k] ? ea - 8 : 0), *bt = (const uint8_t *)args.job.b.data + (inside[k] ? eb - 8 : 0);
+                    unsigned long long x, y;
+                    __builtin_memcpy(&x, ah, 8); __builtin_memcpy(&y, bh, 8);
+                    heads[k] = x ^ y;
+                    __builtin_memcpy(&x, at, 8); __builtin_memcpy(&y, bt, 8);
+                    tails[k] = x ^ y;
+                }
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) {
+                    const uint32_t mn = las[k] < lbs[k] ? las[k] : lbs[k];
+                    uint32_t pre = heads[k] ? (uint32_t)__builtin_ctzll(heads[k]) >> 3 : 8u;
+                    pre = pre < kAffixCap ? pre : kAffixCap;
+                    pre = pre < mn ? pre : mn;
+                    uint32_t suf = tails[k] ? (uint32_t)__builtin_clzll(tails[k]) >> 3 : 8u;
+                    suf = suf < kAffixCap ? suf : kAffixCap;
+                    suf = suf < mn - pre ? suf : mn - pre;
+                    affix[k] = inside[k] ? pre | (suf << 3) : 0u;
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const uint32_t idx = (uint32_t)k * kThreads + threadIdx.x;
             cls[k] = 0xFFu; txt[k] = 0; rank[k] = 0;
             if (idx < count) {
                 const uint64_t p = base + idx;
-                uint64_t a0, b0;
-                uint32_t la, lb;
-                if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
-                else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
+                uint32_t la = las[k], lb = lbs[k];
                 cells += (unsigned long long)la * lb;
                 syms += (unsigned long long)la + lb;
                 maxa = la > maxa ? la : maxa;
                 maxb = lb > maxb ? lb : maxb;
                 shorts += (la <= 32 && lb <= 32) ? 1u : 0u;
                 const uint32_t diff = la > lb ? la - lb : lb - la;
+                const uint32_t shared = (affix[k] & 7u) + (affix[k] >> 3);
+                la -= shared; lb -= shared;
                 if (la == 0 || lb == 0) {
                     store_result(args.job, p, (int64_t)clamp_bound(la + lb, args.job.bound));
                 } else if (args.job.bound != 0xFFFFFFFFu && diff > args.job.bound) {
@@ -216,7 +261,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
             if (key[k] != 0xFFFFFFFFu) {
                 const uint32_t word = tl.bins[key[k] >> 1];
                 const uint32_t start = (key[k] & 1u) ? word >> 16 : word & 0xFFFFu;
-                tl.sorted[start + rank[k]] = (uint16_t)((uint32_t)k * kThreads + threadIdx.x);
+                tl.sorted[start + rank[k]] = (uint16_t)(((uint32_t)k * kThreads + threadIdx.x) | (affix[k] << 10));   // index | prefix << 10 | suffix << 13
             }
         }
         __syncthreads();
@@ -249,9 +294,12 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                 uint64_t p = 0, a0 = 0, b0 = 0;
                 uint32_t la = 0, lb = 0;
                 if (have) {
-                    p = base + tl.sorted[cstart + pidx];
+                    const uint32_t entry = tl.sorted[cstart + pidx];
+                    p = base + (entry & 1023u);
                     if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
                     else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
+                    const uint32_t pre = (entry >> 10) & 7u, both = pre + (entry >> 13);   // what the pair shares at both ends (step B)
+                    a0 += pre; b0 += pre; la -= both; lb -= both;
                 }
                 bp_item<Sym, kWide>(args, wv, G, have, p, a0, la, b0, lb, staged, base);
 #ifdef SWH_TILE_PROFILE
@@ -351,6 +399,8 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
     t.k = args;
     t.k.boundary = nullptr;
     t.tile = tp.tile; t.tiles = tp.tiles; t.shift = tp.shift;
+    static const bool no_affix = [] { const char *e = getenv("STRINGWARS_AMD_AFFIX"); return e && atoi(e) == 0; }();   // comparison knob
+    t.cut_affixes = sizeof(Sym) == 1 && !no_affix ? 1u : 0u;
     t.partials = scope->plan_partials;
     t.done_counter = scope->done_counter;
     t.summary = scope->summary_dev;

@@ -20,6 +20,7 @@ KERNELS = {
     "bitparallel_tiled_u32": "swh::k_bitparallel_tiled<unsigned int>",
     "bitparallel_long": "swh::k_bitparallel_long<unsigned char>",
     "direct_short": "swh::k_direct_short<",
+    "short_tiled": "swh::k_short_tiled<",
     "banded": "swh::k_banded<",
     "wavefront": "swh::k_wavefront<",
 }

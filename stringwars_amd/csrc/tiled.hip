@@ -54,6 +54,11 @@ template <typename Sym> constexpr size_t tiled_lds_bytes() {
 #ifdef SWH_TILE_PROFILE
 // Diagnostic build only (make EXTRA=-DSWH_TILE_PROFILE): wave cycles per phase of k_bitparallel_tiled, summed over waves.
 __device__ unsigned long long g_tile_phase[8];
+__device__ unsigned long long g_tile_span[2048][4];   // per workgroup: start, end of planning, end of items, end (100 MHz clock)
+extern "C" void swh_debug_tile_spans(unsigned long long *out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_span), sizeof(unsigned long long) * 2048 * 4);
+}
 extern "C" void swh_debug_tile_phases(unsigned long long *out) {
     unsigned long long zero[8] = {};
     (void)hipDeviceSynchronize();
@@ -90,6 +95,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
     uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
 #ifdef SWH_TILE_PROFILE
     unsigned long long phase_acc[4] = {0, 0, 0, 0}, phase_t = __builtin_readcyclecounter(), items_done = 0;
+    if (threadIdx.x == 0) g_tile_span[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
 #endif
 
     for (uint32_t tile = blockIdx.x; tile < targs.tiles; tile += gridDim.x) {
@@ -266,6 +272,9 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         }
         __syncthreads();
         TILE_STAMP(0);   // planning the tile
+#ifdef SWH_TILE_PROFILE
+        if (threadIdx.x == 0) g_tile_span[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+#endif
         // The key counters have done their work: keep the 64 class starts (class_thr is free since step D), then the
         // 4 KB they occupied stage the tile's distances -- one coalesced sweep at the end instead of 4-byte stores
         // scattered over the tile's window (which reached HBM as one 32-byte sector each: 6x the result bytes).
@@ -310,6 +319,9 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         TILE_STAMP(1);   // work items
         __syncthreads();
         TILE_STAMP(2);   // waiting for the workgroup's other waves
+#ifdef SWH_TILE_PROFILE
+        if (threadIdx.x == 0) g_tile_span[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
+#endif
         for (uint32_t i = threadIdx.x; i < count; i += kThreads) {
             const uint32_t d = staged[i];
             if (d != 0xFFFFFFFFu) store_result(args.job, base + i, (int64_t)d);
@@ -317,6 +329,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         __syncthreads();   // the next tile rewrites the lists
     }
 #ifdef SWH_TILE_PROFILE
+    if (threadIdx.x == 0) g_tile_span[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
         for (int q = 0; q < 3; ++q) atomicAdd(&g_tile_phase[q], phase_acc[q]);
         atomicAdd(&g_tile_phase[3], 1ull);

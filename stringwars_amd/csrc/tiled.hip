@@ -30,6 +30,12 @@ constexpr int kTileBuckets = 32;   // text-length buckets per class
 constexpr int kTileClasses = 64;
 constexpr int kTileBins = kTileClasses * kTileBuckets;
 
+// Waves per workgroup. The hardware favours a compute unit's oldest workgroups, so the youngest run the last part of
+// their tile alone: with four-wave workgroups that is ONE wave per SIMD, and a wave of this serial recurrence issues at
+// half rate on its own (C2: the four workgroups of a CU finish at 105 / 150 / 190 / 235 us of a 260 us profiled launch,
+// tools/tile_spans.py). Eight-wave workgroups (two per CU, two tiles each) leave two waves per SIMD in that tail: -6 % for
+// a launch on its own (C2 synchronous: 22.95 -> 24.1-24.6 TCUPS); overlapping launches of two pipeline lanes, where the
+// other launch fills the tail anyway, measure the same with either (27.7-28.2 TCUPS).
 struct TileLds {
     uint16_t sorted[kTileMax];            // tile-local pair indices, sorted by (class, text-length bucket)
     uint32_t bins[kTileBins / 2];         // two u16 counters per word: counts, then exclusive prefixes
@@ -37,7 +43,7 @@ struct TileLds {
     uint16_t class_thr[kTileClasses];     // ranks >= thr move up to class_tgt
     uint16_t class_tgt[kTileClasses];
     uint32_t item_prefix[kTileClasses + 1];
-    uint32_t wave_sums[4];
+    uint32_t wave_sums[16];
     uint32_t ticket;
 };
 struct TileTail {   // after the last tile the counters' space serves the call summary
@@ -47,8 +53,8 @@ struct TileTail {   // after the last tile the counters' space serves the call s
 };
 static_assert(sizeof(TileTail) <= sizeof(uint32_t) * kTileBins / 2, "the tail reuses TileLds::bins");
 
-template <typename Sym> constexpr size_t tiled_lds_bytes() {
-    return (size_t)BpTraits<Sym>::kWaves * (bp_table_words<Sym>() + 64) * 4 + sizeof(TileLds);
+template <typename Sym, int kWaves> constexpr size_t tiled_lds_bytes() {
+    return (size_t)kWaves * (bp_table_words<Sym>() + 64) * 4 + sizeof(TileLds);
 }
 
 #ifdef SWH_TILE_PROFILE
@@ -81,9 +87,9 @@ struct TiledArgs {
     CallSummary *summary;   // host-mapped: the last workgroup reports (common.hpp: report_call_summary)
 };
 
-template <typename Sym, bool kWide>
+template <typename Sym, int kWaves, bool kWide>
 __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, const uint64_t a_total, const uint64_t b_total) {
-    constexpr int kWaves = BpTraits<Sym>::kWaves, kThreads = kWaves * 64, kTableWords = bp_table_words<Sym>();
+    constexpr int kThreads = kWaves * 64, kTableWords = bp_table_words<Sym>();
     constexpr int kPer = kTileMax / kThreads;   // pairs per thread and tile
     const KernelArgs &args = targs.k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -365,8 +371,8 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
     }
 }
 
-template <typename Sym>
-__global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel_tiled(TiledArgs targs) {
+template <typename Sym, int kWaves>
+__global__ __launch_bounds__(kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel_tiled(TiledArgs targs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KernelArgs &args = targs.k;
     const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
@@ -374,10 +380,10 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
     const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
                                         : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
     if constexpr (sizeof(Sym) == 1) {
-        if (a_total >= 16 && b_total >= 16) tiled_run<Sym, true>(targs, smem, a_total, b_total);
-        else tiled_run<Sym, false>(targs, smem, a_total, b_total);
+        if (a_total >= 16 && b_total >= 16) tiled_run<Sym, kWaves, true>(targs, smem, a_total, b_total);
+        else tiled_run<Sym, kWaves, false>(targs, smem, a_total, b_total);
     } else {
-        tiled_run<Sym, false>(targs, smem, a_total, b_total);
+        tiled_run<Sym, kWaves, false>(targs, smem, a_total, b_total);
     }
 }
 
@@ -401,10 +407,9 @@ TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text) {
     return tp;
 }
 
-template <typename Sym>
+template <typename Sym, int kWaves>
 static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text) {
-    constexpr int kWaves = BpTraits<Sym>::kWaves;
-    constexpr size_t lds = tiled_lds_bytes<Sym>();
+    constexpr size_t lds = tiled_lds_bytes<Sym, kWaves>();
     uint32_t slots = (uint32_t)scope->compute_units * (uint32_t)((160 * 1024) / lds);
     if (slots > (uint32_t)kMaxPartials) slots = kMaxPartials;
     const TilePlan tp = plan_tiles(pairs, slots, longest_text);
@@ -417,22 +422,24 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
     t.partials = scope->plan_partials;
     t.done_counter = scope->done_counter;
     t.summary = scope->summary_dev;
-    opt_in_dynamic_lds(scope, (const void *)k_bitparallel_tiled<Sym>, lds);
+    opt_in_dynamic_lds(scope, (const void *)k_bitparallel_tiled<Sym, kWaves>, lds);
     static const bool debug = getenv("STRINGWARS_AMD_DEBUG") != nullptr;
     if (debug) {
         int per_cu = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bitparallel_tiled<Sym>, kWaves * 64, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bitparallel_tiled<Sym, kWaves>, kWaves * 64, lds);
         fprintf(stderr, "[swh] tiled: pairs %llu tile %u tiles %u blocks %u shift %u lds %zu -> %d workgroups per CU\n",
                 (unsigned long long)pairs, tp.tile, tp.tiles, tp.blocks, tp.shift, lds, per_cu);
     }
     StampGuard guard(scope, sizeof(Sym) == 1 ? "bitparallel_tiled" : "bitparallel_tiled_u32");
-    hipLaunchKernelGGL(k_bitparallel_tiled<Sym>, dim3(tp.blocks), dim3(kWaves * 64), lds, scope->stream, t);
+    hipLaunchKernelGGL((k_bitparallel_tiled<Sym, kWaves>), dim3(tp.blocks), dim3(kWaves * 64), lds, scope->stream, t);
     SWH_HIP_CHECK(hipGetLastError());
 }
 
 void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text) {
-    if (args.sym_bytes == 4) launch_tiled_sym<uint32_t>(scope, args, pairs, longest_text);
-    else launch_tiled_sym<uint8_t>(scope, args, pairs, longest_text);
+    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_TILED_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4 or 8
+    if (args.sym_bytes == 4) launch_tiled_sym<uint32_t, BpTraits<uint32_t>::kWaves>(scope, args, pairs, longest_text);
+    else if (forced == 4) launch_tiled_sym<uint8_t, 4>(scope, args, pairs, longest_text);
+    else launch_tiled_sym<uint8_t, 8>(scope, args, pairs, longest_text);
 }
 
 }  // namespace swh

@@ -27,9 +27,15 @@
 
 namespace swh {
 
-template <typename Sym, bool kWide>
+// kBpWaves: waves per workgroup. Byte strings run ONE 16-wave workgroup per compute unit whose waves take the CU's share
+// of the items (item = blockIdx.x + turn * gridDim.x) from an LDS ticket: the hardware serves a CU's oldest waves first, so
+// with a fixed list per wave the youngest were left to finish theirs alone, one wave per SIMD -- the regime where this
+// serial recurrence issues at half rate (see tiled.hip). A ticket in LDS costs nothing next to an item (the global one
+// this kernel started with saturated at 88 dequeues per microsecond).
+template <typename Sym, int kBpWaves, bool kWide>
 __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const uint64_t a_total, const uint64_t b_total) {
-    constexpr int kBpWaves = BpTraits<Sym>::kWaves, kBpTableWords = bp_table_words<Sym>();
+    constexpr int kBpTableWords = bp_table_words<Sym>();
+    constexpr bool kTicket = kBpWaves > BpTraits<Sym>::kWaves;
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     uint32_t *item_prefix = (uint32_t *)smem + (size_t)kBpWaves * (kBpTableWords + 64);  // [65]
@@ -48,7 +54,7 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
             if ((int)threadIdx.x >= off) incl += up;
         }
         item_prefix[threadIdx.x] = incl - mine;
-        if (threadIdx.x == 63) item_prefix[64] = incl;
+        if (threadIdx.x == 63) { item_prefix[64] = incl; item_prefix[66] = 0; }   // [66]: the workgroup's ticket
     }
     __syncthreads();
     const uint32_t items_total = item_prefix[64];
@@ -56,7 +62,13 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
     const uint32_t waves_total = gridDim.x * kBpWaves;
     const uint32_t wave_id = blockIdx.x * kBpWaves + wave_in_block;
 
-    for (uint32_t w = wave_id; w < items_total; w += waves_total) {
+    for (uint32_t w = wave_id;; w += waves_total) {
+        if constexpr (kTicket) {
+            uint32_t turn = 0;
+            if (lane == 0) turn = __hip_atomic_fetch_add(&item_prefix[66], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            w = blockIdx.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)turn) * gridDim.x;
+        }
+        if (w >= items_total) break;
         const uint32_t item = items_total - 1 - w;  // heavy classes (many blocks, long texts) first
         // class = number of prefix entries <= item (prefix is non-decreasing, prefix[0] = 0)
         const uint32_t G = (uint32_t)__popcll(__ballot(my_prefix <= item));
@@ -79,18 +91,18 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
     }
 }
 
-template <typename Sym>
-__global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel(KernelArgs args) {
+template <typename Sym, int kBpWaves>
+__global__ __launch_bounds__(kBpWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel(KernelArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
                                         : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
     const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
                                         : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
     if constexpr (sizeof(Sym) == 1) {
-        if (a_total >= 16 && b_total >= 16) bp_run<Sym, true>(args, smem, a_total, b_total);
-        else bp_run<Sym, false>(args, smem, a_total, b_total);
+        if (a_total >= 16 && b_total >= 16) bp_run<Sym, kBpWaves, true>(args, smem, a_total, b_total);
+        else bp_run<Sym, kBpWaves, false>(args, smem, a_total, b_total);
     } else {
-        bp_run<Sym, false>(args, smem, a_total, b_total);
+        bp_run<Sym, kBpWaves, false>(args, smem, a_total, b_total);
     }
 }
 
@@ -316,26 +328,30 @@ void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_hos
     SWH_HIP_CHECK(hipGetLastError());
 }
 
-template <typename Sym>
+template <typename Sym, int kWaves>
 static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     // The work list lives in the device plan; the host only bounds the grid (an item holds >= 1 pair).
-    constexpr int kWaves = BpTraits<Sym>::kWaves;
-    constexpr size_t lds = bp_lds_bytes<Sym>();
+    constexpr size_t lds = (size_t)kWaves * (bp_table_words<Sym>() + 64) * 4 + 80 * 4;
     KernelArgs k = args;
     k.boundary = nullptr;
     uint64_t blocks64 = (pairs + kWaves - 1) / kWaves;
-    // bytes: 33 KB blocks of 4 waves, 4 per CU; code points: 29 KB blocks of 2 waves, 5 per CU
-    uint32_t max_blocks = (uint32_t)scope->compute_units * (sizeof(Sym) == 1 ? 4 : 5);
+    // as many workgroups as the compute units hold (bytes: one of 16 waves, or four of 4; code points: five of 2)
+    const uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+    uint32_t max_blocks = (uint32_t)scope->compute_units * (per_cu ? per_cu : 1u);
     uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
-    opt_in_dynamic_lds(scope, (const void *)k_bitparallel<Sym>, lds);
+    opt_in_dynamic_lds(scope, (const void *)k_bitparallel<Sym, kWaves>, lds);
     StampGuard guard(scope, sizeof(Sym) == 1 ? "bitparallel" : "bitparallel_u32");
-    hipLaunchKernelGGL(k_bitparallel<Sym>, dim3(blocks), dim3(kWaves * 64), lds, scope->stream, k);
+    hipLaunchKernelGGL((k_bitparallel<Sym, kWaves>), dim3(blocks), dim3(kWaves * 64), lds, scope->stream, k);
     SWH_HIP_CHECK(hipGetLastError());
 }
 
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs) {
-    if (args.sym_bytes == 4) launch_bitparallel_sym<uint32_t>(scope, args, pairs);
-    else launch_bitparallel_sym<uint8_t>(scope, args, pairs);
+    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_BP_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4 or 16
+    if (args.sym_bytes == 4) {
+        if (forced == 4) launch_bitparallel_sym<uint32_t, BpTraits<uint32_t>::kWaves>(scope, args, pairs);
+        else launch_bitparallel_sym<uint32_t, 10>(scope, args, pairs);   // 14 KB of tables per wave: ten waves are what a CU holds
+    } else if (forced == 4) launch_bitparallel_sym<uint8_t, 4>(scope, args, pairs);
+    else launch_bitparallel_sym<uint8_t, 16>(scope, args, pairs);
 }
 
 }  // namespace swh

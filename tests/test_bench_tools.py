@@ -39,7 +39,7 @@ def test_pmc_constants_folds_counter_passes(tmp_path):
     run.mkdir()
     rows = []
     for dispatch in (1, 2, 3):
-        rows.append({"Dispatch_Id": dispatch, "Kernel_Name": "void swh::k_bitparallel_tiled<unsigned char>(swh::TiledArgs)",
+        rows.append({"Dispatch_Id": dispatch, "Kernel_Name": "void swh::k_bitparallel_tiled<unsigned char, 8>(swh::TiledArgs)",
                      "Counter_Name": "SQ_INSTS_VALU", "Counter_Value": 80e6 + dispatch * 1e6})
         rows.append({"Dispatch_Id": dispatch, "Kernel_Name": "void swh::k_tape_longest<unsigned int>(...)",
                      "Counter_Name": "SQ_INSTS_VALU", "Counter_Value": 5.0})

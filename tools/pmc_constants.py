@@ -14,11 +14,11 @@ import os
 
 # stamp name used by the library's timing (swh_timing_t::dominant_name) -> substring of the kernel symbol
 KERNELS = {
-    "bitparallel": "swh::k_bitparallel<unsigned char>",
-    "bitparallel_u32": "swh::k_bitparallel<unsigned int>",
-    "bitparallel_tiled": "swh::k_bitparallel_tiled<unsigned char>",
-    "bitparallel_tiled_u32": "swh::k_bitparallel_tiled<unsigned int>",
-    "bitparallel_long": "swh::k_bitparallel_long<unsigned char>",
+    "bitparallel": "swh::k_bitparallel<unsigned char,",
+    "bitparallel_u32": "swh::k_bitparallel<unsigned int,",
+    "bitparallel_tiled": "swh::k_bitparallel_tiled<unsigned char,",
+    "bitparallel_tiled_u32": "swh::k_bitparallel_tiled<unsigned int,",
+    "bitparallel_long": "swh::k_bitparallel_long<unsigned char",
     "direct_short": "swh::k_direct_short<",
     "short_tiled": "swh::k_short_tiled<",
     "banded": "swh::k_banded<",

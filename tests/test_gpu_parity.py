@@ -1176,3 +1176,28 @@ def test_fused_planner_gives_up_instead_of_hanging():
     env = dict(os.environ, STRINGWARS_AMD_FUSED_OVERSUBSCRIBE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert done.returncode == 0 and "gave-up ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
+
+
+def test_comparison_knobs_keep_parity():
+    """The environment knobs DESIGN.md quotes A/B numbers from select other launch shapes of the same kernels (four-wave
+    workgroups with fixed item lists, no affix cut, k_direct_short for every word-sized batch): each must stay bit-exact."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, oracle, stringwars_amd as sw\n"
+        "scope = sw.DeviceScope(gpu_device=0)\n"
+        "for workload, count in (('tokens64', 120000), ('short_words', 150000), ('utf8_lines', 900)):\n"
+        "    a, b = sw.generate_pairs(workload, count, seed=13)\n"
+        "    want = oracle.levenshtein_pairs(a, b, algo='hyyro')\n"
+        "    pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)\n"
+        "    for algorithm in ('auto', 'bitparallel', 'tiled'):\n"
+        "        engine = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm)\n"
+        "        assert (engine.pairs(pa, pb, scope) == want).all(), (workload, algorithm)\n"
+        "        assert (engine.pairs(a, b, scope, bound=5) == np.minimum(want, 6)).all(), (workload, algorithm)\n"
+        "ua, ub = sw.generate_pairs('utf8_lines', 700, seed=14)\n"
+        "assert (sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm='bitparallel').pairs(ua, ub, scope) == oracle.levenshtein_pairs(ua, ub, utf8=True)).all()\n"
+        "print('knobs ok')\n")
+    env = dict(os.environ, STRINGWARS_AMD_BP_WAVES="4", STRINGWARS_AMD_TILED_WAVES="4", STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and "knobs ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])

@@ -208,7 +208,14 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         return c;
     };
     auto request = [&](const ShortChunk &c, ShortRequest<Off> &r) {
-        const Off *pa = off_a + c.base, *pb = off_b + c.base;   // uniform bases, 32-bit lane offsets
+        // uniform bases, made visibly so (the chunk travels through loop-carried registers): the loads then take an SGPR base
+        // and a 32-bit lane offset instead of 64-bit address arithmetic per load
+        auto uniform = [](uint64_t v) -> uint64_t {
+            return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+                   ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+        };
+        const uint64_t first = uniform(c.base);
+        const Off *pa = off_a + first, *pb = off_b + first;
 #pragma unroll
         for (int k = 0; k < kShortPer; ++k) {
             uint32_t q = (uint32_t)k * kShortThreads + threadIdx.x;
@@ -219,7 +226,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         if constexpr (kWide) {
             // unit u of a segment starts 16 u bytes into it; units that would reach past the tape are read from its last 16 bytes
             // instead (and repaired below); units past the segment are harmless slack
-            const uint8_t *sa = a_data + c.a_lo, *sb = b_data + c.b_lo;
+            const uint8_t *sa = a_data + uniform(c.a_lo), *sb = b_data + uniform(c.b_lo);
             const int64_t room_a = (int64_t)(a_total - c.a_lo) - 16, room_b = (int64_t)(b_total - c.b_lo) - 16;
             const int lim_a = (int)(room_a > 0x10000 ? 0x10000 : room_a), lim_b = (int)(room_b > 0x10000 ? 0x10000 : room_b);
 #pragma unroll

@@ -24,8 +24,8 @@
 
 namespace swh {
 
-constexpr int kTileMax = 1024;     // pairs per tile: 10 bits of the u16 index list (the other six: common prefix / suffix)
-constexpr uint32_t kAffixCap = 7;  // symbols cut off at either end (three bits each)
+constexpr int kTileMax = 1024;     // pairs per tile: 10 bits of an index-list entry (then 5 + 5 bits: common prefix / suffix)
+constexpr uint32_t kAffixCap = 16; // symbols cut off at either end: what one 16-byte window shows
 constexpr int kTileBuckets = 32;   // text-length buckets per class
 constexpr int kTileClasses = 64;
 constexpr int kTileBins = kTileClasses * kTileBuckets;
@@ -37,7 +37,7 @@ constexpr int kTileBins = kTileClasses * kTileBuckets;
 // a launch on its own (C2 synchronous: 22.95 -> 24.1-24.6 TCUPS); overlapping launches of two pipeline lanes, where the
 // other launch fills the tail anyway, measure the same with either (27.7-28.2 TCUPS).
 struct TileLds {
-    uint16_t sorted[kTileMax];            // tile-local pair indices, sorted by (class, text-length bucket)
+    uint32_t sorted[kTileMax];            // tile-local pair indices (| prefix << 10 | suffix << 16), sorted by (class, text-length bucket)
     uint32_t bins[kTileBins / 2];         // two u16 counters per word: counts, then exclusive prefixes
     uint32_t class_count[kTileClasses];   // pairs per natural class; after step C: per final class
     uint16_t class_thr[kTileClasses];     // ranks >= thr move up to class_tgt
@@ -114,9 +114,9 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         __syncthreads();
         // ---- B: classify my pairs ---------------------------------------------------------------------------------
         // Every load a thread needs here is requested in two batches (indices clamped into the batch, no branch between the
-        // loads): the extents of its pairs, then -- byte strings -- the first and last eight bytes of both strings of every
+        // loads): the extents of its pairs, then -- byte strings -- the first and last sixteen bytes of both strings of every
         // pair. What a pair shares at both ends is cut off before it is classified (the first thing rapidfuzz's Levenshtein
-        // does, too): up to kAffixCap symbols each, which is what fits the spare bits of the tile's index list.
+        // does, too): up to kAffixCap symbols each, kept in the upper bits of the pair's entry in the tile's index list.
         uint32_t cls[kPer], txt[kPer], rank[kPer], affix[kPer];
         uint64_t a0s[kPer], b0s[kPer];
         uint32_t las[kPer], lbs[kPer];
@@ -130,31 +130,31 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         }
         if constexpr (sizeof(Sym) == 1 && kWide) {
             if (targs.cut_affixes) {
-                unsigned long long heads[kPer], tails[kPer];
+                uint4 ha[kPer], hb[kPer], ta[kPer], tb[kPer];
                 bool inside[kPer];
 #pragma unroll
                 for (int k = 0; k < kPer; ++k) {
                     // windows that would leave the tapes (the first / last strings) are read at the tapes' start and not used
                     const uint64_t ea = a0s[k] + las[k], eb = b0s[k] + lbs[k];
-                    inside[k] = a0s[k] + 8 <= a_total && b0s[k] + 8 <= b_total && ea >= 8 && eb >= 8;
-                    const uint8_t *ah = (const uint8_t *)args.job.a.data + (inside[k] ? a0s[k] : 0), *bh = (const uint8_t *)args.job.b.data + (inside[k] ? b0s[k] : 0);
-                    const uint8_t *at = (const uint8_t *)args.job.a.data + (inside[k] ? ea - 8 : 0), *bt = (const uint8_t *)args.job.b.data + (inside[k] ? eb - 8 : 0);
-                    unsigned long long x, y;
-                    __builtin_memcpy(&x, ah, 8); __builtin_memcpy(&y, bh, 8);
-                    heads[k] = x ^ y;
-                    __builtin_memcpy(&x, at, 8); __builtin_memcpy(&y, bt, 8);
-                    tails[k] = x ^ y;
+                    inside[k] = a0s[k] + 16 <= a_total && b0s[k] + 16 <= b_total && ea >= 16 && eb >= 16;
+                    const uint8_t *ad = (const uint8_t *)args.job.a.data, *bd = (const uint8_t *)args.job.b.data;
+                    __builtin_memcpy(&ha[k], ad + (inside[k] ? a0s[k] : 0), 16);
+                    __builtin_memcpy(&hb[k], bd + (inside[k] ? b0s[k] : 0), 16);
+                    __builtin_memcpy(&ta[k], ad + (inside[k] ? ea - 16 : 0), 16);
+                    __builtin_memcpy(&tb[k], bd + (inside[k] ? eb - 16 : 0), 16);
                 }
 #pragma unroll
                 for (int k = 0; k < kPer; ++k) {
                     const uint32_t mn = las[k] < lbs[k] ? las[k] : lbs[k];
-                    uint32_t pre = heads[k] ? (uint32_t)__builtin_ctzll(heads[k]) >> 3 : 8u;
-                    pre = pre < kAffixCap ? pre : kAffixCap;
+                    const unsigned long long h_lo = (unsigned long long)(ha[k].x ^ hb[k].x) | ((unsigned long long)(ha[k].y ^ hb[k].y) << 32);
+                    const unsigned long long h_hi = (unsigned long long)(ha[k].z ^ hb[k].z) | ((unsigned long long)(ha[k].w ^ hb[k].w) << 32);
+                    const unsigned long long t_lo = (unsigned long long)(ta[k].x ^ tb[k].x) | ((unsigned long long)(ta[k].y ^ tb[k].y) << 32);
+                    const unsigned long long t_hi = (unsigned long long)(ta[k].z ^ tb[k].z) | ((unsigned long long)(ta[k].w ^ tb[k].w) << 32);
+                    uint32_t pre = h_lo ? (uint32_t)__builtin_ctzll(h_lo) >> 3 : (h_hi ? 8u + ((uint32_t)__builtin_ctzll(h_hi) >> 3) : 16u);
                     pre = pre < mn ? pre : mn;
-                    uint32_t suf = tails[k] ? (uint32_t)__builtin_clzll(tails[k]) >> 3 : 8u;
-                    suf = suf < kAffixCap ? suf : kAffixCap;
+                    uint32_t suf = t_hi ? (uint32_t)__builtin_clzll(t_hi) >> 3 : (t_lo ? 8u + ((uint32_t)__builtin_clzll(t_lo) >> 3) : 16u);
                     suf = suf < mn - pre ? suf : mn - pre;
-                    affix[k] = inside[k] ? pre | (suf << 3) : 0u;
+                    affix[k] = inside[k] ? pre | (suf << 6) : 0u;
                 }
             }
         }
@@ -171,7 +171,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                 maxb = lb > maxb ? lb : maxb;
                 shorts += (la <= 32 && lb <= 32) ? 1u : 0u;
                 const uint32_t diff = la > lb ? la - lb : lb - la;
-                const uint32_t shared = (affix[k] & 7u) + (affix[k] >> 3);
+                const uint32_t shared = (affix[k] & 63u) + (affix[k] >> 6);
                 la -= shared; lb -= shared;
                 if (la == 0 || lb == 0) {
                     store_result(args.job, p, (int64_t)clamp_bound(la + lb, args.job.bound));
@@ -273,7 +273,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
             if (key[k] != 0xFFFFFFFFu) {
                 const uint32_t word = tl.bins[key[k] >> 1];
                 const uint32_t start = (key[k] & 1u) ? word >> 16 : word & 0xFFFFu;
-                tl.sorted[start + rank[k]] = (uint16_t)(((uint32_t)k * kThreads + threadIdx.x) | (affix[k] << 10));   // index | prefix << 10 | suffix << 13
+                tl.sorted[start + rank[k]] = ((uint32_t)k * kThreads + threadIdx.x) | (affix[k] << 10);   // index | prefix << 10 | suffix << 16
             }
         }
         __syncthreads();
@@ -313,7 +313,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                     p = base + (entry & 1023u);
                     if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
                     else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
-                    const uint32_t pre = (entry >> 10) & 7u, both = pre + (entry >> 13);   // what the pair shares at both ends (step B)
+                    const uint32_t pre = (entry >> 10) & 63u, both = pre + (entry >> 16);   // what the pair shares at both ends (step B)
                     a0 += pre; b0 += pre; la -= both; lb -= both;
                 }
                 bp_item<Sym, kWide>(args, wv, G, have, p, a0, la, b0, lb, staged, base);

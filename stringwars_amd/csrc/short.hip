@@ -350,6 +350,10 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         // ---- the next chunk's global reads go out now and come back while this chunk's work items run -----------------------
         const ShortChunk nxt = next_chunk(cand, cand_base, cand_len, cand_bounds);
         ShortRequest<Off> req_next;
+        // Nothing older may be pending when the requests go out: with the previous chunk's result stores still counted (they
+        // finished long ago), hipcc cannot tell what the work-item loop below may overwrite and puts a wait for EVERYTHING --
+        // the requests included -- in front of the first item; the whole round trip was exposed.
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         if (nxt.any) request(nxt, req_next);
         // ---- E: work items of 64 sorted pairs, heaviest (last) first, dealt by an LDS ticket ----------------------------
         {

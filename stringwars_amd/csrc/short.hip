@@ -94,7 +94,13 @@ extern "C" void swh_debug_short_phases(unsigned long long *out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_short_phase), sizeof(zero));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_short_phase), zero, sizeof(zero));
 }
-#define SHORT_STAMP(slot) do { const unsigned long long now__ = __builtin_readcyclecounter(); phase_acc[slot] += now__ - phase_t; phase_t = now__; } while (0)
+// wall-clock (100 MHz) time stamps of the first chunks of every 16th workgroup: g_short_span[workgroup / 16][chunk][stamp]
+__device__ unsigned long long g_short_span[64][8][8];
+extern "C" void swh_debug_short_spans(unsigned long long *out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_short_span), sizeof(unsigned long long) * 64 * 8 * 8);
+}
+#define SHORT_STAMP(slot) do { if (span_on && threadIdx.x == 0 && chunk_no < 8) g_short_span[blockIdx.x >> 4][chunk_no][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SHORT_STAMP(slot) do {} while (0)
 #endif
@@ -151,7 +157,9 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
     uint32_t cells = 0, syms = 0, maxa = 0, maxb = 0, misfit = 0;
     const uint32_t bound = job.bound;
 #ifdef SWH_SHORT_PROFILE
-    unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_t = __builtin_readcyclecounter(), items_done = 0;
+    unsigned long long items_done = 0;
+    const bool span_on = (blockIdx.x & 15u) == 0 && (blockIdx.x >> 4) < 64;
+    uint32_t chunk_no = 0;
 #endif
 
     // ---- the workgroup's chunks, in order: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; a tile is one chunk when its
@@ -247,6 +255,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
     while (cur.any) {
         const uint64_t base = cur.base;
         const uint32_t len = cur.len;
+        SHORT_STAMP(7);   // top of the chunk
         // ---- A: the chunk's segments into LDS (requested while the previous chunk's work items ran) ---------------------------
         const bool cand = candidate(cand_base, cand_len);
         const Off cand_bounds = bounds_request(cand, cand_base, cand_len);
@@ -469,6 +478,9 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
             }
         }
         SHORT_STAMP(6);   // F
+#ifdef SWH_SHORT_PROFILE
+        ++chunk_no;
+#endif
         // no barrier here: the next chunk rewrites `staged` in its step B, behind its first barrier, and what its step A
         // rewrites (segments, counters, ticket) nobody reads after step E
         cur = nxt;
@@ -476,7 +488,6 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
     }
 #ifdef SWH_SHORT_PROFILE
     if (lane == 0) {
-        for (int q = 0; q < 7; ++q) atomicAdd(&g_short_phase[q], phase_acc[q]);
         atomicAdd(&g_short_phase[7], 1ull);
         atomicAdd(&g_short_phase[8], items_done);
     }

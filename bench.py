@@ -386,14 +386,15 @@ def main():
                                             workload, pairs, constants, extra={"measured": "one synchronous call on an idle GPU"})
         parity = None
         cpu_baseline, cpu_baselines = None, None
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             import oracle  # checker + reported baseline only; never on the timed GPU path
-            check = min(pairs, 20_000)
+            check = min(pairs, 20_000)   # (rank 0's shard; the other ranks' slices are covered by `gather_ok`)
             want = oracle.levenshtein_pairs(a, b, algo="hyyro", count=check)
             parity = bool((want == pipelined_result[:check]).all() and (want == sync_result[:check]).all()
                           and (pipelined_result == sync_result).all())
-            cpu_baselines = cpu_rows(a, b)
-            cpu_baseline = {k: v for k, v in cpu_baselines[0].items() if k != "name"}
+            if world == 1:   # the CPU baseline is timed at N = 1 only
+                cpu_baselines = cpu_rows(a, b)
+                cpu_baseline = {k: v for k, v in cpu_baselines[0].items() if k != "name"}
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "GCUPS (DP cell updates/s) batched Levenshtein", "value": round(total_cells * args.steps / elapsed / 1e9, 2),

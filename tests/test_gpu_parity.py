@@ -1201,3 +1201,23 @@ def test_comparison_knobs_keep_parity():
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert done.returncode == 0 and "knobs ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
+
+
+@pytest.mark.parametrize("config,pairs", [("c2", 60_000), ("c5", 600_000)])
+def test_bench_two_ranks_share_the_gpu(config, pairs):
+    """`bench.py` as the driver launches it for N > 1 -- one process per rank under torch.distributed -- with both ranks on
+    cuda:0 and gloo in RCCL's place (one-GPU boxes): the sharding, the pipelined steps, the gather (weak: `dist.gather`;
+    strong: the chunked send/recv of cells-balanced shards) and its checksums run for real; rank 0's shard is compared with
+    the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + (os.getpid() % 300) + (0 if config == "c2" else 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--pairs", str(pairs),
+           "--steps", "3", "--warmup", "1", "--backend", "gloo", "--share-gpu"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-3000:])
+    line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["gather_ok"] is True and line["parity_vs_oracle"] is True
+    assert line["scaling"] == ("weak" if config == "c2" else "strong") and line["value"] > 0

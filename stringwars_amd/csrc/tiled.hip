@@ -150,9 +150,9 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                     const unsigned long long h_hi = (unsigned long long)(ha[k].z ^ hb[k].z) | ((unsigned long long)(ha[k].w ^ hb[k].w) << 32);
                     const unsigned long long t_lo = (unsigned long long)(ta[k].x ^ tb[k].x) | ((unsigned long long)(ta[k].y ^ tb[k].y) << 32);
                     const unsigned long long t_hi = (unsigned long long)(ta[k].z ^ tb[k].z) | ((unsigned long long)(ta[k].w ^ tb[k].w) << 32);
-                    uint32_t pre = h_lo ? (uint32_t)__builtin_ctzll(h_lo) >> 3 : (h_hi ? 8u + ((uint32_t)__builtin_ctzll(h_hi) >> 3) : 16u);
+                    uint32_t pre = h_lo ? (uint32_t)__builtin_ctzll(h_lo) >> 3 : (h_hi ? 8u + ((uint32_t)__builtin_ctzll(h_hi) >> 3) : kAffixCap);
                     pre = pre < mn ? pre : mn;
-                    uint32_t suf = t_hi ? (uint32_t)__builtin_clzll(t_hi) >> 3 : (t_lo ? 8u + ((uint32_t)__builtin_clzll(t_lo) >> 3) : 16u);
+                    uint32_t suf = t_hi ? (uint32_t)__builtin_clzll(t_hi) >> 3 : (t_lo ? 8u + ((uint32_t)__builtin_clzll(t_lo) >> 3) : kAffixCap);
                     suf = suf < mn - pre ? suf : mn - pre;
                     affix[k] = inside[k] ? pre | (suf << 6) : 0u;
                 }

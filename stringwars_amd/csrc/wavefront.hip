@@ -310,34 +310,53 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                         fetch_cost_row(stream.sym_after(u));
                     }
                     if (s - (uint32_t)gl < rows) {  // active: DP row r = s - gl + 1
-                        int diag = prev_h, left = recv_h, e = recv_e;
+                        int left = recv_h, e = recv_e;
                         [[maybe_unused]] const int bias2 = -2 * ext;   // skewed models use substitution scores as sub - 2 ext (ext == open when linear)
                         [[maybe_unused]] const int open_minus_ext = open - ext;
-                        auto cell = [&](int k, int sc) {
-                            int up = H[k];
-                            int h;
+                        // A cell is computed in two halves one column apart: `cell(k, sc)` first adds the substitution score to
+                        // the diagonal -- H[k - 1] of the previous row, still in its register -- and only then finishes cell
+                        // k - 1, whose new value can so be written IN PLACE. Written the obvious way (finish cell k, keep the old
+                        // H[k] as the next diagonal) the old and the new H[k] are alive together, the strip moves one register
+                        // per row, and because rows are conditional (a lane is active for rows s - gl only) hipcc restored the
+                        // canonical registers with W v_mov per row: a quarter of the instructions of a 64-80 column strip.
+                        int t_pending = 0;
+                        // The last instruction of a cell is written with H[k] as a tied operand: hipcc otherwise puts the new
+                        // value into the dying diagonal's register. `after` (the next cell's diagonal sum, which read the OLD
+                        // H[k]) is an operand only to keep that addition in front -- scheduled behind, the old H[k] needs a copy.
+                        auto finish = [&](int k, int t, int after) {
+                            if constexpr (kSkew) {
+                                asm("v_max3_i32 %0, %1, %0, %2" : "+v"(H[k]) : "v"(t), "v"(left), "v"(after));   // max3(diag + sc, up, left): the score carries the -2g bias
+                                left = H[k];
+                                return;
+                            }
+                            const int up = H[k];
+                            int x, y;   // h = max3(t, x, y)
                             if constexpr (kSkewAffine) {
                                 int f = max(up + open_minus_ext, F[k]);
                                 F[k] = f;
                                 e = max(left + open_minus_ext, e);
-                                h = max(max(diag + sc, e), f);   // sc already carries the -2 ext bias
+                                x = e; y = f;   // the score already carries the -2 ext bias
                             } else if constexpr (kAffine) {
                                 int f = max(up + open, F[k] + ext);
                                 F[k] = f;
                                 e = max(left + open, e + ext);
-                                h = max(max(diag + sc, e), f);
-                            } else if constexpr (kSkew) {
-                                h = max(max(diag + sc, up), left);   // sc already carries the -2g bias
+                                x = e; y = f;
                             } else {
-                                h = max(max(diag + sc, up + open), left + open);
+                                x = up + open; y = left + open;
                             }
                             if constexpr (kLocal) {
-                                h = max(h, 0);
-                                if (c0 + gl * W + k < cols) best = max(best, h);  // phantom columns right of the pair do not count
+                                const int h3 = max(max(t, x), y);
+                                asm("v_max_i32 %0, 0, %1" : "+v"(H[k]) : "v"(h3), "v"(after));
+                                if (c0 + gl * W + k < cols) best = max(best, H[k]);  // phantom columns right of the pair do not count
+                            } else {
+                                asm("v_max3_i32 %0, %1, %2, %3" : "+v"(H[k]) : "v"(t), "v"(x), "v"(y), "v"(after));
                             }
-                            diag = up;
-                            left = h;
-                            H[k] = h;
+                            left = H[k];
+                        };
+                        auto cell = [&](int k, int sc) {
+                            const int t = (k == 0 ? prev_h : H[k > 0 ? k - 1 : 0]) + sc;   // diagonal: the previous row's H[k - 1]
+                            if (k > 0) finish(k - 1, t_pending, t);
+                            t_pending = t;
                         };
                         if constexpr (kClass) {
                             // one 32-byte cost row per step (the row symbol's class), then bytes are picked in
@@ -382,6 +401,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
 #pragma unroll
                             for (int k = 0; k < W; ++k) cell(k, (sym == col_sym(k)) ? match + bias2 : mismatch + bias2);
                         }
+                        finish(W - 1, t_pending, t_pending);
                         out_h = left;
                         out_e = e;
                         if (write_bnd) {

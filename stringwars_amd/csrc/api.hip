@@ -1025,8 +1025,9 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
             table[1024 + b] = (uint8_t)found;
         }
         // Global alignment runs on scores relative to the all-gaps baseline (wavefront.hip): the table holds
-        // cost - 2*extend, which must still fit a signed byte (otherwise the 256x256 LDS path is used).
-        const int bias = -2 * extend;
+        // cost - extend - open (= cost - 2 g for linear gaps; the affine kernel keeps H + (open - extend) in its strips and
+        // takes the surplus back on the diagonal), which must still fit a signed byte (otherwise the 256x256 LDS path is used).
+        const int bias = -(extend + open);
         for (int i = 0; i < classes && fits; ++i)
             for (int j = 0; j < classes; ++j) {
                 int v = (int)matrix[rep[i] * 256 + rep[j]] + bias;

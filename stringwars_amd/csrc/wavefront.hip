@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                         sel[(k >> 2) * PQ + pq] |= ((cls_k >> 3) == (uint32_t)pq ? (cls_k & 7u) : 0x0Cu) << (8 * (k & 3));
                 } else if constexpr (kPackCols) bs[k >> 2] |= sym_k << (8 * (k & 3));
                 else bs[k] = sym_k;
-                H[k] = (kLocal || kSkew) ? 0 : (kSkewAffine ? open - ext : open + (int)j * ext);  // row 0: H[0][j+1] = open + j*ext
+                H[k] = (kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)j * ext);  // row 0: H[0][j+1] = open + j*ext (skew-affine: H^ + (open - ext), see `finish`)
                 if constexpr (kAffine) F[k] = kNegInf;
             }
             auto col_sym = [&](int k) -> uint32_t {
@@ -254,10 +254,10 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 else return bs[k];
             };
             // my right-edge outputs (what the lane above me consumes), row 0
-            int out_h = (kLocal || kSkew) ? 0 : (kSkewAffine ? open - ext : open + (int)(c0 + gl * W + W - 1) * ext);
+            int out_h = (kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)(c0 + gl * W + W - 1) * ext);
             int out_e = kNegInf;
             // diagonal input for my first active row: H[0][c0 + gl*W]
-            int prev_h = (!kLocal && !kSkew && (c0 + gl * W)) ? (kSkewAffine ? open - ext : open + (int)(c0 + gl * W - 1) * ext) : 0;
+            int prev_h = (!kLocal && !kSkew && (c0 + gl * W)) ? (kSkewAffine ? 2 * (open - ext) : open + (int)(c0 + gl * W - 1) * ext) : (kSkewAffine ? open - ext : 0);
             int bnd_next[4] = {0, 0, 0, 0}, ebnd_next[4] = {kNegInf, kNegInf, kNegInf, kNegInf};
             int bnd_cur[4], ebnd_cur[4];
             const bool read_bnd = pass > 0 && gl == 0;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = s0 + u;
                     // left-edge inputs: group lane 0 takes the DP boundary column, others the lane below
-                    int edge_h = pass == 0 ? ((kLocal || kSkew) ? 0 : (kSkewAffine ? open - ext : open + (int)s * ext)) : bnd_cur[u];  // H[s+1][c0]
+                    int edge_h = pass == 0 ? ((kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)s * ext)) : bnd_cur[u];  // H[s+1][c0]
                     int recv_h = dpp_shift_up<G>(edge_h, out_h);
                     int recv_e = kNegInf;
                     if constexpr (kAffine) recv_e = dpp_shift_up<G>(pass == 0 ? kNegInf : ebnd_cur[u], out_e);
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                     }
                     if (s - (uint32_t)gl < rows) {  // active: DP row r = s - gl + 1
                         int left = recv_h, e = recv_e;
-                        [[maybe_unused]] const int bias2 = -2 * ext;   // skewed models use substitution scores as sub - 2 ext (ext == open when linear)
+                        [[maybe_unused]] const int bias2 = -(open + ext);   // skewed models use substitution scores as sub - ext - open (= sub - 2g when linear; the affine strip holds H^ + (open - ext))
                         [[maybe_unused]] const int open_minus_ext = open - ext;
                         // A cell is computed in two halves one column apart: `cell(k, sc)` first adds the substitution score to
                         // the diagonal -- H[k - 1] of the previous row, still in its register -- and only then finishes cell
@@ -332,10 +332,16 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                             const int up = H[k];
                             int x, y;   // h = max3(t, x, y)
                             if constexpr (kSkewAffine) {
-                                int f = max(up + open_minus_ext, F[k]);
+                                // The strip holds H' = H^ + (open - ext): what E^ and F^ take their maxima with. One addition
+                                // per cell instead of two (E^ = max(H'left, E^left), F^ = max(H'up, F^up)); the diagonal's
+                                // surplus is folded into the substitution scores (sub - ext - open).
+                                int f = max(up, F[k]);
                                 F[k] = f;
-                                e = max(left + open_minus_ext, e);
-                                x = e; y = f;   // the score already carries the -2 ext bias
+                                e = max(left, e);
+                                const int h3 = max(max(t, e), f);
+                                asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open_minus_ext), "v"(after));
+                                left = H[k];
+                                return;
                             } else if constexpr (kAffine) {
                                 int f = max(up + open, F[k] + ext);
                                 F[k] = f;
@@ -422,6 +428,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                         for (int k = 0; k < W; ++k)
                             if ((uint32_t)k == kk) result = H[k];
                         if constexpr (kSkew || kSkewAffine) result += (int)(rows + cols) * ext;
+                        if constexpr (kSkewAffine) result -= open - ext;   // the strip holds H^ + (open - ext)
                         store_score(args.job, p, result);
                     }
                 }

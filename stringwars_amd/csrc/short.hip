@@ -365,6 +365,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         if (nxt.any) request(nxt, req_next);
         // ---- E: work items of 64 sorted pairs, heaviest (last) first, dealt by an LDS ticket ----------------------------
+        __builtin_amdgcn_s_setprio(0);
         {
             const uint32_t total = lds.total, items = (total + 63u) >> 6;
             for (;;) {
@@ -453,6 +454,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
 #endif
             }
         }
+        __builtin_amdgcn_s_setprio(3);   // the steps around E are chains of round trips and barriers: they go first, E fills the gaps
         SHORT_STAMP(4);   // E
         __syncthreads();
         SHORT_STAMP(5);   // waiting for the other waves' items

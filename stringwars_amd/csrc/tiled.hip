@@ -108,6 +108,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         const uint64_t base = (uint64_t)tile * targs.tile;
         const uint32_t count = (uint32_t)(args.job.pairs - base < targs.tile ? args.job.pairs - base : targs.tile);
         // ---- A: clear the counters ------------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(3);   // planning is a chain of round trips and barriers: it goes first, the work items of other workgroups fill the gaps
         for (int i = threadIdx.x; i < kTileBins / 2; i += kThreads) tl.bins[i] = 0;
         if (threadIdx.x < kTileClasses) tl.class_count[threadIdx.x] = 0;
         if (threadIdx.x == 0) tl.ticket = 0;
@@ -290,6 +291,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         for (int i = threadIdx.x; i < kTileBins / 2; i += kThreads) staged[i] = 0xFFFFFFFFu;   // "no distance here" (trivial pairs are stored directly)
         __syncthreads();
         // ---- G: work items, heaviest first (high class, long text), dealt by an LDS ticket --------------------------------
+        __builtin_amdgcn_s_setprio(0);
         {
             const uint32_t items_total = tl.item_prefix[64];
             const uint32_t my_prefix = tl.item_prefix[lane];

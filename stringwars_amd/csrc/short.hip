@@ -373,6 +373,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
                 if (lane == 0) t = __hip_atomic_fetch_add(&lds.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
                 if (t >= items) break;
+                __builtin_amdgcn_s_setprio(1);   // an item's head is three LDS round trips in a row
                 const uint32_t item = items - 1 - t;
                 const uint32_t e = item * 64 + (uint32_t)lane;
                 const bool active = e < total;
@@ -416,6 +417,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
                 short_lds_order();
                 // the recurrence runs in the low 16 bits of every lane (the looked-up word is shifted down); what a lane
                 // < 32 sees above bit 15 are its partner's rows, and nothing ever moves down across bit 16
+                __builtin_amdgcn_s_setprio(0);
                 uint32_t pv = 0xFFFFFFFFu, mv = 0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {

@@ -1027,7 +1027,7 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
         // Global alignment runs on scores relative to the all-gaps baseline (wavefront.hip): the table holds
         // cost - extend - open (= cost - 2 g for linear gaps; the affine kernel keeps H + (open - extend) in its strips and
         // takes the surplus back on the diagonal), which must still fit a signed byte (otherwise the 256x256 LDS path is used).
-        const int bias = -(extend + open);
+        const int bias = kind == 2 ? -open : -(extend + open);   // local alignment: no baseline to be relative to, but its strips hold H + open
         for (int i = 0; i < classes && fits; ++i)
             for (int j = 0; j < classes; ++j) {
                 int v = (int)matrix[rep[i] * 256 + rep[j]] + bias;
@@ -1040,8 +1040,7 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
             hipError_t err = hipMalloc((void **)&engine->class_dev, sizeof table);
             if (err == hipSuccess) err = hipMemcpy(engine->class_dev, table, sizeof table, hipMemcpyHostToDevice);
             if (err != hipSuccess) { swh_levenshtein_free((swh_levenshtein_t)engine); return fail_hip(error, HipFailure{err, "class table upload"}); }
-            if (kind == 1) { engine->scoring.class_table = engine->class_dev; engine->scoring.classes = (uint32_t)classes; }  // local alignment keeps the 256x256 path
-            // (measured: class-table cost rows for Smith-Waterman gain ~3 %; its cell is seven ops, the lookup a small part)
+            engine->scoring.class_table = engine->class_dev; engine->scoring.classes = (uint32_t)classes;
         }
     }
     *out = engine;

@@ -24,7 +24,8 @@ namespace swh {
 enum WfModel : int {
     kUniformLinear = 0, kMatrixLinear = 1, kMatrixAffine = 2, kMatrixLinearLocal = 3, kMatrixAffineLocal = 4,
     kClassLinear = 5, kClassAffine = 6,  // <= 32 symbol classes: cost rows live in registers, bytes picked by v_perm_b32
-    kUniformAffine = 7                   // match / mismatch by comparison (any symbol width), Gotoh gaps: general-cost Levenshtein
+    kUniformAffine = 7,                  // match / mismatch by comparison (any symbol width), Gotoh gaps: general-cost Levenshtein
+    kClassLinearLocal = 8, kClassAffineLocal = 9   // Smith-Waterman on the class tables (cost rows without the global models' bias)
 };
 constexpr size_t kClassLds = 32 * 32 + 256;  // 32x32 i8 class costs, then the byte -> class map
 
@@ -122,19 +123,22 @@ __device__ __forceinline__ void store_score(const Job &job, uint64_t p, int scor
 // group of four columns. Up to eight classes need one, 20 amino acids + "other" three, the full 32 classes four.
 template <typename Sym, int G, int W, int MODEL, int PQ = 4>
 __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls) {
-    constexpr bool kClass = MODEL == kClassLinear || MODEL == kClassAffine;
+    constexpr bool kClass = MODEL == kClassLinear || MODEL == kClassAffine || MODEL == kClassLinearLocal || MODEL == kClassAffineLocal;
     constexpr bool kMatrix = MODEL != kUniformLinear && MODEL != kUniformAffine && !kClass;   // per-cell LDS gather from the 256x256 table
-    constexpr bool kAffine = MODEL == kMatrixAffine || MODEL == kMatrixAffineLocal || MODEL == kClassAffine || MODEL == kUniformAffine;
+    constexpr bool kAffine = MODEL == kMatrixAffine || MODEL == kMatrixAffineLocal || MODEL == kClassAffine || MODEL == kUniformAffine || MODEL == kClassAffineLocal;
     static_assert(!kClass || W % 4 == 0, "class model handles columns four at a time");
     // Smith-Waterman (local) on the same tiles: boundaries and every cell are floored at 0 and the result is the
     // maximum over all cells (`SmithWatermanScores`, bench.rs:882-963).
-    constexpr bool kLocal = MODEL == kMatrixLinearLocal || MODEL == kMatrixAffineLocal;
+    constexpr bool kLocal = MODEL == kMatrixLinearLocal || MODEL == kMatrixAffineLocal || MODEL == kClassLinearLocal || MODEL == kClassAffineLocal;
     // Linear gaps (g = open = extend), global alignment: registers hold scores relative to the all-gaps baseline,
     //     U[r][k] = H[r][k] - (r + k) * g,   so that   U[r][k] = max3( U[r-1][k-1] + (sub - 2g),  U[r-1][k],  U[r][k-1] ):
     // ONE add and one max3 per cell (the up / left terms need no gap add at all), every boundary is zero, lanes
     // exchange U values as they are, and the result is U + (rows + cols) * g. The class model folds -2g into its
     // cost table, so its cell is `v_add_u32_sdwa (sext byte) ; v_max3_i32`.
     constexpr bool kSkew = !kAffine && !kLocal;
+    // Smith-Waterman on the class tables keeps H' = H + open in its strips (what the up / left terms need; the diagonal's
+    // surplus is folded into the table, which holds sub - open): one addition per cell instead of two.
+    constexpr bool kLocalBiased = kLocal && kClass;
     // Gotoh gets the same treatment relative to the extend cost: with X^ = X - (r + k) * ext for H, E and F,
     //     E^ = max(H^left + (open - ext), E^left)   F^ = max(H^up + (open - ext), F^up)   H^ = max3(H^diag + (sub - 2 ext), E^, F^)
     // -- six VALU instead of eight; the boundary row / column become the constant open - ext.
@@ -241,12 +245,15 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 uint32_t sym_k = j < cols ? (uint32_t)col_data[col0 + j] : 0u;
                 if constexpr (kClass) {
                     const uint32_t cls_k = lclass_of[sym_k & 0xffu];
+                    // (Smith-Waterman: columns right of the pair pick a zero byte everywhere = substitution `open` <= 0, so a
+                    // phantom cell never exceeds the real cell it descends from and the running maximum needs no column test)
+                    const bool picks = !kLocalBiased || j < cols;
 #pragma unroll
                     for (int pq = 0; pq < PQ; ++pq)
-                        sel[(k >> 2) * PQ + pq] |= ((cls_k >> 3) == (uint32_t)pq ? (cls_k & 7u) : 0x0Cu) << (8 * (k & 3));
+                        sel[(k >> 2) * PQ + pq] |= (picks && (cls_k >> 3) == (uint32_t)pq ? (cls_k & 7u) : 0x0Cu) << (8 * (k & 3));
                 } else if constexpr (kPackCols) bs[k >> 2] |= sym_k << (8 * (k & 3));
                 else bs[k] = sym_k;
-                H[k] = (kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)j * ext);  // row 0: H[0][j+1] = open + j*ext (skew-affine: H^ + (open - ext), see `finish`)
+                H[k] = kLocalBiased ? open : (kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)j * ext);  // row 0: H[0][j+1] = open + j*ext (skew-affine: H^ + (open - ext), see `finish`)
                 if constexpr (kAffine) F[k] = kNegInf;
             }
             auto col_sym = [&](int k) -> uint32_t {
@@ -254,10 +261,10 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 else return bs[k];
             };
             // my right-edge outputs (what the lane above me consumes), row 0
-            int out_h = (kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)(c0 + gl * W + W - 1) * ext);
+            int out_h = kLocalBiased ? open : (kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)(c0 + gl * W + W - 1) * ext);
             int out_e = kNegInf;
             // diagonal input for my first active row: H[0][c0 + gl*W]
-            int prev_h = (!kLocal && !kSkew && (c0 + gl * W)) ? (kSkewAffine ? 2 * (open - ext) : open + (int)(c0 + gl * W - 1) * ext) : (kSkewAffine ? open - ext : 0);
+            int prev_h = kLocalBiased ? open : (!kLocal && !kSkew && (c0 + gl * W)) ? (kSkewAffine ? 2 * (open - ext) : open + (int)(c0 + gl * W - 1) * ext) : (kSkewAffine ? open - ext : 0);
             int bnd_next[4] = {0, 0, 0, 0}, ebnd_next[4] = {kNegInf, kNegInf, kNegInf, kNegInf};
             int bnd_cur[4], ebnd_cur[4];
             const bool read_bnd = pass > 0 && gl == 0;
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t s = s0 + u;
                     // left-edge inputs: group lane 0 takes the DP boundary column, others the lane below
-                    int edge_h = pass == 0 ? ((kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)s * ext)) : bnd_cur[u];  // H[s+1][c0]
+                    int edge_h = pass == 0 ? (kLocalBiased ? open : (kLocal || kSkew) ? 0 : (kSkewAffine ? 2 * (open - ext) : open + (int)s * ext)) : bnd_cur[u];  // H[s+1][c0]
                     int recv_h = dpp_shift_up<G>(edge_h, out_h);
                     int recv_e = kNegInf;
                     if constexpr (kAffine) recv_e = dpp_shift_up<G>(pass == 0 ? kNegInf : ebnd_cur[u], out_e);
@@ -343,14 +350,18 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
                                 left = H[k];
                                 return;
                             } else if constexpr (kAffine) {
-                                int f = max(up + open, F[k] + ext);
+                                int f = max(kLocalBiased ? up : up + open, F[k] + ext);
                                 F[k] = f;
-                                e = max(left + open, e + ext);
+                                e = max(kLocalBiased ? left : left + open, e + ext);
                                 x = e; y = f;
                             } else {
-                                x = up + open; y = left + open;
+                                x = kLocalBiased ? up : up + open; y = kLocalBiased ? left : left + open;
                             }
-                            if constexpr (kLocal) {
+                            if constexpr (kLocalBiased) {
+                                const int h3 = max(max(max(t, x), y), 0);
+                                best = max(best, h3);   // (phantom columns cannot win: see the selectors)
+                                asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open), "v"(after));
+                            } else if constexpr (kLocal) {
                                 const int h3 = max(max(t, x), y);
                                 asm("v_max_i32 %0, 0, %1" : "+v"(H[k]) : "v"(h3), "v"(after));
                                 if (c0 + gl * W + k < cols) best = max(best, H[k]);  // phantom columns right of the pair do not count
@@ -457,7 +468,7 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
     constexpr int kGroups = 64 / G;
     uint32_t chunks = (count + kGroups - 1) / kGroups;
     uint32_t blocks = (chunks + 3) / 4;
-    size_t lds = (MODEL == kUniformLinear || MODEL == kUniformAffine) ? 0 : (MODEL == kClassLinear || MODEL == kClassAffine ? kClassLds : kMatrixLds);
+    size_t lds = (MODEL == kUniformLinear || MODEL == kUniformAffine) ? 0 : (MODEL == kClassLinear || MODEL == kClassAffine || MODEL == kClassLinearLocal || MODEL == kClassAffineLocal ? kClassLds : kMatrixLds);
     // persistent-ish grid: enough blocks to fill the chip several times over, waves stride over chunks
     uint32_t max_blocks = (uint32_t)scope->compute_units * (lds > 4096 ? 2 : 8);
     if (blocks > max_blocks) blocks = max_blocks;
@@ -536,7 +547,7 @@ static void launch_class_model(Scope *scope, const KernelArgs &args, const Plan 
         else if (w <= 32) launch_one<uint8_t, 64, 32, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w32");
         else if (w <= 48) launch_one<uint8_t, 64, 48, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w48");
         else if (w <= 64) launch_one<uint8_t, 64, 64, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w64");
-        else if constexpr (MODEL == kClassLinear) {
+        else if constexpr (MODEL == kClassLinear || MODEL == kClassLinearLocal) {
             if (w <= 80) launch_one<uint8_t, 64, 80, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w80");
             else launch_one<uint8_t, 64, 96, MODEL, PQ>(scope, args, cls, count, "wavefront_class_g64_w96");
         } else {
@@ -582,7 +593,19 @@ static void launch_wavefront_classes(Scope *scope, const KernelArgs &args, const
     } else if (!matrix) {
         if (!args.affine) launch_model<uint8_t, kUniformLinear>(scope, args, plan);
         else launch_model<uint8_t, kUniformAffine>(scope, args, plan);
-    } else if (args.scoring.class_table && !args.local) {
+    } else if (args.scoring.class_table && args.local) {
+        // Smith-Waterman on the class tables (the engine uploaded cost rows without a bias for it)
+        const uint32_t classes = args.scoring.classes ? args.scoring.classes : 32;
+        if (!args.affine) {
+            if (classes <= 8) launch_class_model<kClassLinearLocal, 1>(scope, args, plan);
+            else if (classes <= 24) launch_class_model<kClassLinearLocal, 3>(scope, args, plan);
+            else launch_class_model<kClassLinearLocal, 4>(scope, args, plan);
+        } else {
+            if (classes <= 8) launch_class_model<kClassAffineLocal, 1>(scope, args, plan);
+            else if (classes <= 24) launch_class_model<kClassAffineLocal, 3>(scope, args, plan);
+            else launch_class_model<kClassAffineLocal, 4>(scope, args, plan);
+        }
+    } else if (args.scoring.class_table) {
         // one v_perm per group of four columns and per 8 classes the matrix distinguishes
         const uint32_t classes = args.scoring.classes ? args.scoring.classes : 32;
         if (!args.affine) {

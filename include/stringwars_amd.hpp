@@ -22,6 +22,11 @@
 #include <unordered_set>
 #include <vector>
 
+#include <linux/perf_event.h>
+#include <sys/ioctl.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "stringwars_amd.h"
 #include "stringwars_amd_harness.h"
 
@@ -311,9 +316,53 @@ struct BenchBudget {
     }
 };
 
+/// Cycle and instruction counters of the calling thread around the measured region (utils.rs:589-620): two
+/// perf_event descriptors, user space only; whichever cannot be opened (perf_event_paranoid, containers) is
+/// simply absent and its columns are left out, as in the reference. For a GPU engine they describe the HOST side
+/// of the call -- the submit, the wait -- which is what the reference's counters see of its `<1gpu>` rows too.
+class HardwareCounters {
+    int cycles_ = -1, instructions_ = -1;
+    static int open_counter(uint64_t config) {
+        perf_event_attr attr;
+        std::memset(&attr, 0, sizeof attr);
+        attr.type = PERF_TYPE_HARDWARE;
+        attr.size = sizeof attr;
+        attr.config = config;
+        attr.disabled = 1;
+        attr.exclude_kernel = 1;
+        attr.exclude_hv = 1;
+        int fd = (int)syscall(SYS_perf_event_open, &attr, 0, -1, -1, 0);
+        if (fd < 0) return -1;
+        if (ioctl(fd, PERF_EVENT_IOC_RESET, 0) < 0 || ioctl(fd, PERF_EVENT_IOC_ENABLE, 0) < 0) { close(fd); return -1; }
+        return fd;
+    }
+    static bool stop_counter(int &fd, uint64_t &value) {
+        if (fd < 0) return false;
+        bool ok = ioctl(fd, PERF_EVENT_IOC_DISABLE, 0) == 0 && read(fd, &value, sizeof value) == (ssize_t)sizeof value;
+        close(fd);
+        fd = -1;
+        return ok;
+    }
+
+  public:
+    HardwareCounters() : cycles_(open_counter(PERF_COUNT_HW_CPU_CYCLES)), instructions_(open_counter(PERF_COUNT_HW_INSTRUCTIONS)) {}
+    HardwareCounters(const HardwareCounters &) = delete;
+    HardwareCounters &operator=(const HardwareCounters &) = delete;
+    ~HardwareCounters() {
+        if (cycles_ >= 0) close(cycles_);
+        if (instructions_ >= 0) close(instructions_);
+    }
+    void stop(bool &has_cycles, uint64_t &cycles, bool &has_instructions, uint64_t &instructions) {
+        has_cycles = stop_counter(cycles_, cycles);
+        has_instructions = stop_counter(instructions_, instructions);
+    }
+};
+
 struct BenchStats {
     double elapsed_seconds = 0;
     uint64_t calls = 0, elements = 0, bytes = 0;
+    bool has_cycles = false, has_instructions = false;
+    uint64_t cycles = 0, instructions = 0;
     std::vector<double> latencies_ns;
     /// index round(q * (n-1)) of the sorted samples (utils.rs:639-647)
     bool latency_quantile(double q, double &out) const {
@@ -324,8 +373,8 @@ struct BenchStats {
         out = sorted[std::min(rank, sorted.size() - 1)];
         return true;
     }
-    /// The canonical line `{:<42} {cols.join(" | ")}` (utils.rs:652-692). cyc/B and IPC columns need perf_event
-    /// counters, which the reference also omits when they are unavailable (utils.rs:601-605).
+    /// The canonical line `{:<42} {cols.join(" | ")}` (utils.rs:652-692); `cyc/B` and `IPC` appear when the
+    /// perf_event counters could be read (utils.rs:672-680) and are left out otherwise.
     std::string line(const std::string &name, ReportAs report) const {
         double seconds = std::max(elapsed_seconds, 1e-12);
         std::vector<std::string> columns;
@@ -340,6 +389,14 @@ struct BenchStats {
         }
         columns.push_back(buffer);
         if (report != ReportAs::Bytes && bytes > 0) { swh_format_si_rate(bps, "B/s", 0, buffer, sizeof buffer); columns.push_back(buffer); }
+        if (has_cycles && bytes > 0) {
+            std::snprintf(buffer, sizeof buffer, "%.2f cyc/B", (double)cycles / (double)bytes);
+            columns.push_back(buffer);
+        }
+        if (has_cycles && has_instructions && cycles > 0) {
+            std::snprintf(buffer, sizeof buffer, "IPC %.2f", (double)instructions / (double)cycles);
+            columns.push_back(buffer);
+        }
         double p50, p99;
         if (latency_quantile(0.5, p50) && latency_quantile(0.99, p99)) {
             char a[48], b[48];
@@ -367,6 +424,7 @@ inline BenchStats measure_throughput(const std::string &name, ReportAs report, c
     }
     const uint64_t kStrideCap = 1024;
     const double kTargetBetweenChecks = 1e-3;
+    HardwareCounters counters;
     auto start = clock::now();
     auto deadline = start + std::chrono::duration_cast<clock::duration>(std::chrono::duration<double>(budget.measure_seconds));
     uint64_t stride = 1, countdown = 1, calls_since_check = 0;
@@ -384,6 +442,7 @@ inline BenchStats measure_throughput(const std::string &name, ReportAs report, c
         last_check = now; calls_since_check = 0; countdown = stride;
     }
     stats.elapsed_seconds = std::chrono::duration<double>(clock::now() - start).count();
+    counters.stop(stats.has_cycles, stats.cycles, stats.has_instructions, stats.instructions);
     std::printf("%s\n", stats.line(name, report).c_str());
     std::fflush(stdout);
     return stats;

@@ -41,11 +41,48 @@ def test_filter_env_is_honoured():
     assert result.returncode == 0 and "STRINGWARS_FILTER active" in result.stderr or "SKIPPED" in result.stdout
 
 
+def test_report_line_with_and_without_hardware_counters(tmp_path):
+    """utils.rs:652-692: `cyc/B` and `IPC` sit between the byte rate and the latencies when the perf_event counters were
+    readable and are left out -- nothing else moves -- when they were not. A measured loop of host work prints whichever
+    this machine allows."""
+    source = tmp_path / "line.cpp"
+    source.write_text(r'''
+#include "stringwars_amd.hpp"
+using namespace swa::harness;
+int main() {
+    BenchStats stats;
+    stats.elapsed_seconds = 2.0; stats.calls = 4; stats.elements = 3000000000ull; stats.bytes = 500000;
+    std::printf("%s\n", stats.line("plain", ReportAs::Cups).c_str());
+    stats.has_cycles = true; stats.cycles = 1250000;
+    std::printf("%s\n", stats.line("cycles-only", ReportAs::Cups).c_str());
+    stats.has_instructions = true; stats.instructions = 2500000;
+    std::printf("%s\n", stats.line("both", ReportAs::Bytes).c_str());
+    volatile uint64_t sink = 0;
+    BenchStats looped = measure_throughput("host/loop", ReportAs::Bytes, BenchBudget{0.0, 0.05}, [&] {
+        for (int i = 0; i < 20000; ++i) sink = sink + (uint64_t)i * 3u;
+        return WorkUnits{20000, 20000};
+    });
+    return looped.calls > 0 && (!looped.has_cycles || looped.cycles > 0) ? 0 : 1;
+}
+''')
+    binary = tmp_path / "line"
+    library_dir = os.path.join(ROOT, "stringwars_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), str(source), "-o", str(binary), "-L", library_dir,
+                    "-lstringwars_amd", f"-Wl,-rpath,{library_dir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"], check=True, capture_output=True, text=True, timeout=300)
+    result = subprocess.run([str(binary)], capture_output=True, text=True, timeout=60)
+    assert result.returncode == 0, result.stderr
+    lines = result.stdout.splitlines()
+    assert lines[0] == f"{'plain':<42} 1.50 GCUPS | 250.00 kB/s"
+    assert lines[1] == f"{'cycles-only':<42} 1.50 GCUPS | 250.00 kB/s | 2.50 cyc/B"
+    assert lines[2] == f"{'both':<42} 250.00 kB/s | 2.50 cyc/B | IPC 2.00"
+    assert re.match(r"^host/loop\s+\d+\.\d\d [kMG]?B/s( \| \d+\.\d\d cyc/B)?( \| IPC \d+\.\d\d)? \| p50 .* p99 .*$", lines[3]), lines[3]
+
+
 @pytest.mark.gpu
 def test_rows_are_measured_on_gpu():
     result = run({"STRINGWARS_TIME": "0.3"})
     assert result.returncode == 0, result.stderr
-    line = re.compile(r"^(\S+)\s+\d+\.\d\d [kMG]?CUPS \| \d+\.\d\d [kMG]?B/s \| p50 \d+\.\d\d (ns|µs|ms|s) p99 \d+\.\d\d (ns|µs|ms|s)$")
+    line = re.compile(r"^(\S+)\s+\d+\.\d\d [kMG]?CUPS \| \d+\.\d\d [kMG]?B/s( \| \d+\.\d\d cyc/B)?( \| IPC \d+\.\d\d)? \| p50 \d+\.\d\d (ns|µs|ms|s) p99 \d+\.\d\d (ns|µs|ms|s)$")
     measured = {m.group(1) for m in map(line.match, result.stdout.splitlines()) if m}
     assert measured == set(ROWS) | {"uniform/stringwars_amd::levenshtein_pairs<prepared,1gpu>"}, result.stdout
     filtered = run({"STRINGWARS_TIME": "0.1", "STRINGWARS_FILTER": "uniform/.*pairs<1gpu"})

@@ -174,13 +174,20 @@ __device__ __forceinline__ void report_call_summary(const PlanPartial &mine, Pla
     auto &rcells = lds.rcells; auto &rsyms = lds.rsyms;
     auto &rmaxa = lds.rmaxa; auto &rmaxb = lds.rmaxb; auto &rshort = lds.rshort; auto &rviol = lds.rviol;
     if (threadIdx.x == 0) {
-        partials[blockIdx.x] = mine;
-        __threadfence();
-        lds.is_last = atomicAdd(done_counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+        // The row goes out as agent-scope atomic stores (written through to where every XCD sees them) and the counter is
+        // bumped once they are acknowledged: ordering by completion, without `__threadfence()` -- a release/acquire pair at
+        // agent scope writes back and invalidates the XCD's whole L2, here with the call's results freshly dirty in it, once
+        // per workgroup. The last workgroup reads the rows with agent-scope atomic loads.
+        unsigned long long *row = (unsigned long long *)&partials[blockIdx.x];
+        __hip_atomic_store(row + 0, mine.cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(row + 1, mine.symbols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(row + 2, (unsigned long long)mine.max_la | (unsigned long long)mine.max_lb << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(row + 3, (unsigned long long)mine.short_pairs | (unsigned long long)mine.pad << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds.is_last = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!lds.is_last) return;
-    __threadfence();
     unsigned long long cells = 0, syms = 0;
     uint32_t maxa = 0, maxb = 0, shorts = 0, viol = 0;
     for (uint32_t i = threadIdx.x; i < gridDim.x; i += blockDim.x) {

@@ -391,8 +391,13 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_fused(PrepassArgs args, F
     if (threadIdx.x == 0) {
         PlanPartial part{lcells, lsyms, lmaxa, lmaxb, lshorts, 0};
         if (args.direct_short) part = PlanPartial{0, 0, 0, 0, 0, 0};   // the sums are k_direct_short's
-        args.partials[blockIdx.x] = part;
-        __threadfence();
+        // ordering by completion instead of `__threadfence()` (an L2 write-back per workgroup): see report_call_summary
+        unsigned long long *row = (unsigned long long *)&args.partials[blockIdx.x];
+        __hip_atomic_store(row + 0, part.cells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(row + 1, part.symbols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(row + 2, (unsigned long long)part.max_la | (unsigned long long)part.max_lb << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(row + 3, (unsigned long long)part.short_pairs | (unsigned long long)part.pad << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         atomicAdd(fused.barrier, 1u);
         // Wait for the rest of the grid. The launch is sized to be resident as a whole, but a device shared with
         // somebody else's long-running kernels could still keep workgroups out: after ~2 s the launch gives up, the
@@ -409,8 +414,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_fused(PrepassArgs args, F
             __builtin_amdgcn_s_sleep(2);
         }
         if (!gave_up && __hip_atomic_load(fused.barrier + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) gave_up = true;
-        wave_sum[0] = gave_up ? 1u : 0u;
-        __threadfence();
+        wave_sum[0] = gave_up ? 1u : 0u;   // what crosses the barrier (key totals, partial rows) is read with agent-scope atomic loads
     }
     __syncthreads();
     if (wave_sum[0]) {   // an empty plan with the failure mark: the DP kernels find nothing to do, the host redoes the call

@@ -102,9 +102,14 @@ def roofline_of(kernel, kernel_ms, cells, algorithmic_bytes, workload, pairs, co
         if entry.get("fetch_kb") is not None and entry.get("write_kb") is not None:
             # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of the bytes
             # of wide reads (128-B requests tallied at 64 B) -> doubled; WRITE_SIZE as is. Infinity-Cache hits are counted.
+            # Calibrated on this box (profiles/r2/fetch_calibration.txt): x2 holds for coalesced streams and for windows in
+            # adjacent sectors, a lone 64-byte sector is fetched and tallied as 64 B (x1) -- kernels whose work items read
+            # scattered 16-byte windows lie between `vs_algorithmic_lower` (x1) and `vs_algorithmic` (x2).
             roof["traffic"] = int((entry["fetch_kb"] * 1024 * 2 + entry["write_kb"] * 1024) * scale)
+            lower = (entry["fetch_kb"] * 1024 + entry["write_kb"] * 1024) * scale
             roof["traffic_detail"] = {"fetch_kb_raw": round(entry["fetch_kb"] * scale, 1), "write_kb_raw": round(entry["write_kb"] * scale, 1),
-                                      "fetch_correction": 2, "vs_algorithmic": round(roof["traffic"] / max(algorithmic_bytes, 1), 2)}
+                                      "fetch_correction": 2, "vs_algorithmic": round(roof["traffic"] / max(algorithmic_bytes, 1), 2),
+                                      "vs_algorithmic_lower": round(lower / max(algorithmic_bytes, 1), 2)}
         roof["pmc_source"] = f"{entry.get('source')}; launches of {entry['pairs_per_launch']} pairs"
     else:
         roof["note"] = f"no PMC constants for {kernel}|{workload} in profiles/r2/pmc_constants.json"

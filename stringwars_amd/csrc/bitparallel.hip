@@ -141,7 +141,17 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
     uint32_t keep_mask = lane == 0 ? 0u : 0xFFFFFFFFu;
     asm volatile("" : "+v"(keep_mask));
 
-    for (uint32_t w = wave_id; w < ccount; w += waves_total) {
+    // One pair per wave and a few pairs per wave in all (10 K pairs of 4 KB on 4096 waves: 2.4): dealt round-robin, the last
+    // round is half empty. The waves draw the next pair from one global ticket instead -- longest texts first, so the list
+    // is scheduled longest-processing-time-first; a pair takes milliseconds, the ticket's 88 dequeues per microsecond
+    // (bitparallel.hip, top) are not in the way here.
+    for (uint32_t w = wave_id;; w += waves_total) {
+        if (args.ticket) {
+            uint32_t drawn = 0;
+            if (lane == 0) drawn = __hip_atomic_fetch_add(args.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+        }
+        if (w >= ccount) break;
         const uint64_t p = args.perm[cstart + (ccount - 1 - w)];   // longest texts first
         uint64_t a0, b0;
         uint32_t la, lb;
@@ -317,6 +327,12 @@ void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_hos
     const uint32_t max_blocks = (uint32_t)scope->compute_units * (bytes ? 4 : 5);
     if (blocks > max_blocks) blocks = max_blocks;
     // args.boundary / boundary_stride: the carry words, sized by the caller (bp_long_carry_words, <= 4096 waves)
+    static const bool round_robin = [] { const char *e = getenv("STRINGWARS_AMD_LONG_TICKET"); return e && atoi(e) == 0; }();   // comparison knob
+    args.ticket = nullptr;
+    if (!round_robin && count > blocks * (uint32_t)waves) {   // more pairs than waves: somebody gets a second one
+        args.ticket = scope->plan_leftover + 6;
+        SWH_HIP_CHECK(hipMemsetAsync(args.ticket, 0, 4, scope->stream));
+    }
     StampGuard guard(scope, bytes ? "bitparallel_long" : "bitparallel_long_u32");
     if (bytes) {
         opt_in_dynamic_lds(scope, (const void *)k_bitparallel_long<uint8_t>, lds);

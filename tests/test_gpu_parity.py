@@ -199,6 +199,37 @@ def test_random_levenshtein_long(sw, orc, scope, algorithm):
     assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
 
 
+def test_more_long_pairs_than_waves(sw, orc, scope):
+    """k_bitparallel_long runs one pair per wave on at most 4096 waves; with more pairs than that the waves draw them from a
+    ticket. 4500 pairs of 2.1-2.4 K symbols: symmetry and identity over the whole batch, 40 pairs against the oracle; and
+    the same through STRINGWARS_AMD_LONG_TICKET=0's round-robin list in a process of its own."""
+    rng = np.random.default_rng(4500)
+    count = 4500
+    la, lb = rng.integers(2100, 2400, count), rng.integers(2100, 2400, count)
+    items_a = [rng.integers(97, 101, n).astype(np.uint8) for n in la]
+    items_b = []
+    for i, n in enumerate(lb):
+        if i % 9 == 0:
+            items_b.append(items_a[i].copy())                 # identical
+        elif i % 3 == 0:
+            edited = items_a[i].copy()                        # related: substitutions, then cut or padded to length n
+            where = rng.integers(0, edited.size, 60)
+            edited[where] = rng.integers(97, 101, 60)
+            items_b.append(np.concatenate([edited, rng.integers(97, 101, max(0, n - edited.size)).astype(np.uint8)])[:max(n, 1)])
+        else:
+            items_b.append(rng.integers(97, 101, n).astype(np.uint8))
+    a, b = sw.Strs([x.tobytes() for x in items_a]), sw.Strs([x.tobytes() for x in items_b])
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    got, swapped = engine.pairs(a, b, scope), engine.pairs(b, a, scope)
+    assert (got == swapped).all()
+    assert (got[::9] == 0).all() and (got <= np.maximum(a.lengths, b.lengths)).all()
+    assert (got >= np.abs(a.lengths.astype(np.int64) - b.lengths.astype(np.int64))).all()
+    sample = np.sort(rng.choice(count, 40, replace=False))
+    sa, sb = sw.Strs([items_a[i].tobytes() for i in sample]), sw.Strs([items_b[i].tobytes() for i in sample])
+    assert got[sample].tolist() == orc.levenshtein_pairs(sa, sb, algo="hyyro").tolist()
+    assert engine.pairs(a, b, scope).tolist() == got.tolist()   # the ticket starts from zero again
+
+
 @pytest.mark.parametrize("utf8", [False, True])
 def test_patterns_longer_than_64_blocks(sw, orc, scope, utf8):
     """Both strings > 2048 symbols: the bit-parallel kernel walks the text once per pass of 64 blocks and hands the
@@ -1196,8 +1227,17 @@ def test_comparison_knobs_keep_parity():
         "        assert (engine.pairs(a, b, scope, bound=5) == np.minimum(want, 6)).all(), (workload, algorithm)\n"
         "ua, ub = sw.generate_pairs('utf8_lines', 700, seed=14)\n"
         "assert (sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm='bitparallel').pairs(ua, ub, scope) == oracle.levenshtein_pairs(ua, ub, utf8=True)).all()\n"
+        "rng = np.random.default_rng(5)\n"
+        "la = [rng.integers(97, 101, 2200).astype(np.uint8).tobytes() for _ in range(4300)]\n"
+        "lb = [x if i % 2 else rng.integers(97, 101, 2100).astype(np.uint8).tobytes() for i, x in enumerate(la)]\n"
+        "long_a, long_b = sw.Strs(la), sw.Strs(lb)\n"
+        "got = sw.LevenshteinDistances(capabilities=scope).pairs(long_a, long_b, scope)\n"
+        "assert (got[1::2] == 0).all() and (got[0::2] >= 100).all() and (got[0::2] <= 2200).all()\n"
+        "pick = list(range(0, 4300, 430))\n"
+        "assert got[pick].tolist() == oracle.levenshtein_pairs(sw.Strs([la[i] for i in pick]), sw.Strs([lb[i] for i in pick]), algo='hyyro').tolist()\n"
         "print('knobs ok')\n")
     env = dict(os.environ, STRINGWARS_AMD_BP_WAVES="4", STRINGWARS_AMD_TILED_WAVES="4", STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct",
+               STRINGWARS_AMD_LONG_TICKET="0",
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert done.returncode == 0 and "knobs ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])

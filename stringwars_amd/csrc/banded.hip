@@ -47,9 +47,12 @@ __device__ __forceinline__ uint32_t band_load_sym(const Sym *base, int idx, int 
 }
 
 // WBITS = number of live window bits (a multiple of 4, >= k + 1): bits [64 - WBITS, 63].
-// P = pairs per item. The recurrence is a serial chain per pair and one wave issues a dependent instruction only every
-// ~8.5 cycles, so a batch of 100 K pairs (1564 items of 64 = 1.5 waves per SIMD) ran at 11 SIMD-cycles per instruction.
-// Items of 32 pairs leave half of phase 2's lanes idle (+30 % instructions) but double the resident waves.
+// P = the most pairs an item can hold (LDS layout). The recurrence is a serial chain per pair and one wave issues a dependent
+// instruction only every ~8.5 cycles, so a batch of 100 K pairs (1564 items of 64 = 1.5 waves per SIMD) ran at 11 SIMD-cycles
+// per instruction. Items of 32 pairs leave half of phase 2's lanes idle (+30 % instructions) but double the resident waves.
+// How many pairs an item really gets is decided here, from the class's size: every wave of the launch the same number of
+// items (one, while the class fits) of the same size -- 100 K pairs on 4096 waves are items of 26, four waves on every SIMD,
+// where items of 32 left some SIMDs with four waves and some with three.
 template <typename Sym, int WBITS, int P>
 __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
     constexpr size_t kBandLdsPerWave = band_lds_per_wave(P);
@@ -62,15 +65,22 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
     uint32_t *stage = (uint32_t *)(wave_lds + (size_t)P * kBandPitch * 8 + (size_t)P * kBandParamWords * 4);  // [2][kBandStage]
 
     const uint32_t cstart = args.plan->class_start[cls], ccount = args.plan->class_count[cls];
-    const uint32_t chunks = (ccount + P - 1) / P;
     const uint32_t waves_total = gridDim.x * kBandWaves;
+    uint32_t per_item = P;
+    if (!args.band_fixed_items) {
+        const uint32_t rounds = (ccount + waves_total * P - 1) / (waves_total * P);
+        per_item = rounds ? (ccount + waves_total * rounds - 1) / (waves_total * rounds) : 2;
+        per_item = (per_item + 1) & ~1u;
+        per_item = per_item < 2 ? 2 : (per_item > (uint32_t)P ? (uint32_t)P : per_item);
+    }
+    const uint32_t chunks = (ccount + per_item - 1) / per_item;
     const uint32_t wave_id = blockIdx.x * kBandWaves + wave_in_block;
     const uint32_t k = args.job.bound;
 
     for (uint32_t item_rev = wave_id; item_rev < chunks; item_rev += waves_total) {
         const uint32_t item = chunks - 1 - item_rev;  // longest texts first
-        const uint32_t pidx = item * P + lane;
-        const bool have = lane < P && pidx < ccount;
+        const uint32_t pidx = item * per_item + lane;
+        const bool have = (uint32_t)lane < per_item && pidx < ccount;
         uint64_t p = 0, a0 = 0, b0 = 0;
         uint32_t la = 0, lb = 0;
         if (have) {
@@ -132,13 +142,13 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
             };
             issue_loads(half);
 #pragma unroll 1
-            for (int pp = 0; pp < P / 2; ++pp) {
+            for (int pp = 0; pp < (int)per_item / 2; ++pp) {
                 const int q = pp * 2 + half;               // pair slot served by my half of the wave
                 const uint32_t tsym = nxt_tsym;
 #pragma unroll
                 for (int r = 0; r < kStageLoads; ++r)
                     if (col + 32 * r < 32 + WBITS) win[col + 32 * r] = nxt_sym[r];
-                if (pp + 1 < P / 2) issue_loads(q + 2);
+                if (pp + 1 < (int)per_item / 2) issue_loads(q + 2);
                 wave_lds_fence();  // every lane reads symbols its neighbours staged
                 // hits: window symbol j <-> band bit 64 - WBITS + j. Built as kSegs independent accumulators
                 // (seg = seg * 2 + (symbol == text symbol), one compare + one add-with-carry per symbol, most
@@ -219,7 +229,9 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
 template <typename Sym, int WBITS, int P>
 static void launch_banded_items(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     const size_t lds = kBandWaves * band_lds_per_wave(P);
-    uint64_t items = (pairs + P - 1) / P;
+    // the kernel sizes its items from the class's real size (known on the device only); the grid is the whole device
+    // unless the batch is too small to give every wave two pairs
+    uint64_t items = args.band_fixed_items ? (pairs + P - 1) / P : (pairs + 1) / 2;
     uint64_t blocks64 = (items + kBandWaves - 1) / kBandWaves;
     uint32_t max_blocks = (uint32_t)scope->compute_units * (uint32_t)(160 * 1024 / lds);   // 77 KB (P = 64) / 41 KB per block
     uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
@@ -231,16 +243,21 @@ static void launch_banded_items(Scope *scope, const KernelArgs &args, uint64_t p
 
 template <typename Sym, int WBITS>
 static void launch_banded_one(Scope *scope, const KernelArgs &args, uint64_t pairs) {
-    // `pairs` bounds the banded class from above (its size is only known on the device at this point): below eight
-    // 64-pair items per CU the half-size items win
-    if (pairs < (uint64_t)64 * 8 * scope->compute_units) launch_banded_items<Sym, WBITS, 32>(scope, args, pairs);
-    else launch_banded_items<Sym, WBITS, 64>(scope, args, pairs);
+    // Items of at most 32 pairs: 40 KB of LDS per workgroup, four workgroups = sixteen waves per CU. Measured on C3's 100 K
+    // pairs with the items sized by the kernel: capacity 20 / 24 / 32 / 40 / 64 (6 / 5 / 4 / 3 / 2 workgroups
+    // per CU): 0.356 / 0.344 / 0.331 / 0.351 / 0.450 ms; at 150 K - 800 K pairs 32 beats 64 by 13-17 % as well.
+    // STRINGWARS_AMD_BAND_CAP=64: the large items (comparison knob).
+    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_BAND_CAP"); return e ? atoi(e) : 0; }();
+    if (forced == 64) launch_banded_items<Sym, WBITS, 64>(scope, args, pairs);
+    else launch_banded_items<Sym, WBITS, 32>(scope, args, pairs);
 }
 
 void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     const uint32_t k = args.job.bound;
     KernelArgs a = args;
     a.boundary = nullptr;
+    static const bool fixed_items = [] { const char *e = getenv("STRINGWARS_AMD_BAND_ITEMS"); return e && e[0] == 'f'; }();   // "fixed": comparison knob
+    a.band_fixed_items = fixed_items ? 1u : 0u;
 #define SWH_BAND(SYM)                                                     \
     if (k + 1 <= 8) launch_banded_one<SYM, 8>(scope, a, pairs);           \
     else if (k + 1 <= 16) launch_banded_one<SYM, 16>(scope, a, pairs);    \

@@ -399,6 +399,7 @@ struct KernelArgs {
     uint32_t local;         // Smith-Waterman: local alignment (floors at 0, maximum over all cells)
     int32_t *boundary;      // scratch for multi-pass wavefront
     uint64_t boundary_stride;  // int32 elements per group slot
+    uint32_t band_fixed_items;   // k_banded: items of exactly P pairs (comparison knob STRINGWARS_AMD_BAND_ITEMS=fixed)
     uint32_t *ticket;       // k_bitparallel_long: the launch's next pair (zeroed before the launch); null: pairs dealt round-robin
 };
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs);

@@ -1237,7 +1237,7 @@ def test_comparison_knobs_keep_parity():
         "assert got[pick].tolist() == oracle.levenshtein_pairs(sw.Strs([la[i] for i in pick]), sw.Strs([lb[i] for i in pick]), algo='hyyro').tolist()\n"
         "print('knobs ok')\n")
     env = dict(os.environ, STRINGWARS_AMD_BP_WAVES="4", STRINGWARS_AMD_TILED_WAVES="4", STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct",
-               STRINGWARS_AMD_LONG_TICKET="0",
+               STRINGWARS_AMD_LONG_TICKET="0", STRINGWARS_AMD_BAND_ITEMS="fixed", STRINGWARS_AMD_BAND_CAP="64",
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert done.returncode == 0 and "knobs ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])

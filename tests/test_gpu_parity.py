@@ -1187,6 +1187,24 @@ def test_config5_short_words_large(sw, orc, scope):
     assert (got == want).all()
 
 
+def test_config5_one_gpu_slice_at_full_size(sw, orc, scope):
+    """Config C5 is 100 M word pairs over 8 GPUs: one GPU's slice, 12.5 M pairs, at full size. Too many for the oracle, so:
+    three independent routes (k_short_tiled, the general tiled kernel, the planned path with k_direct_short) must agree on
+    every pair, the distance must be symmetric and inside its length bounds, and 1 % of the pairs go to the oracle."""
+    count = 12_500_000
+    a, b = sw.generate_pairs("short_words", count, seed=42)
+    pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
+    got = sw.LevenshteinDistances(capabilities=scope).pairs(pa, pb, scope)
+    for algorithm in ("tiled", "bitparallel"):
+        other = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm).pairs(pa, pb, scope)
+        assert (other == got).all(), algorithm
+    assert (sw.LevenshteinDistances(capabilities=scope).pairs(pb, pa, scope) == got).all()
+    la, lb = a.lengths.astype(np.int64), b.lengths.astype(np.int64)
+    assert (got >= np.abs(la - lb)).all() and (got <= np.maximum(la, lb)).all()
+    sample = np.arange(0, count, 100)
+    assert (got[sample] == orc.levenshtein_pairs(_pick(sw, a, sample), _pick(sw, b, sample), algo="hyyro")).all()
+
+
 def test_fused_planner_gives_up_instead_of_hanging():
     """The one-launch planner waits at a grid-wide barrier; if its grid cannot be resident as a whole (forced here by
     oversubscribing it) it must give up after its time-out, and the call must be redone with the three-pass planner --

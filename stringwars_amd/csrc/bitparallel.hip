@@ -19,9 +19,10 @@
 //
 // Distance = n + popcount(Pv) - popcount(Mv) summed over the pair's blocks after the last text
 // symbol (D[m][n] = D[0][n] + sum of the vertical deltas of the last column): no per-step score.
-// Work items (chunks of floor(64/G) same-class pairs, sorted by text length by the pre-pass) are
-// dealt round-robin to waves -- no atomics: one ticket word saturates near 88 dequeues/us
-// (MI355X_MICROARCH.md "dequeue"), slower than the DP itself.
+// Work items (chunks of floor(64/G) same-class pairs, sorted by text length by the pre-pass) are dealt to
+// workgroups by index and inside a workgroup by an LDS ticket (bp_run below). Not by one global ticket: a
+// single word saturates near 88 dequeues/us (MI355X_MICROARCH.md "dequeue"), slower than the DP itself on
+// short items -- k_bitparallel_long, whose items take milliseconds, does use one.
 // Definition matched: `rapidfuzz::distance::levenshtein::distance` (bench.rs:416-419).
 #include "bp_item.hpp"
 

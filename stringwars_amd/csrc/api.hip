@@ -543,7 +543,10 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         // overlaps it.
         SWH_HIP_CHECK(hipEventRecord(scope->plan_ready, stream));
         if (pre.banded) launch_banded(scope, k, pairs);
-        if (bitpar_ok) launch_bitparallel(scope, k, pairs);
+        // Bounded calls: the banded kernel keeps the device busy while the plan travels, so the bit-parallel launch waits until
+        // the host knows whether it has any pairs at all (C3: none -- an empty launch and its gap were 8 us of a 0.4 ms call).
+        const bool bitpar_deferred = bitpar_ok && pre.banded;
+        if (bitpar_ok && !bitpar_deferred) launch_bitparallel(scope, k, pairs);
         Plan &plan = *scope->plan_host;
         SWH_HIP_CHECK(hipStreamWaitEvent(scope->side_stream, scope->plan_ready, 0));
         SWH_HIP_CHECK(hipMemcpyAsync(&plan, plan_dev, sizeof(Plan), hipMemcpyDeviceToHost, scope->side_stream));
@@ -564,6 +567,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         scope->hint_max_la = plan.max_la; scope->hint_max_lb = plan.max_lb;
         if (*invalid_host) return invalid_utf8();
 
+        if (bitpar_deferred) {
+            bool any_bp = false;
+            for (int c = kClassBp0; c < kClassBp0 + 64; ++c) any_bp |= plan.class_count[c] != 0;
+            if (any_bp) launch_bitparallel(scope, k, pairs);
+        }
         // patterns of more than 64 blocks: multi-pass bit-parallel kernel, carries between passes in scratch
         if (bitpar_ok && plan.class_count[kClassBpLong]) {
             const uint64_t stride = bp_long_carry_words(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb);

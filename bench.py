@@ -53,8 +53,8 @@ CONFIGS = {
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     p.add_argument("--workload", default=None, help="override the config's synthetic workload")
     p.add_argument("--pairs", type=int, default=None, help="pairs per GPU (weak configs) / in total (strong configs)")

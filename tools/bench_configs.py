@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--algorithm", default="auto")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--warm-seconds", type=float, default=0.3, help="untimed calls before the measured ones (clock ramp)")
     ap.add_argument("--offsets", default="u64", choices=["u32", "u64"])
     ap.add_argument("--prepared", action="store_true", help="prepare the tapes once (swh_tape_prepare_*) outside the timed calls")
     args = ap.parse_args()
@@ -68,6 +69,10 @@ def main():
             engine = cls(capabilities=scope, algorithm=args.algorithm)
             call = lambda: engine.pairs(da, db, scope, bound=cfg.get("bound"), out=out)
         call()
+        # the device takes a few hundred milliseconds of work to reach its clocks: warm up by the clock, not by a count
+        warm_until = time.perf_counter() + args.warm_seconds
+        while time.perf_counter() < warm_until:
+            call()
         scope.set_profiling(True)
         walls, timings = [], []
         for _ in range(args.repeats):

@@ -9,18 +9,18 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$REPO"
 # 1. the bench lines (C2 headline; C5 at 20 M pairs, the single-GPU slice of 100 M / 8 rounded up, and at the full 100 M)
 timeout 300 python3 bench.py > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
-timeout 300 python3 bench.py --config c5 --pairs 20000000 --steps 10 > "$OUT/bench_c5_20m.json" 2> "$OUT/bench_c5_20m.err"
-timeout 400 python3 bench.py --config c5 --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5_100m.json" 2> "$OUT/bench_c5_100m.err"
+timeout 300 python3 bench.py --config c5 --pairs 20000000 > "$OUT/bench_c5_20m.json" 2> "$OUT/bench_c5_20m.err"
+timeout 400 python3 bench.py --config c5 --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/bench_c5_100m.json" 2> "$OUT/bench_c5_100m.err"
 # 2. per-config tables: raw tapes (hint route), prepared tapes
-timeout 300 python3 tools/bench_configs.py --configs c1,c2,c3,c3u,c3b,c4,c4a,c4b,c4l,c5 --repeats 5 > "$OUT/configs_table.jsonl" 2> "$OUT/configs.err"
-timeout 300 python3 tools/bench_configs.py --configs c1,c2,c3,c3u,c3b,c4,c4a,c4b,c4l,c5 --repeats 5 --prepared --offsets u32 >> "$OUT/configs_table.jsonl" 2>> "$OUT/configs.err"
-timeout 300 python3 tools/bench_configs.py --configs c2 --repeats 5 --prepared --offsets u32 --algorithm bitparallel >> "$OUT/configs_table.jsonl" 2>> "$OUT/configs.err"
+timeout 300 python3 tools/bench_configs.py --configs c1,c2,c3,c3u,c3b,c4,c4a,c4b,c4l,c5 --repeats 9 > "$OUT/configs_table.jsonl" 2> "$OUT/configs.err"
+timeout 300 python3 tools/bench_configs.py --configs c1,c2,c3,c3u,c3b,c4,c4a,c4b,c4l,c5 --repeats 9 --prepared --offsets u32 >> "$OUT/configs_table.jsonl" 2>> "$OUT/configs.err"
+timeout 300 python3 tools/bench_configs.py --configs c2 --repeats 9 --prepared --offsets u32 --algorithm bitparallel >> "$OUT/configs_table.jsonl" 2>> "$OUT/configs.err"
 timeout 300 python3 tools/bench_cross.py > "$OUT/crossproduct_table.jsonl" 2> "$OUT/cross.err"
 # 3. rocprofv3 --kernel-trace --stats of the bench command and of the other configs
 cd /tmp && export TMPDIR=/tmp
 stats() { name=$1; shift; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rp_$name" -o "$name" -- python3 "$@" > "$OUT/rp_$name.log" 2>&1; cp "$OUT/rp_$name/${name}_kernel_stats.csv" "$OUT/${name}_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/rp_$name"; }
 stats bench_c2 "$REPO/bench.py" --no-cpu-baseline
-stats bench_c5 "$REPO/bench.py" --config c5 --pairs 20000000 --steps 10 --no-cpu-baseline
+stats bench_c5 "$REPO/bench.py" --config c5 --pairs 20000000 --no-cpu-baseline
 stats config_c3 "$REPO/tools/bench_configs.py" --configs c3 --repeats 10 --prepared
 stats config_c4_linear "$REPO/tools/bench_configs.py" --configs c4 --repeats 5
 stats config_c4_affine "$REPO/tools/bench_configs.py" --configs c4a --repeats 5

@@ -55,6 +55,7 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steps before the W warm-up steps, by the clock: brings an idle device to its clocks (0: none)")
     p.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     p.add_argument("--workload", default=None, help="override the config's synthetic workload")
     p.add_argument("--pairs", type=int, default=None, help="pairs per GPU (weak configs) / in total (strong configs)")
@@ -312,6 +313,25 @@ def main():
     # `value`: K steps enqueued asynchronously on two internal lanes (host-side work of step i+1 overlaps step i)
     scope.set_async(True)
     scope.set_pipelined(True)
+    # An idle MI355X takes a few hundred milliseconds of work to reach its clocks (profiles/r2: the same 20 steps measure
+    # 8 % apart right after start-up and after a second of calls). The device is brought there first -- every rank runs the same
+    # number of untimed steps, the collective included --, then come the W warm-up steps and the K timed ones.
+    if args.prewarm_seconds > 0:
+        fence()
+        start = time.perf_counter()
+        for _ in range(8):                      # what a step costs here
+            step()
+        fence()
+        per_step = (time.perf_counter() - start) / 8
+        extra = int(min(max(args.prewarm_seconds / max(per_step, 1e-6) - 8, 0), 100000))
+        if world > 1:                           # the same count on every rank: a step contains the collective
+            agreed = torch.tensor([extra], dtype=torch.int64, device=comm_device)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
+            extra = int(agreed.item())
+        for i in range(extra):
+            step()
+            if i % 64 == 63:
+                fence()
     for _ in range(args.warmup):
         step()
     elapsed = timed_region(args.steps)
@@ -411,7 +431,7 @@ def main():
                        "value_is": "rate of the K timed steps, calls enqueued asynchronously on two internal lanes",
                        "value_sync_call_is": "rank 0's shard, K synchronous calls timed by the host (the reference's compute_into metric, utils.rs:721-799)",
                        "pairs_per_gpu": pairs, "pairs_total": total_pairs, "cells_per_gpu": cells, "algorithm": args.algorithm,
-                       "offsets": str(offsets_dtype), "pieces_per_step": len(pieces) if strong else 1,
+                       "offsets": str(offsets_dtype), "pieces_per_step": len(pieces) if strong else 1, "device_prewarm_s": args.prewarm_seconds,
                        "collective": ("ncclSend/ncclRecv group per piece to rank 0 (variable-size gather of u32 distances)" if strong
                                       else "RCCL gather of u32 distances to rank 0") if world > 1 else "none",
                        "seed": args.seed},

@@ -28,12 +28,12 @@ stats config_c4_256class "$REPO/tools/bench_configs.py" --configs c4b --repeats 
 # 4. PMC passes (SQ_*, FETCH_SIZE, WRITE_SIZE in runs of their own) -> pmc_constants.json
 cd "$REPO"
 pmc() { name=$1; shift; mkdir -p "$OUT/pmc_$name"; ( cd /tmp; for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do tag=$(echo $set | cut -d' ' -f1); timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/pmc_$name" -o "$tag" -- python3 "$@" > "$OUT/pmc_$name/$tag.log" 2>&1; done ); }
-pmc c2 "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1
-python3 tools/pmc_constants.py "$OUT/pmc_c2" --workload tokens64 --pairs 1000000 --out "$OUT/pmc_constants.json" --source "rocprofv3 --pmc passes over 'bench.py --no-cpu-baseline --steps 3 --warmup 1' (tools/refresh_profiles.sh)"
-pmc c2_planned "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --algorithm bitparallel
+pmc c2 "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --prewarm-seconds 0
+python3 tools/pmc_constants.py "$OUT/pmc_c2" --workload tokens64 --pairs 1000000 --out "$OUT/pmc_constants.json" --source "rocprofv3 --pmc passes over 'bench.py --no-cpu-baseline --steps 3 --warmup 1 --prewarm-seconds 0' (tools/refresh_profiles.sh)"
+pmc c2_planned "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --prewarm-seconds 0 --algorithm bitparallel
 python3 tools/pmc_constants.py "$OUT/pmc_c2_planned" --workload tokens64 --pairs 1000000 --out "$OUT/pmc_constants.json" --source "the same with --algorithm bitparallel"
-pmc c5 "$REPO/bench.py" --config c5 --pairs 20000000 --chunks 1 --steps 3 --warmup 1 --no-cpu-baseline
-python3 tools/pmc_constants.py "$OUT/pmc_c5" --workload short_words --pairs 20000000 --out "$OUT/pmc_constants.json" --source "rocprofv3 --pmc passes over 'bench.py --config c5 --pairs 20000000 --chunks 1 --steps 3 --warmup 1 --no-cpu-baseline'"
+pmc c5 "$REPO/bench.py" --config c5 --pairs 20000000 --chunks 1 --steps 3 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline
+python3 tools/pmc_constants.py "$OUT/pmc_c5" --workload short_words --pairs 20000000 --out "$OUT/pmc_constants.json" --source "rocprofv3 --pmc passes over 'bench.py --config c5 --pairs 20000000 --chunks 1 --steps 3 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline'"
 pmc c4_linear "$REPO/tools/bench_configs.py" --configs c4 --repeats 2
 pmc c4_affine "$REPO/tools/bench_configs.py" --configs c4a --repeats 2
 pmc c4_256class "$REPO/tools/bench_configs.py" --configs c4b --repeats 2

@@ -8,7 +8,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for tile in 0 256 512; do
     if [ "$tile" = 0 ]; then unset STRINGWARS_AMD_TILE; else export STRINGWARS_AMD_TILE=$tile; fi
-    timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/t$tile" -o fetch -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/t$tile.log" 2>&1
+    timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/t$tile" -o fetch -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --prewarm-seconds 0 > "$OUT/t$tile.log" 2>&1
     timeout 200 python3 "$REPO/bench.py" --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/t$tile.json"
     python3 - "$OUT" "$tile" <<'PY' >> "$OUT/summary.txt"
 import csv, glob, json, sys

@@ -16,6 +16,10 @@ algorithm skips. `value` is the rate of the K timed steps, enqueued asynchronous
 like-for-like figure for the reference's synchronous `compute_into` (bench.rs:478-486, utils.rs:721-799) is
 `value_sync_call`. One JSON line is printed by rank 0.
 
+Order of a run: data, tapes, `--prewarm-seconds` (default 0.5) of untimed steps that bring an idle device to its clocks
+(`config.device_prewarm_s`; the same count on every rank), the W warm-up steps, the K timed steps between
+barrier + synchronize on both sides, then the checks (oracle, checksums), the synchronous calls, the CPU rows.
+
     python bench.py                       # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W

@@ -329,7 +329,10 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
                 d0[k] = pat | (txt << 16);
                 d1[k] = m | (n << 8) | (q << 16);
                 if (q < len && longer <= (uint32_t)kShortMaxLen) {
-                    if (cut_off || n == 0) {
+                    // nothing left on one side: m insertions. One symbol left on the longer side, hence on both (n <= m): they
+                    // differ -- equal ones would have gone with the prefix or the suffix, whose windows cover all 16 bytes --, one
+                    // substitution, m again. (5.6 % of the synthetic words, beside the 24 % with an empty side.)
+                    if (cut_off || n == 0 || m == 1) {
                         lds.staged[q] = (uint8_t)(cut_off ? bound + 1 : clamp_bound(m, bound));
                     } else {
                         key[k] = (n - 1) * 16 + (m - 1);

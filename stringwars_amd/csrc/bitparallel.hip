@@ -363,10 +363,14 @@ static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_
 }
 
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs) {
-    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_BP_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4 or 16
+    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_BP_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4 (both widths), 10 (code points)
     if (args.sym_bytes == 4) {
         if (forced == 4) launch_bitparallel_sym<uint32_t, BpTraits<uint32_t>::kWaves>(scope, args, pairs);
-        else launch_bitparallel_sym<uint32_t, 10>(scope, args, pairs);   // 14 KB of tables per wave: ten waves are what a CU holds
+        else if (forced == 10) launch_bitparallel_sym<uint32_t, 10>(scope, args, pairs);
+        // 14.25 KB of tables and accumulators per wave: eleven waves are what a CU's 160 KB hold, with 2.9 KB to spare. Code points
+        // are latency-bound (seven dependent look-ups per column): 8 / 10 / 11 waves measure 1.31 / 1.13 / 1.05 ms on C3's lines.
+        // (Bytes are issue-bound: two workgroups of nine waves lose 8 % against the one of sixteen.)
+        else launch_bitparallel_sym<uint32_t, 11>(scope, args, pairs);
     } else if (forced == 4) launch_bitparallel_sym<uint8_t, 4>(scope, args, pairs);
     else launch_bitparallel_sym<uint8_t, 16>(scope, args, pairs);
 }

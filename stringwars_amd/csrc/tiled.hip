@@ -438,10 +438,13 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
 }
 
 void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text) {
-    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_TILED_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4 or 8
-    if (args.sym_bytes == 4) {   // code points: 14.6 KB of tables per wave -- eight waves fill a CU (two-wave workgroups, five per CU: STRINGWARS_AMD_TILED_WAVES=4)
+    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_TILED_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4; code points also 8
+    if (args.sym_bytes == 4) {   // code points: 14.25 KB of tables per wave -- one workgroup of ten waves fills a CU next to the tile's lists
+                                 // (latency-bound like the planned kernel: 8 -> 10 waves is 8 % on token-sized strings; STRINGWARS_AMD_TILED_WAVES=8 / =4:
+                                 // eight waves; two-wave workgroups, five per CU)
         if (forced == 4) launch_tiled_sym<uint32_t, BpTraits<uint32_t>::kWaves>(scope, args, pairs, longest_text);
-        else launch_tiled_sym<uint32_t, 8>(scope, args, pairs, longest_text);
+        else if (forced == 8) launch_tiled_sym<uint32_t, 8>(scope, args, pairs, longest_text);
+        else launch_tiled_sym<uint32_t, 10>(scope, args, pairs, longest_text);
     }
     else if (forced == 4) launch_tiled_sym<uint8_t, 4>(scope, args, pairs, longest_text);
     else launch_tiled_sym<uint8_t, 8>(scope, args, pairs, longest_text);

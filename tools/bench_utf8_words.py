@@ -27,6 +27,10 @@ got = eng.pairs(pa, pb, scope)
 want = oracle.levenshtein_pairs(sw.Strs(A[:20000]), sw.Strs(B[:20000]), utf8=True)
 assert (got[:20000] == want).all()
 scope.set_profiling(True)
+import time
+until = time.perf_counter() + 0.3   # clocks
+while time.perf_counter() < until:
+    eng.pairs(pa, pb, scope)
 best = 1e9
 for _ in range(7):
     eng.pairs(pa, pb, scope); t = scope.last_timing(); best = min(best, t["compute_ms"])

@@ -1227,7 +1227,9 @@ def test_fused_planner_gives_up_instead_of_hanging():
     assert done.returncode == 0 and "gave-up ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
 
 
-def test_comparison_knobs_keep_parity():
+@pytest.mark.parametrize("shapes", [{"STRINGWARS_AMD_BP_WAVES": "4", "STRINGWARS_AMD_TILED_WAVES": "4"},
+                                    {"STRINGWARS_AMD_BP_WAVES": "10", "STRINGWARS_AMD_TILED_WAVES": "8"}])
+def test_comparison_knobs_keep_parity(shapes):
     """The environment knobs DESIGN.md quotes A/B numbers from select other launch shapes of the same kernels (four-wave
     workgroups with fixed item lists, no affix cut, k_direct_short for every word-sized batch): each must stay bit-exact."""
     import subprocess
@@ -1243,6 +1245,8 @@ def test_comparison_knobs_keep_parity():
         "        engine = sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm)\n"
         "        assert (engine.pairs(pa, pb, scope) == want).all(), (workload, algorithm)\n"
         "        assert (engine.pairs(a, b, scope, bound=5) == np.minimum(want, 6)).all(), (workload, algorithm)\n"
+        "ta, tb = sw.Strs([('\u0416\u4e2d\U0001F600a' * (3 + i % 17))[: 5 + i % 60] for i in range(30000)]), sw.Strs([('\u4e2d\u0416a\U0001F600' * (2 + i % 19))[: 4 + i % 70] for i in range(30000)])\n"
+        "assert (sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm='tiled').pairs(ta, tb, scope) == oracle.levenshtein_pairs(ta, tb, utf8=True)).all()\n"
         "ua, ub = sw.generate_pairs('utf8_lines', 700, seed=14)\n"
         "assert (sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm='bitparallel').pairs(ua, ub, scope) == oracle.levenshtein_pairs(ua, ub, utf8=True)).all()\n"
         "rng = np.random.default_rng(5)\n"
@@ -1254,7 +1258,7 @@ def test_comparison_knobs_keep_parity():
         "pick = list(range(0, 4300, 430))\n"
         "assert got[pick].tolist() == oracle.levenshtein_pairs(sw.Strs([la[i] for i in pick]), sw.Strs([lb[i] for i in pick]), algo='hyyro').tolist()\n"
         "print('knobs ok')\n")
-    env = dict(os.environ, STRINGWARS_AMD_BP_WAVES="4", STRINGWARS_AMD_TILED_WAVES="4", STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct",
+    env = dict(os.environ, **shapes, STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct",
                STRINGWARS_AMD_LONG_TICKET="0", STRINGWARS_AMD_BAND_ITEMS="fixed", STRINGWARS_AMD_BAND_CAP="64",
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

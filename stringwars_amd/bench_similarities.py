@@ -90,6 +90,29 @@ def main(argv=None) -> int:
             H.measure(name, lambda: engine.pairs(col_a, col_b, scope, out=out), cells, total_bytes, warmup, time_limit)
             print(f"  {name} checksum={int(out.sum())}", file=sys.stderr)                  # bench.py:305
 
+    # Bounded Levenshtein: out[i] = min(d, k + 1); k from STRINGWARS_ERROR_BOUND (the reference's only trace of
+    # a bound, README.md:311; STRINGWARS_BOUND is an alias), default 32. Bytes and code points, every pair checked against
+    # the unbounded distance of the same engine.
+    bound = H.get_env_parsed("STRINGWARS_ERROR_BOUND", H.get_env_parsed("STRINGWARS_BOUND", 32))
+    for label, cls, lengths in ((f"stringwars_amd.levenshtein_pairs<k={bound},1gpu>", swa.LevenshteinDistances, nbytes),
+                                (f"stringwars_amd.edit_distance<k={bound},1gpu>", swa.LevenshteinDistancesUTF8, codepoints)):
+        if not H.should_run(f"uniform/{label}", pattern):
+            continue
+        if scope is None:
+            print(f"{label}: SKIPPED ({scope_error})")
+            continue
+        half = len(tokens) // 2
+        col_a, col_b = swa.Strs(tokens[:half]), swa.Strs(tokens[half:2 * half])
+        engine = cls(capabilities=scope)
+        out = np.zeros(half, dtype=np.uint32)
+        cells = int((lengths[:half] * lengths[half:2 * half]).sum())
+        H.measure(label, lambda: engine.pairs(col_a, col_b, scope, bound=bound, out=out), cells, int(nbytes[:2 * half].sum()), warmup, time_limit)
+        unbounded = engine.pairs(col_a, col_b, scope)
+        if not (out == np.minimum(unbounded, bound + 1)).all():
+            print(f"error: {label}: bounded != min(unbounded, k + 1)", file=sys.stderr)
+            return 2
+        print(f"  {label} exceeded={int((unbounded > bound).sum())} of {half}", file=sys.stderr)
+
     byte_to_class, class_costs = swa.unary_class_costs(2, -1)                          # bench.py:742
     for header, category, gap_open, gap_extend in (("# linear", "linear", -2, -2), ("# affine", "affine", -5, -1)):
         print(header)

@@ -8,6 +8,7 @@
 //   make -C stringwars_amd/csrc bench && STRINGWARS_DATASET=README.md STRINGWARS_TIME=1 ./stringwars_amd/bench_similarities
 #include <cinttypes>
 #include <cstdio>
+#include <memory>
 #include <numeric>
 
 #include "../../include/stringwars_amd.hpp"
@@ -178,6 +179,47 @@ int main() {
                 } catch (const Error &e) { skipped(multi_name, e.what()); }
             }
         } catch (const Error &e) { skipped(name, e.what()); }
+    }
+
+    {
+        // Bounded Levenshtein: out[i] = min(d, k + 1). The reference's only trace of it is the
+        // STRINGWARS_ERROR_BOUND variable (README.md:311); STRINGWARS_BOUND is accepted as an alias. Bytes and code points.
+        const uint32_t bound = (uint32_t)get_env_parsed("STRINGWARS_ERROR_BOUND", get_env_parsed("STRINGWARS_BOUND", 32));
+        size_t n = tokens.synthetic ? tape_len : tape_len / 2;
+        BytesTapeView pa = tokens.a().subview(0, n);
+        BytesTapeView pb = tokens.synthetic ? tokens.b().subview(0, n) : tokens.a().subview(n, 2 * n);
+        for (int utf8 = 0; utf8 < 2; ++utf8) {
+            char name[96];
+            std::snprintf(name, sizeof name, "uniform/stringwars_amd::levenshtein_pairs%s<k=%u,1gpu>", utf8 ? "_utf8" : "", bound);
+            if (!have_gpu) { skipped(name, gpu_error); continue; }
+            try {
+                std::vector<uint32_t> out(n), unbounded(n);
+                uint64_t pcells = 0, pbytes = 0;
+                // cells counted in code points for the Utf8 row, as the reference does (bench.rs:230-247)
+                auto symbols = [&](const BytesTapeView &t, size_t i) {
+                    if (!utf8) return (size_t)t.length(i);
+                    size_t count = 0;
+                    for (uint64_t at = t.offsets[i]; at < t.offsets[i + 1]; ++at) count += (t.data[at] & 0xC0) != 0x80;
+                    return count;
+                };
+                for (size_t i = 0; i < n; ++i) { pcells += (uint64_t)symbols(pa, i) * symbols(pb, i); pbytes += pa.length(i) + pb.length(i); }
+                std::unique_ptr<LevenshteinDistances> engine(utf8 ? new LevenshteinDistancesUtf8(gpu, 0, 1, 1, 1) : new LevenshteinDistances(gpu, 0, 1, 1, 1));
+                BenchStats stats = measure_throughput(name, ReportAs::Cups, budget, [&] {
+                    engine->pairs_into(gpu, pa, pb, out.data(), bound);   // invalid UTF-8 throws on the first call -> SKIPPED (bench.rs:615-636)
+                    return WorkUnits{pcells, pbytes};
+                });
+                if (stats.calls == 0) continue;                            // filtered out: no work at all (utils.rs:727-729)
+                engine->pairs_into(gpu, pa, pb, unbounded.data());
+                // the definition, checked on every pair of the row: bounded == min(unbounded, k + 1)
+                size_t exceeded = 0;
+                for (size_t i = 0; i < n; ++i) {
+                    uint32_t want = unbounded[i] > bound ? bound + 1 : unbounded[i];
+                    if (out[i] != want) { std::fprintf(stderr, "error: %s: pair %zu is %u, min(d, k+1) is %u\n", name, i, out[i], want); return 2; }
+                    exceeded += unbounded[i] > bound;
+                }
+                std::fprintf(stderr, "  %s exceeded=%zu of %zu\n", name, exceeded, n);
+            } catch (const Error &e) { skipped(name, e.what()); }
+        }
     }
 
     uint8_t byte_to_class[256];

@@ -13,6 +13,7 @@ ROWS = [
     "uniform/stringwars_amd::levenshtein_pairs<1gpu>", "linear/stringwars_amd::NeedlemanWunschScores<1gpu>",
     "affine/stringwars_amd::NeedlemanWunschScores<1gpu>", "linear/stringwars_amd::SmithWatermanScores<1gpu>",
     "affine/stringwars_amd::SmithWatermanScores<1gpu>",
+    "uniform/stringwars_amd::levenshtein_pairs<k=32,1gpu>", "uniform/stringwars_amd::levenshtein_pairs_utf8<k=32,1gpu>",
 ]
 
 
@@ -93,3 +94,9 @@ def test_rows_are_measured_on_gpu():
     names = {m.group(1) for m in map(line.match, multi.stdout.splitlines()) if m}
     assert multi.returncode == 0 and "uniform/stringwars_amd::levenshtein_pairs<3gpu>" in names, (multi.stdout, multi.stderr[-800:])
     assert "Skipping: linear/stringwars_amd::NeedlemanWunschScores<1gpu>" in filtered.stderr
+    # the bounded rows take k from STRINGWARS_ERROR_BOUND (reference README.md:311); k = 2 is exceeded by README words and the
+    # binary itself checks bounded == min(unbounded, k + 1) on every pair (exit code 2 otherwise)
+    bounded = run({"STRINGWARS_TIME": "0.1", "STRINGWARS_ERROR_BOUND": "2", "STRINGWARS_FILTER": "k="})
+    names = {m.group(1) for m in map(line.match, bounded.stdout.splitlines()) if m}
+    assert bounded.returncode == 0 and names == {"uniform/stringwars_amd::levenshtein_pairs<k=2,1gpu>", "uniform/stringwars_amd::levenshtein_pairs_utf8<k=2,1gpu>"}, (bounded.stdout, bounded.stderr[-800:])
+    assert re.search(r"exceeded=[1-9]\d* of", bounded.stderr)

@@ -62,7 +62,7 @@ def test_script_skips_loudly_without_gpu():
         pytest.skip("GPU present")
     result = run_script(["--time-limit", "0"])
     assert result.returncode == 0, result.stderr
-    assert result.stdout.count("SKIPPED (no_device") == 7 and "# uniform" in result.stdout and "# affine" in result.stdout
+    assert result.stdout.count("SKIPPED (no_device") == 9 and "# uniform" in result.stdout and "# affine" in result.stdout
 
 
 @pytest.mark.gpu
@@ -70,8 +70,14 @@ def test_script_measures_rows_on_gpu():
     result = run_script(["--time-limit", "0.2"])
     assert result.returncode == 0, result.stderr
     rows = [l for l in result.stdout.splitlines() if "CUPS" in l]
-    assert len(rows) == 7, result.stdout
+    assert len(rows) == 9, result.stdout
+    assert sum("<k=32,1gpu>" in row for row in rows) == 2                   # the bounded rows (bytes, code points)
     for row in rows:
-        assert re.match(r"^\S+<1gpu>\s+\d+\.\d\d [kMG]?CUPS \| \d+\.\d\d [kMG]?B/s \| p50 .* p99 .*$", row), row
+        assert re.match(r"^\S+<(k=32,)?1gpu>\s+\d+\.\d\d [kMG]?CUPS \| \d+\.\d\d [kMG]?B/s \| p50 .* p99 .*$", row), row
+    env_bound = subprocess.run([sys.executable, "-m", "stringwars_amd.bench_similarities", "--dataset", os.path.join(ROOT, "README.md"),
+                                "--time-limit", "0.05", "-k", "k="], env=dict(os.environ, PYTHONPATH=ROOT, STRINGWARS_ERROR_BOUND="2"),
+                               capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert env_bound.returncode == 0 and len([l for l in env_bound.stdout.splitlines() if "<k=2,1gpu>" in l and "CUPS" in l]) == 2, env_bound.stdout + env_bound.stderr
+    assert re.search(r"exceeded=[1-9]\d* of", env_bound.stderr), env_bound.stderr   # k = 2 is exceeded by README words
     only = run_script(["--time-limit", "0.05", "-k", "SmithWaterman"])
     assert len([l for l in only.stdout.splitlines() if "CUPS" in l]) == 2

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""bench.py -- GCUPS of batched Levenshtein on MI355X (BASELINE.json metric).
+"""bench.py -- GCUPS of batched Levenshtein on MI355X (BASELINE.json metric), one JSON line from rank 0.
 
-A "step" is one pass of the hot path over one batch held resident in HBM, tapes prepared once outside the timed
-region (as the reference builds its tape views once, bench.rs:292-306), plus -- for N > 1 -- the RCCL gather of the
-u32 distances to rank 0 that the north-star names.
+A "step" is ONE SYNCHRONOUS CALL of the hot path over one batch held resident in HBM -- results visible on return,
+the reference's own metric (`compute_into` inside `measure_throughput`, bench.rs:478-486, utils.rs:721-799) -- with tapes
+prepared once outside the timed region (as the reference builds its tape views once, bench.rs:292-306), plus, for
+N > 1, the RCCL gather of the u32 distances to rank 0 that the north-star names, waited for inside the step.
 
   --config c2 (default)  BASELINE configs[1]: 1,000,000 printable-ASCII token pairs per GPU, lengths U[32,96],
                          unbounded. Weak scaling: rank r scores pairs [r*P, (r+1)*P) of the seeded stream.
@@ -12,17 +13,27 @@ u32 distances to rank 0 that the north-star names.
                          send each piece to rank 0 (ncclSend / ncclRecv group) while the next one is scored.
 
 CUPS accounting is the reference's (similarities/bench.rs:413-414): cells = sum len(a_i)*len(b_i), whatever the
-algorithm skips. `value` is the rate of the K timed steps, enqueued asynchronously (two internal lanes); the
-like-for-like figure for the reference's synchronous `compute_into` (bench.rs:478-486, utils.rs:721-799) is
-`value_sync_call`. One JSON line is printed by rank 0.
+algorithm skips. Fields of the line:
 
-Order of a run: data, tapes, `--prewarm-seconds` (default 0.5) of untimed steps that bring an idle device to its clocks
-(`config.device_prewarm_s`; the same count on every rank), the W warm-up steps, the K timed steps between
-barrier + synchronize on both sides, then the checks (oracle, checksums), the synchronous calls, the CPU rows.
+  value              rate of the K timed synchronous steps (barrier + synchronize on both sides, max over ranks)
+  value_steady       the same calls over at least `--steady-seconds` (default 1 s) of wall time
+  value_pipelined    K steps enqueued asynchronously on two internal lanes (not the reference's metric; what a caller
+                     that does not need each result before the next call gets)
+  roofline           dominant kernel of the synchronous call: executed lane-ops (PMC constants, profiles/r3) over the kernel
+                     time measured live with hipEvents inside the library, on the kernel's own stream
+  configs            (N = 1) every other BASELINE config at full size, same measurement per entry: C1, C3 prepared / raw,
+                     C4 linear / affine / full byte alphabet, C5 at 20 M pairs per GPU -- each with its synchronous-call
+                     GCUPS, kernel time, roofline object and a parity check against the oracle
+  cpu_baseline(s)    the oracle's CPU rows on this box's host cores, bounded samples (rank 0, N = 1)
+
+Order of a run: data, tapes, `--prewarm-seconds` of untimed steps (an idle MI355X needs a few hundred milliseconds of work
+to reach its clocks), W warm-up steps, the K timed steps, a profiled repeat, the steady-state loop, the pipelined steps,
+the checks, the other configs, the CPU rows.
 
     python bench.py                       # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --only-config c4_linear --calls 3     # exactly 3 engine calls of one config (PMC passes)
 """
 import argparse
 import json
@@ -36,15 +47,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kernel_sources import KERNELS as KERNEL_SOURCES, source_digest  # noqa: E402
 
 # Peaks from /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 32-bit
 # integer lane-ops/s (the FP32 vector peak 157.3 TFLOP/s counts an FMA as two); HBM3E 8 TB/s.
 PEAK_VALU_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 PEAK_HBM_GBS = 8000.0
-NOMINAL_OPS_PER_CELL = 5  # SURVEY.md 8d's scalar-DP model: compare, add-diagonal, min(up,left), +1, min
-# Executed VALU instructions and HBM traffic per launch come from rocprofv3 PMC passes over this very command
-# (tools/profile_pmc.sh -> tools/pmc_constants.py); they cannot be read from inside the process.
-PMC_CONSTANTS = os.path.join(ROOT, "profiles", "r2", "pmc_constants.json")
+# SURVEY.md 8d's scalar-DP models (32-bit integer ops per cell): Levenshtein 5, NW linear 6 (+1 LDS read), Gotoh 11 (+1)
+NOMINAL_OPS_PER_CELL = {"lev": 5, "lev_utf8": 5, "nw_linear": 6, "nw_affine": 11}
+# Executed VALU instructions and HBM traffic per call come from rocprofv3 PMC passes over `bench.py --only-config ...`
+# (tools/refresh_profiles.sh -> tools/pmc_constants.py); they cannot be read from inside the process.
+PMC_CONSTANTS = os.path.join(ROOT, "profiles", "r3", "pmc_constants.json")
+PMC_CONSTANTS_NAME = os.path.relpath(PMC_CONSTANTS, ROOT)
 
 CONFIGS = {
     "c2": dict(workload="tokens64", pairs=1_000_000, scaling="weak",
@@ -53,6 +68,29 @@ CONFIGS = {
                text="C5 short_words: {pairs} word pairs (<= 16 B, mean ~6) in total, split over the GPUs, unbounded Levenshtein"),
 }
 
+# The other BASELINE configs at full size, measured after the headline legs at N = 1 (`configs` in the line) and one at a
+# time under the profiler (`--only-config`). kind: lev (bytes) / lev_utf8 (code points) / nw; `check` = pairs compared
+# with the oracle; README rows mirrored: /root/reference/similarities/README.md:33-40, :67-70, :107-110.
+LEGS = {
+    "c1": dict(workload="words16", pairs=10_000, kind="lev", prepared=True, check=10_000,
+               text="C1: 10 K ASCII word pairs <= 16 B, unbounded Levenshtein (BASELINE configs[0] shape, on the GPU)"),
+    "c2": dict(workload="tokens64", pairs=1_000_000, kind="lev", prepared=True, check=20_000,
+               text="C2: 1 M ASCII token pairs ~64 B, unbounded Levenshtein (the headline config)"),
+    "c3": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=True, variant="k32", check=1_000,
+               text="C3: 100 K UTF-8 line pairs ~1 KB, bounded Levenshtein k = 32 over code points, tapes prepared (decoded once)"),
+    "c3_raw": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, variant="k32", check=1_000,
+                   text="C3 on raw device tapes: UTF-8 validated and decoded inside every call"),
+    "c4_linear": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=4,
+                      text="C4: NW, 256x256 i8 matrix (20 amino acids + other), 10 K pairs ~4 KB, linear gaps -4"),
+    "c4_affine": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-11, -1), prepared=True, variant="affine", check=4,
+                      text="C4 with affine gaps (-11, -1)"),
+    "c4_bytes": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=4,
+                     text="C4 over the full byte alphabet (all 256 classes of the matrix in use), 2 K pairs ~4 KB, linear gaps -4"),
+    "c5": dict(workload="short_words", pairs=20_000_000, kind="lev", prepared=True, check=200_000,
+               text="C5: one GPU's share of the 100 M short-word pairs (20 M pairs <= 16 B, mean ~6), unbounded Levenshtein"),
+}
+DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c4_linear", "c4_affine", "c4_bytes", "c5"]
+
 
 def parse_args():
     p = argparse.ArgumentParser()
@@ -60,6 +98,7 @@ def parse_args():
     p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steps before the W warm-up steps, by the clock: brings an idle device to its clocks (0: none)")
+    p.add_argument("--steady-seconds", type=float, default=1.0, help="length of the steady-state loop of synchronous calls behind `value_steady` (0: none)")
     p.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     p.add_argument("--workload", default=None, help="override the config's synthetic workload")
     p.add_argument("--pairs", type=int, default=None, help="pairs per GPU (weak configs) / in total (strong configs)")
@@ -68,33 +107,54 @@ def parse_args():
     p.add_argument("--algorithm", default="auto", choices=["auto", "wavefront", "bitparallel", "tiled"])
     p.add_argument("--seed", type=int, default=int(os.environ.get("STRINGWARS_SEED", "42")))
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-configs", action="store_true", help="leave the other BASELINE configs out of the line")
+    p.add_argument("--no-pipelined", action="store_true", help="leave the pipelined steps out (the profiler then sees synchronous launches only)")
+    p.add_argument("--legs", default=",".join(DEFAULT_LEGS), help="which configs go into `configs`")
+    p.add_argument("--only-config", default=None, choices=sorted(LEGS), help="run ONE config's leg and print its entry (PMC / rocprof passes)")
+    p.add_argument("--calls", type=int, default=0, help="with --only-config: make exactly this many engine calls (no clock-driven loops)")
+    p.add_argument("--leg-pairs", type=int, default=0, help="with --only-config / --legs: scale every leg to this many pairs (testing)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo + --share-gpu exercises the multi-rank control flow on a one-GPU box (testing only)")
     p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (testing only; never a result)")
     return p.parse_args()
 
 
-def load_pmc_constants():
+def load_pmc_constants(path=PMC_CONSTANTS):
     try:
-        with open(PMC_CONSTANTS) as handle:
+        with open(path) as handle:
             return json.load(handle)
     except (OSError, ValueError):
         return {"kernels": {}}
 
 
-def roofline_of(kernel, kernel_ms, cells, algorithmic_bytes, workload, pairs, constants, extra=None):
-    """Roofline object of one kernel launch. `achieved` is EXECUTED work: SQ_INSTS_VALU (wave instructions, PMC) x 64
-    lanes / the kernel's duration measured live with hipEvents on its own stream; `frac` = achieved / the integer
-    VALU peak. SURVEY 8d's nominal 5-ops-per-cell model is carried separately (a bit-parallel kernel executes ~1.2
-    lane-ops per cell, so that figure exceeds the peak by construction and is not a roofline fraction)."""
+def kernel_family(stamp):
+    """The library stamps launches with the instantiation's name (`wavefront_class_g64_w80`, `nwprofile_w16`); PMC constants and
+    source digests are kept per kernel family."""
+    for family in ("wavefront", "nwprofile"):
+        if stamp.startswith(family):
+            return family
+    return stamp
+
+
+def roofline_of(kernel, kernel_ms, cells, algorithmic_bytes, workload, pairs, constants, extra=None, variant="", model="lev"):
+    """Roofline object of one call's dominant kernel family. `achieved` is EXECUTED work: SQ_INSTS_VALU (wave instructions
+    of every dispatch of the family in one call, PMC) x 64 lanes / the time those kernels cover, measured live with hipEvents
+    on their own streams; `frac` = achieved / the integer VALU peak. SURVEY 8d's nominal ops-per-cell model is carried
+    separately (a bit-parallel kernel executes ~1.2 lane-ops per cell, so that figure exceeds the peak by construction and is
+    not a roofline fraction). `pmc_stale` is true when the kernel's sources changed since the counters were taken."""
     seconds = kernel_ms * 1e-3
-    entry = constants.get("kernels", {}).get(f"{kernel}|{workload}")
-    scale = pairs / entry["pairs_per_launch"] if entry else 1.0   # the counters were taken on launches of pairs_per_launch pairs
+    stamp = kernel
+    kernel = kernel_family(stamp)
+    key = f"{kernel}|{workload}" + (f"|{variant}" if variant else "")
+    entry = constants.get("kernels", {}).get(key)
+    per_call = entry.get("pairs_per_call", entry.get("pairs_per_launch")) if entry else None
+    scale = pairs / per_call if entry else 1.0   # the counters were taken on calls of `pairs_per_call` pairs: work is linear in pairs
     hbm_gbs = algorithmic_bytes / seconds / 1e9 if seconds > 0 else 0.0
+    nominal = NOMINAL_OPS_PER_CELL.get(model, 5)
     roof = {
-        "bound": "valu", "kernel": kernel, "kernel_ms": round(kernel_ms, 4), "unit": "Tint32op/s", "peak": round(PEAK_VALU_TOPS, 1),
+        "bound": "valu", "kernel": kernel, "longest_launch": stamp, "kernel_ms": round(kernel_ms, 4), "unit": "Tint32op/s", "peak": round(PEAK_VALU_TOPS, 1),
         "achieved": None, "frac": None, "traffic": None, "cells_per_launch": cells,
-        "nominal_ops_per_cell_equiv": round(NOMINAL_OPS_PER_CELL * cells / seconds / 1e12, 3) if seconds > 0 else None,
+        "nominal_ops_per_cell_equiv": round(nominal * cells / seconds / 1e12, 3) if seconds > 0 else None,
         "hbm": {"achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 4),
                 "algorithmic_bytes": algorithmic_bytes},
     }
@@ -115,9 +175,13 @@ def roofline_of(kernel, kernel_ms, cells, algorithmic_bytes, workload, pairs, co
             roof["traffic_detail"] = {"fetch_kb_raw": round(entry["fetch_kb"] * scale, 1), "write_kb_raw": round(entry["write_kb"] * scale, 1),
                                       "fetch_correction": 2, "vs_algorithmic": round(roof["traffic"] / max(algorithmic_bytes, 1), 2),
                                       "vs_algorithmic_lower": round(lower / max(algorithmic_bytes, 1), 2)}
-        roof["pmc_source"] = f"{entry.get('source')}; launches of {entry['pairs_per_launch']} pairs"
+        roof["pmc_source"] = f"{entry.get('source')}; calls of {per_call} pairs"
+        if kernel in KERNEL_SOURCES and entry.get("source_digest") is not None:
+            roof["pmc_stale"] = entry["source_digest"] != source_digest(kernel)
+        else:
+            roof["pmc_stale"] = None   # an entry without a digest cannot be tied to the tree
     else:
-        roof["note"] = f"no PMC constants for {kernel}|{workload} in profiles/r2/pmc_constants.json"
+        roof["note"] = f"no PMC constants for {key} in {PMC_CONSTANTS_NAME}"
     if extra:
         roof.update(extra)
     return roof
@@ -178,6 +242,115 @@ def cpu_rows(a, b, budget_s=6.0):
     return rows
 
 
+def codepoint_lengths(strs):
+    """Code points per string of a UTF-8 tape (the reference counts cells in `chars().count()`, bench.rs:230-247)."""
+    leads = ((strs.data & 0xC0) != 0x80).astype(np.int64)
+    prefix = np.concatenate(([0], np.cumsum(leads)))
+    return prefix[strs.offsets[1:].astype(np.int64)] - prefix[strs.offsets[:-1].astype(np.int64)]
+
+
+def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_override=0, check=True, algorithm="auto"):
+    """One BASELINE config, measured like the headline: tapes resident in HBM, synchronous calls timed by the host, the DP
+    kernels' time from the library's hipEvents, executed lane-ops from the PMC constants, a sample against the oracle.
+    With `calls` > 0 exactly that many engine calls are made (the profiler's passes need a known count)."""
+    leg = LEGS[name]
+    pairs = pairs_override or leg["pairs"]
+    started = time.perf_counter()
+    a, b = sw.generate_pairs(leg["workload"], pairs, seed=seed)
+    generate_s = time.perf_counter() - started
+    if int(a.offsets[-1]) < 2 ** 32 and int(b.offsets[-1]) < 2 ** 32:
+        a, b = a.with_offsets(np.uint32), b.with_offsets(np.uint32)
+    as_torch = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else (x.view(np.int32) if x.dtype == np.uint32 else x)).to(device)
+    tensors = [as_torch(x) for x in (a.data, a.offsets, b.data, b.offsets)]
+    da = sw.DeviceTape(tensors[0].data_ptr(), tensors[1].data_ptr(), a.count, a.offsets.dtype, keepalive=tensors[:2])
+    db = sw.DeviceTape(tensors[2].data_ptr(), tensors[3].data_ptr(), b.count, b.offsets.dtype, keepalive=tensors[2:])
+    kind, utf8 = leg["kind"], leg["kind"] == "lev_utf8"
+    out = torch.zeros(pairs + 4, dtype=torch.int32, device=device)
+    if kind == "nw":
+        alphabet = None if leg["workload"] == "bytes4k" else sw.synth.AMINO_ACIDS
+        matrix = sw.substitution_matrix(seed, alphabet)
+        engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)
+        model = "nw_linear" if leg["gaps"][0] == leg["gaps"][1] else "nw_affine"
+    else:
+        engine = (sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances)(capabilities=scope, algorithm=algorithm)
+        model = kind
+    if leg["prepared"]:
+        pa, pb = sw.PreparedTape(scope, da, utf8=utf8), sw.PreparedTape(scope, db, utf8=utf8)
+        call = engine.bind_pairs(pa, pb, scope, out, bound=leg.get("bound")) if kind != "nw" else engine.bind_pairs(pa, pb, scope, out)
+    elif kind == "nw":
+        call = lambda: engine.pairs(da, db, scope, out=out)
+    else:
+        call = lambda: engine.pairs(da, db, scope, bound=leg.get("bound"), out=out)
+    made = 0
+    if calls > 0:                              # the profiler's passes: a fixed number of calls, the last one stamped
+        for _ in range(calls - 1):
+            call()
+        scope.set_profiling(True)
+        call()
+        timing = scope.last_timing()
+        scope.set_profiling(False)
+        made, elapsed, timed_calls, best_ms = calls, None, 0, None
+    else:
+        call()
+        warm_until = time.perf_counter() + 0.25   # by the clock, not by a count: the device must be at its clocks
+        while time.perf_counter() < warm_until:
+            call()
+        torch.cuda.synchronize()
+        walls, start = [], time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            call()
+            now = time.perf_counter()
+            walls.append(now - t0)
+            if (now - start >= 0.35 and len(walls) >= 5) or now - start >= 3.0:
+                break
+        elapsed, timed_calls, best_ms = now - start, len(walls), min(walls) * 1e3
+        scope.set_profiling(True)
+        timings = []
+        for _ in range(3):
+            call()
+            timings.append(scope.last_timing())
+        scope.set_profiling(False)
+        timing = min(timings, key=lambda t: t["compute_ms"])
+    if utf8:
+        lengths_a, lengths_b = codepoint_lengths(a), codepoint_lengths(b)
+    else:
+        lengths_a, lengths_b = a.lengths.astype(np.int64), b.lengths.astype(np.int64)
+    cells = int((lengths_a * lengths_b).sum())
+    algorithmic_bytes = int(a.data.nbytes + b.data.nbytes + 2 * pairs * a.offsets.dtype.itemsize + 4 * pairs)
+    entry = {"config": name, "workload": leg["text"], "pairs": pairs, "cells": cells, "dtype": "i32" if kind == "nw" else "u32",
+             "tapes": "prepared" if leg["prepared"] else "raw device tapes", "offsets": str(a.offsets.dtype)}
+    if timed_calls:
+        entry.update({"value": round(cells * timed_calls / elapsed / 1e9, 2), "unit": "GCUPS",
+                      "value_is": f"{timed_calls} synchronous calls over {elapsed:.2f} s timed by the host, after 0.25 s of untimed calls",
+                      "ms_per_call": round(elapsed / timed_calls * 1e3, 4), "best_call_ms": round(best_ms, 4),
+                      "gcups_kernels": round(cells / max(timing["compute_ms"], 1e-9) / 1e6, 2)})
+    else:
+        entry["calls_made"] = made
+    entry["kernels_per_call"] = timing["kernels"]
+    entry["all_kernels_ms"] = round(timing["total_ms"], 4)
+    entry["roofline"] = roofline_of(timing["dominant_name"], timing["compute_ms"], cells, algorithmic_bytes, leg["workload"], pairs, constants,
+                                    variant=leg.get("variant", ""), model=model,
+                                    extra={"measured": "hipEvents inside the library: time covered by the DP kernels of one synchronous call"})
+    if timing["cells"] != cells:
+        entry["cells_mismatch"] = {"library": timing["cells"], "host": cells}
+    if check and leg.get("check"):
+        import oracle  # the checker; the timed calls above never touch it
+        count = min(pairs, leg["check"])
+        got = out[:pairs].cpu().numpy()
+        if kind == "nw":
+            want = oracle.nw_pairs(a, b, matrix, leg["gaps"][0], leg["gaps"][1], count=count)
+            ok = bool((got[:count].astype(np.int64) == want.astype(np.int64)).all())
+        else:
+            want = oracle.levenshtein_pairs(a, b, utf8=utf8, algo="hyyro" if not utf8 else "wf", bound=leg.get("bound"), count=count)
+            ok = bool((got[:count].astype(np.uint32) == want.astype(np.uint32)).all())
+        entry["parity_vs_oracle"] = ok
+        entry["parity_sample"] = f"first {count} pairs of the call's results against oracle/"
+    entry["generate_s"] = round(generate_s, 2)
+    del call, engine
+    return entry
+
+
 def main():
     args = parse_args()
     import torch
@@ -198,6 +371,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # a stream of our own: on the legacy default stream the library's side stream (wavefront class kernels run on two streams)
+    # would serialise with it instead of overlapping
+    torch.cuda.set_stream(torch.cuda.Stream(device))
+
+    if args.only_config:
+        scope = sw.DeviceScope(gpu_device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        entry = run_leg(args.only_config, sw, scope, torch, device, args.seed, load_pmc_constants(), calls=args.calls,
+                        pairs_override=args.leg_pairs, check=not args.no_cpu_baseline, algorithm=args.algorithm)
+        print(json.dumps(entry), flush=True)
+        return
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -250,8 +434,12 @@ def main():
     pa, pb = sw.PreparedTape(scope, da), sw.PreparedTape(scope, db)
 
     # ---- the step ------------------------------------------------------------------------------------------------------
+    # Two result buffers: consecutive steps alternate between them (the pipelined steps need that; the synchronous ones do
+    # it too so that both modes run the same calls). In synchronous mode every call returns with its results visible
+    # and the step also waits for its gather; in pipelined mode calls are enqueued and only `fence()` waits.
     outs = [torch.zeros(max(pairs, 1), dtype=torch.int32, device=device) for _ in range(2)]
     counter = [0]
+    pipelined = [False]
     if strong:
         if args.chunks <= 0:
             args.chunks = 4 if world > 1 else 1
@@ -271,9 +459,13 @@ def main():
                 if p_hi > p_lo:
                     piece_calls[slot][j]()
                 if gather is not None:
-                    scope.join()                # the send is ordered on torch's stream: make it wait for this piece
+                    if pipelined[0]:
+                        scope.join()            # the send is ordered on torch's stream: make it wait for this piece
                     gather.send_chunk(outs[slot], j)
             gathers[slot] = gather
+            if gather is not None and not pipelined[0]:
+                gather.wait()                   # synchronous step: the gathered vector is complete on rank 0 at return
+                torch.cuda.current_stream().synchronize()
     else:
         gathered = [[torch.zeros(pairs, dtype=torch.int32, device=comm_device) for _ in range(world)] for _ in range(2)] \
             if rank == 0 and world > 1 else [None, None]
@@ -289,9 +481,14 @@ def main():
                 works[slot] = None
             calls[slot]()               # engine.pairs(pa, pb, scope, out=outs[slot]) with its arguments bound once
             if world > 1:
-                scope.join()            # the gather is ordered on torch's stream: make that stream wait for this call
+                if pipelined[0]:
+                    scope.join()        # the gather is ordered on torch's stream: make that stream wait for this call
                 if args.backend == "nccl":
                     works[slot] = dist.gather(outs[slot], gathered[slot], dst=0, async_op=True)
+                    if not pipelined[0]:
+                        works[slot].wait()
+                        works[slot] = None
+                        torch.cuda.current_stream().synchronize()   # synchronous step: the gathered distances are on rank 0 at return
                 else:
                     dist.gather(outs[slot].cpu(), gathered[slot], dst=0)
 
@@ -314,9 +511,13 @@ def main():
         fence()
         return time.perf_counter() - start
 
-    # `value`: K steps enqueued asynchronously on two internal lanes (host-side work of step i+1 overlaps step i)
-    scope.set_async(True)
-    scope.set_pipelined(True)
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # An idle MI355X takes a few hundred milliseconds of work to reach its clocks (profiles/r2: the same 20 steps measure
     # 8 % apart right after start-up and after a second of calls). The device is brought there first -- every rank runs the same
     # number of untimed steps, the collective included --, then come the W warm-up steps and the K timed ones.
@@ -336,25 +537,23 @@ def main():
             step()
             if i % 64 == 63:
                 fence()
+    # ---- `value`: K synchronous steps -----------------------------------------------------------------------------------
     for _ in range(args.warmup):
         step()
-    elapsed = timed_region(args.steps)
+    elapsed = max_over_ranks(timed_region(args.steps))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         c = torch.tensor([cells], dtype=torch.int64, device=comm_device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells = int(c.item())
     else:
         total_cells = cells
     last_slot = (counter[0] - 1) & 1
-    pipelined_result = outs[last_slot][:pairs].cpu().numpy().astype(np.uint32)   # produced by the timed steps
+    sync_result = outs[last_slot][:pairs].cpu().numpy().astype(np.uint32)   # produced by the timed steps
 
     # ---- every rank's slice of the gathered vector, against a checksum the rank computed locally ---------------------
     gather_ok = None
     if world > 1:
-        mine = torch.tensor([int(pipelined_result.astype(np.int64).sum()), int(np.bitwise_xor.reduce(pipelined_result)) if pairs else 0],
+        mine = torch.tensor([int(sync_result.astype(np.int64).sum()), int(np.bitwise_xor.reduce(sync_result)) if pairs else 0],
                             dtype=torch.int64, device=comm_device)
         sums = [torch.zeros(2, dtype=torch.int64, device=comm_device) for _ in range(world)]
         dist.all_gather(sums, mine)
@@ -366,80 +565,94 @@ def main():
                 slices = [g.cpu().numpy().astype(np.uint32) for g in gathered[last_slot]]
             gather_ok = all(int(s.astype(np.int64).sum()) == int(sums[r][0]) and
                             (int(np.bitwise_xor.reduce(s)) if s.size else 0) == int(sums[r][1]) for r, s in enumerate(slices))
-            gather_ok = bool(gather_ok and (slices[0] == pipelined_result).all())
+            gather_ok = bool(gather_ok and (slices[0] == sync_result).all())
 
-    # ---- the same region with the library's hipEvent pairs on (kernel durations on the kernels' own streams) ---------
-    # They cost a few microseconds of bubbles per call, so `value` above comes from the run without them; same
-    # steps, same overlap -- the conditions `rocprofv3 --kernel-trace --stats` of this command averages over.
+    # ---- the same steps with the library's hipEvent pairs on (kernel durations on the kernels' own streams) ----------
+    # They cost a few microseconds per call, so `value` above comes from the run without them; same calls, same conditions
+    # -- what `rocprofv3 --kernel-trace --stats` of `bench.py --no-pipelined --no-configs --no-cpu-baseline` averages over.
     scope.set_profiling(True)
     timed_region(args.steps)
     totals = scope.timing_totals()
-    scope.set_profiling(False)
-    scope.set_pipelined(False)
-    scope.set_async(False)
-
-    # ---- the reference's own metric: synchronous calls (results visible on return), timed one by one -----------------
-    out = outs[0]
-    sync_call = engine.bind_pairs(pa, pb, scope, out)   # arguments bound once: the loop below only crosses the FFI
-    sync_call()
-    torch.cuda.synchronize()
-    sync_start = time.perf_counter()
-    for _ in range(args.steps):
-        sync_call()
-    sync_elapsed = time.perf_counter() - sync_start
-    scope.set_profiling(True)
-    engine.pairs(pa, pb, scope, out=out)
     sync_timing = scope.last_timing()
     scope.set_profiling(False)
-    sync_result = out[:pairs].cpu().numpy().astype(np.uint32)
+
+    # ---- steady state: the same synchronous steps for at least --steady-seconds ---------------------------------------
+    steady = None
+    if args.steady_seconds > 0:
+        steps_for = max(int(args.steady_seconds / max(elapsed / args.steps, 1e-6) * 1.05) + 1, args.steps)
+        if world > 1:
+            agreed = torch.tensor([steps_for], dtype=torch.int64, device=comm_device)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
+            steps_for = int(agreed.item())
+        steady_elapsed = max_over_ranks(timed_region(steps_for))
+        steady = {"steps": steps_for, "seconds": round(steady_elapsed, 4), "value": round(total_cells * steps_for / steady_elapsed / 1e9, 2)}
+
+    # ---- pipelined: K steps enqueued asynchronously on two internal lanes (host work of step i+1 overlaps step i) ----
+    pipelined_rate, pipelined_result, pipelined_ms = None, None, None
+    if not args.no_pipelined:
+        scope.set_async(True)
+        scope.set_pipelined(True)
+        pipelined[0] = True
+        for _ in range(max(args.warmup, 4)):
+            step()
+        pipelined_elapsed = max_over_ranks(timed_region(args.steps))
+        pipelined_ms = pipelined_elapsed / args.steps * 1e3
+        pipelined_rate = round(total_cells * args.steps / pipelined_elapsed / 1e9, 2)
+        pipelined_result = outs[(counter[0] - 1) & 1][:pairs].cpu().numpy().astype(np.uint32)
+        pipelined[0] = False
+        scope.set_pipelined(False)
+        scope.set_async(False)
 
     line = None
     if rank == 0:
         constants = load_pmc_constants()
-        calls = max(totals["calls"], 1)
-        dominant = sync_timing["dominant_name"]
-        kernel_ms = totals["compute_ms"] / calls
-        per_call_cells = cells / (len(pieces) if strong else 1)
-        per_call_bytes = sync_timing["bytes"] / (len(pieces) if strong else 1)
-        roofline = roofline_of(dominant, kernel_ms, int(per_call_cells), int(per_call_bytes), workload,
-                               pairs // (len(pieces) if strong else 1), constants,
-                               extra={"all_kernels_ms": round(totals["total_ms"] / calls, 4), "launches_timed": totals["calls"],
-                                      "measured": "hipEvents inside the library over a repeat of the timed region"})
-        if roofline.get("achieved") is not None:
-            # two launches overlap in the pipelined region (each then takes about twice as long as alone): per launch the
-            # fraction above halves, per DEVICE it is the work of one launch over the step time
-            step_s = elapsed / args.steps / (len(pieces) if strong else 1)
-            roofline["frac_device"] = round(roofline["valu_wave_insts_per_launch"] * 64 / step_s / 1e12 / PEAK_VALU_TOPS, 4)
-            roofline["frac_device_is"] = "executed lane-ops of one launch / time per launch of the timed region (launches of two lanes overlap)"
-        roofline["sync_call"] = roofline_of(sync_timing["dominant_name"], sync_timing["compute_ms"], sync_timing["cells"], sync_timing["bytes"],
-                                            workload, pairs, constants, extra={"measured": "one synchronous call on an idle GPU"})
+        n_pieces = len(pieces) if strong else 1
+        calls_timed = max(totals["calls"], 1)
+        kernel_ms = totals["compute_ms"] / calls_timed
+        roofline = roofline_of(sync_timing["dominant_name"], kernel_ms, int(cells / n_pieces), int(sync_timing["bytes"]), workload,
+                               pairs // n_pieces, constants,
+                               extra={"all_kernels_ms": round(totals["total_ms"] / calls_timed, 4), "launches_timed": totals["calls"],
+                                      "measured": "hipEvents inside the library over a repeat of the K timed synchronous steps (average per call)"})
+        roofline["unit_note"] = "bound = integer VALU issue (not MFMA: min-plus has no dense contraction; not HBM: see `hbm`)"
         parity = None
         cpu_baseline, cpu_baselines = None, None
         if not args.no_cpu_baseline:
             import oracle  # checker + reported baseline only; never on the timed GPU path
             check = min(pairs, 20_000)   # (rank 0's shard; the other ranks' slices are covered by `gather_ok`)
             want = oracle.levenshtein_pairs(a, b, algo="hyyro", count=check)
-            parity = bool((want == pipelined_result[:check]).all() and (want == sync_result[:check]).all()
-                          and (pipelined_result == sync_result).all())
-            if world == 1:   # the CPU baseline is timed at N = 1 only
-                cpu_baselines = cpu_rows(a, b)
-                cpu_baseline = {k: v for k, v in cpu_baselines[0].items() if k != "name"}
+            parity = bool((want == sync_result[:check]).all() and (pipelined_result is None or (pipelined_result == sync_result).all()))
+        leg_entries = None
+        if world == 1 and not args.no_configs:
+            # release the headline's device memory before the larger configs come
+            leg_entries = []
+            for leg_name in [n for n in args.legs.split(",") if n]:
+                try:
+                    leg_entries.append(run_leg(leg_name, sw, scope, torch, device, args.seed, constants, pairs_override=args.leg_pairs,
+                                               check=not args.no_cpu_baseline))
+                except Exception as error:   # one config failing must not cost the line its headline
+                    leg_entries.append({"config": leg_name, "error": f"{type(error).__name__}: {error}"})
+                torch.cuda.empty_cache()
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N = 1 only
+            cpu_baselines = cpu_rows(a, b)
+            cpu_baseline = {k: v for k, v in cpu_baselines[0].items() if k != "name"}
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "GCUPS (DP cell updates/s) batched Levenshtein", "value": round(total_cells * args.steps / elapsed / 1e9, 2),
             "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "value_sync_call": round(cells * args.steps / sync_elapsed / 1e9, 2),
+            "value_steady": steady["value"] if steady else None, "value_pipelined": pipelined_rate,
             "config": {"workload": cfg["text"].format(pairs=total_pairs if strong else pairs) + ", tapes prepared and resident in HBM",
-                       "value_is": "rate of the K timed steps, calls enqueued asynchronously on two internal lanes",
-                       "value_sync_call_is": "rank 0's shard, K synchronous calls timed by the host (the reference's compute_into metric, utils.rs:721-799)",
+                       "value_is": "rate of the K timed steps; a step is one synchronous call (results visible on return; the reference's "
+                                   "compute_into metric, utils.rs:721-799)" + (" followed by the gather of the distances to rank 0, waited for" if world > 1 else ""),
+                       "value_steady_is": f"the same steps over >= {args.steady_seconds} s: {steady}" if steady else None,
+                       "value_pipelined_is": "K steps enqueued asynchronously on two internal lanes" + (f", {round(pipelined_ms, 4)} ms per step" if pipelined_ms else ""),
                        "pairs_per_gpu": pairs, "pairs_total": total_pairs, "cells_per_gpu": cells, "algorithm": args.algorithm,
-                       "offsets": str(offsets_dtype), "pieces_per_step": len(pieces) if strong else 1, "device_prewarm_s": args.prewarm_seconds,
+                       "offsets": str(offsets_dtype), "pieces_per_step": n_pieces, "device_prewarm_s": args.prewarm_seconds,
                        "collective": ("ncclSend/ncclRecv group per piece to rank 0 (variable-size gather of u32 distances)" if strong
                                       else "RCCL gather of u32 distances to rank 0") if world > 1 else "none",
                        "seed": args.seed},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baselines": cpu_baselines,
+            "roofline": roofline, "configs": leg_entries, "cpu_baseline": cpu_baseline, "cpu_baselines": cpu_baselines,
             "parity_vs_oracle": parity, "gather_ok": gather_ok,
         }
     if world > 1:

@@ -20,7 +20,9 @@ def load(path, name):
 def test_roofline_fraction_is_executed_work_over_peak():
     bench = load(os.path.join(ROOT, "bench.py"), "bench_module")
     constants = {"kernels": {"bitparallel_tiled|tokens64": {
-        "pairs_per_launch": 1_000_000, "valu_insts": 86.0e6, "fetch_kb": 190_000.0, "write_kb": 4_000.0, "source": "unit test"}}}
+        "pairs_per_call": 1_000_000, "valu_insts": 86.0e6, "fetch_kb": 190_000.0, "write_kb": 4_000.0, "source": "unit test",
+        "source_digest": bench.source_digest("bitparallel_tiled")},
+        "wavefront|protein4k|affine": {"pairs_per_call": 10, "valu_insts": 1e6, "fetch_kb": None, "write_kb": None, "source_digest": "0" * 16}}}
     roof = bench.roofline_of("bitparallel_tiled", 0.180, 4_273_938_131, 140_000_000, "tokens64", 1_000_000, constants)
     lane_ops = 86.0e6 * 64
     assert abs(roof["achieved"] - lane_ops / 0.180e-3 / 1e12) < 1e-2
@@ -32,6 +34,37 @@ def test_roofline_fraction_is_executed_work_over_peak():
     assert abs(half["frac"] - roof["frac"]) < 1e-3 and half["traffic"] * 2 == roof["traffic"]
     missing = bench.roofline_of("banded", 0.3, 1, 1, "utf8_lines", 10, constants)
     assert missing["frac"] is None and missing["traffic"] is None and "no PMC constants" in missing["note"]
+    # an entry is tied to the sources it was measured on: same digest -> fresh, another digest -> stale; variants are keyed
+    assert roof["pmc_stale"] is False
+    stale = bench.roofline_of("wavefront", 1.0, 100, 100, "protein4k", 10, constants, variant="affine", model="nw_affine")
+    assert stale["pmc_stale"] is True and stale["frac"] is not None and stale["traffic"] is None
+    assert bench.roofline_of("wavefront", 1.0, 100, 100, "protein4k", 10, constants, variant="linear")["frac"] is None
+
+
+def test_source_digest_follows_the_kernel_sources(tmp_path, monkeypatch):
+    ks = load(os.path.join(ROOT, "tools", "kernel_sources.py"), "kernel_sources_module")
+    before = ks.source_digest("short_tiled")
+    assert before == ks.source_digest("short_tiled") and len(before) == 16
+    for name in ("short.hip", "common.hpp"):
+        (tmp_path / name).write_bytes(open(os.path.join(ks.CSRC, name), "rb").read())
+    monkeypatch.setattr(ks, "CSRC", str(tmp_path))
+    assert ks.source_digest("short_tiled") == before
+    with open(tmp_path / "short.hip", "ab") as handle:
+        handle.write(b"\n// one more line\n")
+    assert ks.source_digest("short_tiled") != before
+    for stamp, (needle, sources) in ks.KERNELS.items():
+        assert needle.startswith("swh::k_") and sources
+
+
+def test_bench_legs_cover_every_baseline_config():
+    """`configs` of the bench line: C1, C3 (prepared and raw), C4 linear / affine / full byte alphabet, C5 -- BASELINE.json's
+    configs beside the headline C2, each at its full size."""
+    bench = load(os.path.join(ROOT, "bench.py"), "bench_module_legs")
+    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c4_linear", "c4_affine", "c4_bytes", "c5"]
+    sizes = {name: (leg["workload"], leg["pairs"]) for name, leg in bench.LEGS.items()}
+    assert sizes["c1"] == ("words16", 10_000) and sizes["c2"] == ("tokens64", 1_000_000) and sizes["c3"] == ("utf8_lines", 100_000)
+    assert sizes["c4_linear"] == sizes["c4_affine"] == ("protein4k", 10_000) and sizes["c4_bytes"] == ("bytes4k", 2_000)
+    assert sizes["c5"] == ("short_words", 20_000_000) and bench.LEGS["c3"]["bound"] == 32 and not bench.LEGS["c3_raw"]["prepared"]
 
 
 def test_pmc_constants_folds_counter_passes(tmp_path):
@@ -55,8 +88,15 @@ def test_pmc_constants_folds_counter_passes(tmp_path):
                 writer.writerow({"Dispatch_Id": dispatch, "Kernel_Name": rows[0]["Kernel_Name"], "Counter_Name": "FETCH_SIZE", "Counter_Value": 1000.0})
     out = tmp_path / "constants.json"
     done = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_constants.py"), str(run), "--workload", "tokens64",
-                           "--pairs", "1000000", "--out", str(out)], capture_output=True, text=True)
+                           "--pairs", "1000000", "--calls", "3", "--out", str(out)], capture_output=True, text=True)
     assert done.returncode == 0, done.stderr
     entry = json.load(open(out))["kernels"]["bitparallel_tiled|tokens64"]
-    assert entry["dispatches"] == 3 and abs(entry["valu_insts"] - 82e6) < 1
-    assert abs(entry["valu_insts_per_pair"] - 82.0) < 1e-6 and entry["fetch_kb"] == 8000.0 and entry["write_kb"] is None
+    assert entry["calls"] == 3 and entry["dispatches_per_call"] == 1.0 and abs(entry["valu_insts"] - 82e6) < 1
+    # FETCH_SIZE: 2 dispatches x 8 rows x 1000 KB over the 3 calls of the command (every pass runs the same command)
+    assert abs(entry["valu_insts_per_pair"] - 82.0) < 1e-6 and abs(entry["fetch_kb"] - 16000.0 / 3) < 0.1 and entry["write_kb"] is None
+    assert len(entry["source_digest"]) == 16
+    # a second variant of the same kernel and workload lands beside it
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_constants.py"), str(run), "--workload", "tokens64", "--pairs", "1000000",
+                    "--calls", "1", "--variant", "k8", "--out", str(out)], check=True, capture_output=True)
+    book = json.load(open(out))["kernels"]
+    assert set(book) == {"bitparallel_tiled|tokens64", "bitparallel_tiled|tokens64|k8"} and abs(book["bitparallel_tiled|tokens64|k8"]["valu_insts"] - 246e6) < 1

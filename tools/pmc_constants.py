@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""Folds the rocprofv3 PMC passes of tools/profile_pmc.sh into profiles/<round>/pmc_constants.json: per kernel and
-workload, the per-dispatch averages bench.py's roofline object needs (SQ_INSTS_VALU for executed lane-ops,
+"""Folds rocprofv3 PMC passes (tools/refresh_profiles.sh) into profiles/<round>/pmc_constants.json: per kernel family,
+workload and variant, the PER-CALL totals bench.py's roofline objects need (SQ_INSTS_VALU for executed lane-ops,
 FETCH_SIZE / WRITE_SIZE for HBM traffic) plus the counters DESIGN.md quotes.
 
-    tools/pmc_constants.py <pmc_outdir> --workload tokens64 --pairs 1000000 [--out profiles/r2/pmc_constants.json]
+    tools/pmc_constants.py <pmc_outdir> --workload tokens64 --pairs 1000000 --calls 4 [--variant linear] [--out ...]
+
+`--calls` is the number of engine calls the profiled command made (`bench.py --only-config NAME --calls N` makes exactly
+N): a call may launch several kernels of one family (the wavefront classes of an NW call), so the figures are sums over
+every dispatch of the family divided by the calls, not per-dispatch averages. Every entry is stamped with a digest of
+the kernel's sources (tools/kernel_sources.py); bench.py flags entries whose digest no longer matches the tree.
 """
 import argparse
 import collections
@@ -11,19 +16,10 @@ import csv
 import glob
 import json
 import os
+import sys
 
-# stamp name used by the library's timing (swh_timing_t::dominant_name) -> substring of the kernel symbol
-KERNELS = {
-    "bitparallel": "swh::k_bitparallel<unsigned char,",
-    "bitparallel_u32": "swh::k_bitparallel<unsigned int,",
-    "bitparallel_tiled": "swh::k_bitparallel_tiled<unsigned char,",
-    "bitparallel_tiled_u32": "swh::k_bitparallel_tiled<unsigned int,",
-    "bitparallel_long": "swh::k_bitparallel_long<unsigned char",
-    "direct_short": "swh::k_direct_short<",
-    "short_tiled": "swh::k_short_tiled<",
-    "banded": "swh::k_banded<",
-    "wavefront": "swh::k_wavefront<",
-}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_sources import KERNELS, ROOT, source_digest  # noqa: E402
 
 
 def main():
@@ -31,7 +27,9 @@ def main():
     ap.add_argument("outdir")
     ap.add_argument("--workload", required=True)
     ap.add_argument("--pairs", type=int, required=True)
-    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r2", "pmc_constants.json"))
+    ap.add_argument("--calls", type=int, required=True, help="engine calls made by the profiled command")
+    ap.add_argument("--variant", default="", help="distinguishes entries of one kernel and workload (linear / affine / k32 / raw ...)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r3", "pmc_constants.json"))
     ap.add_argument("--source", default=None, help="what to record as the origin of the numbers")
     args = ap.parse_args()
     sums = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -43,9 +41,10 @@ def main():
     try:
         book = json.load(open(args.out))
     except (OSError, ValueError):
-        book = {"about": "per-dispatch averages of rocprofv3 --pmc passes (tools/profile_pmc.sh); FETCH_SIZE / WRITE_SIZE in KB, uncorrected",
+        book = {"about": "per-call totals of rocprofv3 --pmc passes (tools/refresh_profiles.sh) over `bench.py --only-config NAME --calls N`: "
+                         "sums over every dispatch of the kernel family / N; FETCH_SIZE / WRITE_SIZE in KB, uncorrected",
                 "kernels": {}}
-    for stamp, needle in KERNELS.items():
+    for stamp, (needle, _) in KERNELS.items():
         merged, counts = collections.defaultdict(float), collections.defaultdict(int)
         for kernel, counters in sums.items():
             if needle not in kernel:
@@ -55,17 +54,19 @@ def main():
                 counts[counter] += len(dispatches[kernel][counter])
         if not merged or "SQ_INSTS_VALU" not in merged:
             continue
-        per = {c: merged[c] / counts[c] for c in merged}
-        # Every dispatch of the profiled command scores `--pairs` pairs, so the averages are per launch of that size; the
-        # per-pair figures let bench.py price launches of another size of the same workload (work is linear in pairs).
-        entry = {"kernel_symbol": needle, "dispatches": int(counts["SQ_INSTS_VALU"]), "pairs_per_launch": args.pairs,
+        per = {c: merged[c] / args.calls for c in merged}
+        entry = {"kernel_symbol": needle, "calls": args.calls, "dispatches_per_call": round(counts["SQ_INSTS_VALU"] / args.calls, 2),
+                 "pairs_per_call": args.pairs,
                  "valu_insts": round(per["SQ_INSTS_VALU"], 1), "valu_insts_per_pair": per["SQ_INSTS_VALU"] / args.pairs,
                  "fetch_kb": round(per["FETCH_SIZE"], 1) if "FETCH_SIZE" in per else None,
                  "write_kb": round(per["WRITE_SIZE"], 1) if "WRITE_SIZE" in per else None,
                  "counters": {c: round(v, 1) for c, v in sorted(per.items())},
-                 "source": args.source or f"tools/profile_pmc.sh -> {os.path.basename(os.path.normpath(args.outdir))}"}
-        book["kernels"][f"{stamp}|{args.workload}"] = entry
-        print(stamp, args.workload, args.pairs, "VALU wave-insts", entry["valu_insts"], "fetch KB", entry["fetch_kb"], "write KB", entry["write_kb"])
+                 "source_digest": source_digest(stamp),
+                 "source": args.source or f"tools/refresh_profiles.sh -> {os.path.basename(os.path.normpath(args.outdir))}"}
+        key = f"{stamp}|{args.workload}" + (f"|{args.variant}" if args.variant else "")
+        book["kernels"][key] = entry
+        print(key, args.pairs, "VALU wave-insts/call", entry["valu_insts"], "fetch KB", entry["fetch_kb"], "write KB", entry["write_kb"],
+              "dispatches/call", entry["dispatches_per_call"])
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(book, open(args.out, "w"), indent=1, sort_keys=True)
 

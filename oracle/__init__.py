@@ -24,7 +24,9 @@ def build(force: bool = False) -> str:
 
 
 build()
-lib = C.CDLL(_LIB)
+# ORACLE_LIBRARY: another build of the same source, e.g. `make -C oracle asan` -> liboracle_asan.so under LD_PRELOAD=libasan
+# (tests/test_sanitizers.py)
+lib = C.CDLL(os.environ.get("ORACLE_LIBRARY") or _LIB)
 _u8p, _vp = C.c_void_p, C.c_void_p
 lib.orc_utf8_decode.restype = C.c_long
 lib.orc_utf8_decode.argtypes = [_u8p, C.c_size_t, _vp]

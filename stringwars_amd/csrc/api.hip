@@ -107,6 +107,11 @@ static void harvest_timing(Scope *scope, bool complete) {
             scope->hint_max_la = sm.max_la; scope->hint_max_lb = sm.max_lb;
             scope->hint_mean_x16 = scope->summary_pairs ? (uint32_t)std::min<uint64_t>(sm.symbols * 8 / scope->summary_pairs, 0xFFFFFFu) : 0u;
             scope->hint_short = (uint64_t)sm.short_pairs * 4 >= scope->summary_pairs;
+        } else if (scope->async) {
+            // An asynchronous plan-free call cannot be redone behind the caller's back (synchronous calls are: run_call_on).
+            // It only runs on prepared tapes, whose lengths were measured: a pair that does not fit means the tape's memory
+            // changed after swh_tape_prepare_* -- the misfit pairs were NOT scored. Reported by the next synchronisation.
+            scope->violation_seen = true;
         }
     }
     scope->summary_pending = false;
@@ -259,7 +264,9 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
     scope->last_timing = swh_timing_t{};
     if (pairs == 0) return swh_success_k;
     // code points of pure-ASCII tapes are their bytes: such a pair of prepared tapes runs on the byte kernels
-    const bool utf8 = prepared ? (spec.pa->utf8 && !(spec.pa->ascii && spec.pb->ascii)) : spec.utf8;
+    // (only when both byte tapes have the same offset width: whether a UTF-8 call is accepted must not depend on what the
+    // tapes contain -- a u32 / u64 mix falls back to the decoded tapes, whose offsets are always u64)
+    const bool utf8 = prepared ? (spec.pa->utf8 && !(spec.pa->ascii && spec.pb->ascii && spec.pa->off64 == spec.pb->off64)) : spec.utf8;
     if (prepared && !utf8 && spec.pa->off64 != spec.pb->off64)
         return fail(error, swh_invalid_argument_k, "prepared byte tapes must share one offset width");
     if (utf8 && engine->scoring.matrix)
@@ -584,15 +591,25 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             launch_bitparallel_long(scope, kl, plan);
         }
 
+        // Global alignment on a class table (<= 32 symbol classes), pairs of more than 384 columns: the column-profile kernel
+        // (nwprofile.hip) takes them -- perm is sorted by class, so they are one contiguous range -- and the wavefront
+        // kernels below see a plan without them. STRINGWARS_AMD_NW=classic keeps everything on the wavefront kernels.
+        static const bool nw_classic = [] { const char *e = getenv("STRINGWARS_AMD_NW"); return e && strcmp(e, "classic") == 0; }();
+        uint32_t profile_first = 0, profile_count = 0;
+        Plan wf_plan = plan;
+        if (engine->kind == 1 && engine->scoring.class_table && sym_bytes == 1 && !nw_classic) {
+            profile_first = plan.class_start[kClassWf64 + kNwProfileFirstWide];
+            for (int c = kClassWf64 + kNwProfileFirstWide; c <= kClassWfMulti; ++c) { profile_count += plan.class_count[c]; wf_plan.class_count[c] = 0; }
+        }
         // wavefront classes (all of them when the plan is wavefront-only)
         bool any_wf = false, multi = false;
         for (int c = kClassWf16; c <= kClassWfMulti; ++c) {
-            if (!plan.class_count[c]) continue;
+            if (!wf_plan.class_count[c]) continue;
             any_wf = true;
             if (c == kClassWfMulti || (k.affine && c >= kClassWf64 + 8)) multi = true;  // (affine strips are capped: the widest classes take several passes)
             if (wavefront_strip_cap() && c >= kClassWf64 && wide_w(c - kClassWf64 < kNumWideW ? c - kClassWf64 : kNumWideW - 1) > wavefront_strip_cap()) multi = true;
         }
-        if (any_wf) {
+        if (any_wf || profile_count) {
             // int32 scores with a -2^29 "minus infinity": keep every reachable score well inside it
             const uint64_t worst_step = std::max<uint64_t>({(uint64_t)std::abs(engine->scoring.open), (uint64_t)std::abs(engine->scoring.extend),
                                                             (uint64_t)std::abs(engine->scoring.match), (uint64_t)std::abs(engine->scoring.mismatch),
@@ -601,17 +618,24 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 SWH_HIP_CHECK(hipStreamSynchronize(stream));
                 return fail(error, swh_unsupported_length_k, "scores of this batch could leave the 32-bit range of the wavefront kernels (costs x lengths too large)");
             }
+            // one boundary column (H, E) per concurrently resident group: two areas for the wavefront class kernels, which
+            // alternate between two streams and run side by side (launch_wavefront), one for the profile kernel's waves
+            const uint64_t stride = (uint64_t)(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb) + 64 + 16;
+            const uint64_t groups = multi ? (uint64_t)scope->compute_units * 8 * 4 : 0;  // max blocks * waves (G = 64)
+            const uint64_t profile_waves = profile_count ? nwprofile_waves(scope, engine->scoring.classes ? engine->scoring.classes : 32) : 0;
+            if (multi || profile_count) ensure(scope->boundary, scope->boundary_bytes, (2 * groups + profile_waves) * stride * 2 * sizeof(int32_t));
+            if (profile_count) {
+                KernelArgs kp = k;
+                kp.boundary = (int32_t *)scope->boundary + 2 * groups * stride * 2;
+                kp.boundary_stride = stride;
+                launch_nwprofile(scope, kp, profile_first, profile_count);
+            }
             if (multi) {
-                // one boundary column (H, E) per concurrently resident group
-                uint64_t stride = (uint64_t)(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb) + 64 + 16;
-                uint64_t groups = (uint64_t)scope->compute_units * 8 * 4;  // max blocks * waves (G = 64)
-                // two areas: class kernels alternate between two streams and run side by side (launch_wavefront)
-                ensure(scope->boundary, scope->boundary_bytes, 2 * groups * stride * 2 * sizeof(int32_t));
                 k.boundary = (int32_t *)scope->boundary;
                 k.boundary_stride = stride;
                 scope->wf_side_boundary = groups * stride * 2;
             }
-            launch_wavefront(scope, k, plan);
+            if (any_wf) launch_wavefront(scope, k, wf_plan);
         }
 
         copy_results_back();
@@ -744,16 +768,22 @@ swh_status_t swh_scope_set_async(swh_scope_t handle, int async) {
 swh_status_t swh_scope_synchronize(swh_scope_t handle, const char **error) {
     Scope *scope = (Scope *)handle;
     if (!scope) return fail(error, swh_invalid_argument_k, "null scope");
+    bool violated = false;
     for (Scope *lane : scope->lanes)
         if (lane) {
             hipError_t lerr = hipStreamSynchronize(lane->stream);
             if (lerr != hipSuccess) return fail_hip(error, HipFailure{lerr, "hipStreamSynchronize (lane)"});
             harvest_timing(lane, true);
+            violated |= lane->violation_seen; lane->violation_seen = false;
         }
     hipError_t err = hipStreamSynchronize(scope->stream);
     if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipStreamSynchronize"});
     harvest_timing(scope, true);
+    violated |= scope->violation_seen; scope->violation_seen = false;
     if (scope->pipelined && scope->last_lane) scope->last_timing = scope->last_lane->last_timing;
+    if (violated)
+        return fail(error, swh_invalid_argument_k, "an asynchronous call met strings longer than its prepared tapes were measured with (was a tape's memory "
+                                                   "changed after swh_tape_prepare_*?): those pairs were not scored");
     return swh_success_k;
 }
 swh_status_t swh_scope_set_pipelined(swh_scope_t handle, int enabled, const char **error) {

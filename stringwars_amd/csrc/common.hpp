@@ -320,6 +320,7 @@ struct Scope {
     CallSummary *summary_dev = nullptr;    // the same memory as the device sees it
     uint32_t *done_counter = nullptr;      // device: workgroups finished (self-resetting), for "last one reports"
     bool summary_pending = false;          // a plan-free call's summary has not been read yet (harvest_timing)
+    bool violation_seen = false;           // an asynchronous plan-free call reported a pair that did not fit: swh_scope_synchronize fails
     uint64_t summary_pairs = 0, summary_extra_bytes = 0;   // what the algorithmic byte count of that call needs besides the summary
     uint32_t summary_sym_bytes = 1, summary_ow = 8, summary_elem = 4;
     // Pipelined mode: calls alternate between `lanes` (internal scopes with their own stream, scratch and plan
@@ -424,6 +425,11 @@ inline uint64_t bp_long_carry_words(uint64_t longest_text) { return 4 * (longest
 constexpr uint64_t kBpLongMaxWaves = 4096;
 void launch_wavefront(Scope *scope, const KernelArgs &args, const Plan &plan_host);
 void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs);
+// nwprofile.hip: global alignment on a class table with the substitution scores served from a column profile in LDS; takes
+// the pairs of plan classes kClassWf64 + kNwProfileFirstWide .. kClassWfMulti (more than 384 columns) = perm[first, first + count)
+constexpr int kNwProfileFirstWide = 3;
+uint32_t nwprofile_waves(const Scope *scope, uint32_t classes);   // waves of a launch = boundary areas it needs
+void launch_nwprofile(Scope *scope, KernelArgs args, uint32_t first, uint32_t count);
 int wavefront_strip_cap();
 
 // UTF-8 staging: decodes a byte tape into u32 code points + u64 code-point offsets.

@@ -398,22 +398,29 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_fused(PrepassArgs args, F
         __hip_atomic_store(row + 2, (unsigned long long)part.max_la | (unsigned long long)part.max_lb << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(row + 3, (unsigned long long)part.short_pairs | (unsigned long long)part.pad << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        atomicAdd(fused.barrier, 1u);
-        // Wait for the rest of the grid. The launch is sized to be resident as a whole, but a device shared with
-        // somebody else's long-running kernels could still keep workgroups out: after ~2 s the launch gives up, the
-        // host falls back to the three-pass planner and never uses this kernel on the scope again.
-        const unsigned long long spin_start = __builtin_readcyclecounter();
-        bool gave_up = false;
-        while ((int32_t)(__hip_atomic_load(fused.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fused.target) < 0) {
-            if (__hip_atomic_load(fused.barrier + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { gave_up = true; break; }
-            if (__builtin_readcyclecounter() - spin_start > 5000000000ull) {
-                __hip_atomic_store(fused.barrier + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gave_up = true;
-                break;
+        // Grid barrier with ONE agreed outcome. Arrivals are counted in barrier[0] (monotonic, per-call target); the outcome of
+        // this call lives in barrier[1] as (target << 2) | state, state 1 = everybody arrived, 2 = given up, and is set by a
+        // compare-and-swap -- by the last workgroup to arrive, or by one that has waited ~2 s (the launch is sized to be
+        // resident as a whole, but a device shared with somebody else's long-running kernels could still keep workgroups
+        // out). Whoever swaps first decides for all: no workgroup can publish its slice of `perm` while another one skips its
+        // own. After a give-up the host falls back to the three-pass planner and never uses this kernel on the scope again.
+        const uint32_t tag = fused.target << 2;
+        auto decide = [&](uint32_t state) {
+            uint32_t seen = __hip_atomic_load(fused.barrier + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((seen & ~3u) != tag || (seen & 3u) == 0) {   // (a value of another call's tag is stale: overwrite it)
+                if (__hip_atomic_compare_exchange_strong(fused.barrier + 1, &seen, tag | state, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             }
-            __builtin_amdgcn_s_sleep(2);
+        };
+        if (atomicAdd(fused.barrier, 1u) + 1u == fused.target) decide(1u);
+        const unsigned long long spin_start = __builtin_readcyclecounter();
+        uint32_t outcome;
+        for (;;) {
+            outcome = __hip_atomic_load(fused.barrier + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((outcome & ~3u) == tag && (outcome & 3u)) break;
+            if (__builtin_readcyclecounter() - spin_start > 5000000000ull) decide(2u);
+            else __builtin_amdgcn_s_sleep(2);
         }
-        if (!gave_up && __hip_atomic_load(fused.barrier + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) gave_up = true;
+        const bool gave_up = (outcome & 3u) != 1u;
         wave_sum[0] = gave_up ? 1u : 0u;   // what crosses the barrier (key totals, partial rows) is read with agent-scope atomic loads
     }
     __syncthreads();
@@ -803,7 +810,10 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
         (void)hipGetLastError();
         scope->fused_per_cu = per_cu > 2 ? 2 : per_cu;
     }
-    const uint32_t fused_slots = (uint32_t)scope->fused_per_cu * (uint32_t)scope->compute_units;
+    // A pipeline lane (api.hip: run_pipelined) shares the device with the other lane's calls -- possibly its planner, which spins
+    // on a grid barrier of its own: each lane sizes its grid for half the device, so that two planners are resident together.
+    const bool is_lane = scope->lane_done != nullptr;
+    const uint32_t fused_slots = (uint32_t)scope->fused_per_cu * (uint32_t)scope->compute_units / (is_lane ? 2u : 1u);
     const uint64_t fused_capacity = (uint64_t)fused_slots * kPlanThreads * kFusedPer;
     const bool fused = !fused_off && !scope->fused_disabled && fused_slots > 0 && fused_slots <= (uint32_t)kMaxPartials && pairs <= fused_capacity;
     if (args.direct_short) {
@@ -817,6 +827,11 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
         // another lane's DP kernel they take turns, which the barrier tolerates); small batches use fewer, >= 2048 pairs each
         uint32_t nb = (uint32_t)((pairs + 2047) / 2048);
         if (nb > fused_slots) nb = fused_slots;
+        // the outcome word carries the target shifted by two bits: start over long before the shift could lose anything
+        if (scope->plan_barrier_target > (1u << 29)) {
+            SWH_HIP_CHECK(hipMemsetAsync(scope->plan_barrier, 0, 2 * sizeof(uint32_t), stream));
+            scope->plan_barrier_target = 0;
+        }
         // test hook: a grid four times larger than the device holds, to exercise the barrier's give-up path
         static const bool oversubscribe = getenv("STRINGWARS_AMD_FUSED_OVERSUBSCRIBE") != nullptr;
         if (oversubscribe) nb = 4 * fused_slots <= (uint32_t)kMaxPartials ? 4 * fused_slots : (uint32_t)kMaxPartials;

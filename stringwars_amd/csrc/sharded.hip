@@ -12,7 +12,9 @@
 // device 0 of a one-GPU box) exchange by device-to-device copies instead, since a communicator cannot hold a GPU twice.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -67,9 +69,22 @@ struct MultiScope {
     std::vector<hipEvent_t> done;         // per member: its shard has been scored
     std::vector<hipEvent_t> begin;
     hipEvent_t gathered = nullptr, gather_begin = nullptr;
+    hipStream_t gather_stream = nullptr;   // first device: the receives run beside that device's own shard
+    uint64_t *check_host = nullptr;        // pinned: per member (sum, xor) as computed on the shard's device, then as gathered
+    std::vector<uint64_t *> check_dev;     // per member, on its device: 2 words; first device: 2 words per member more
     bool same_device = false;
+    bool checked_once = false;             // the first call of a scope verifies its gather (swh_levenshtein_pairs_sharded)
     swh_shard_timing_t timing{};
 };
+
+// (sum, xor) of n distances: what the self-check of the sharded call compares between a shard's device and the gathered vector
+__global__ __launch_bounds__(256) void k_shard_checksum(const uint32_t *values, uint64_t n, unsigned long long *out) {
+    unsigned long long sum = 0, x = 0;
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) { sum += values[i]; x ^= (unsigned long long)values[i] << (i & 31); }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_xor(sum, off); x ^= __shfl_xor(x, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, sum); atomicXor(out + 1, x); }
+}
 
 static thread_local char g_sharded_error[512];
 static swh_status_t sharded_fail(const char **error, swh_status_t status, const char *fmt, const char *a = "", const char *b = "") {
@@ -142,7 +157,7 @@ swh_status_t swh_scope_init_gpus(const int *devices, int count, swh_scope_t *out
         for (int j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
     multi->same_device = !distinct;
     auto cleanup = [&](swh_status_t st) {
-        for (swh_scope_t m : multi->members) swh_scope_free(m);
+        free_multi_scope(multi.release());   // members, events, streams, check buffers, communicators
         swh_scope_free(parent);
         return st;
     };
@@ -153,28 +168,36 @@ swh_status_t swh_scope_init_gpus(const int *devices, int count, swh_scope_t *out
         swh_scope_set_async(member, 1);
         multi->members.push_back(member);
         hipEvent_t ev = nullptr, ev2 = nullptr;
-        (void)hipSetDevice(devices[i]);
-        if (hipEventCreate(&ev) != hipSuccess || hipEventCreate(&ev2) != hipSuccess)
-            return cleanup(sharded_fail(error, swh_device_error_k, "hipEventCreate failed"));
-        multi->done.push_back(ev);
-        multi->begin.push_back(ev2);
+        uint64_t *check = nullptr;
+        if (hipSetDevice(devices[i]) != hipSuccess) return cleanup(sharded_fail(error, swh_device_error_k, "hipSetDevice failed"));
+        if (hipEventCreate(&ev) == hipSuccess) multi->done.push_back(ev);
+        if (hipEventCreate(&ev2) == hipSuccess) multi->begin.push_back(ev2);
+        if (hipMalloc((void **)&check, (2 + (i == 0 ? 2 * (size_t)count : 0)) * sizeof(uint64_t)) == hipSuccess) multi->check_dev.push_back(check);
+        if (!ev || !ev2 || !check) return cleanup(sharded_fail(error, swh_device_error_k, "per-device events / check words could not be created"));
     }
-    (void)hipSetDevice(devices[0]);
-    if (hipEventCreate(&multi->gathered) != hipSuccess || hipEventCreate(&multi->gather_begin) != hipSuccess)
-        return cleanup(sharded_fail(error, swh_device_error_k, "hipEventCreate failed"));
-    if (distinct && count > 1) {
+    if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreate(&multi->gathered) != hipSuccess || hipEventCreate(&multi->gather_begin) != hipSuccess ||
+        hipStreamCreateWithFlags(&multi->gather_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&multi->check_host, 4 * (size_t)count * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess)
+        return cleanup(sharded_fail(error, swh_device_error_k, "gather stream / events of the first device could not be created"));
+    // Test hooks (read per call): STRINGWARS_AMD_RCCL=off makes a scope of several members fail the way a missing RCCL does;
+    // =force builds the communicator whatever the device list looks like -- one member (a one-rank communicator: the real
+    // ncclCommInitAll / group / destroy calls on a one-GPU box) or members sharing a device (which RCCL refuses).
+    const char *rccl_knob = getenv("STRINGWARS_AMD_RCCL");
+    const bool rccl_off = rccl_knob && strcmp(rccl_knob, "off") == 0, rccl_force = rccl_knob && strcmp(rccl_knob, "force") == 0;
+    if (rccl_off && count > 1)
+        return cleanup(sharded_fail(error, swh_rccl_error_k, "RCCL (librccl.so) could not be loaded: %s", "disabled by STRINGWARS_AMD_RCCL=off"));
+    if ((distinct && count > 1) || rccl_force) {
         RcclApi &api = rccl();
-        if (!api.ready()) return cleanup(sharded_fail(error, swh_rccl_error_k, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"));
+        const char *why = api.ready() ? nullptr : dlerror();   // (dlerror() clears the state: read it once)
+        if (!api.ready()) return cleanup(sharded_fail(error, swh_rccl_error_k, "RCCL (librccl.so) could not be loaded: %s", why ? why : "symbols missing"));
         multi->comms.resize(count);
         const int rc = api.CommInitAll(multi->comms.data(), count, devices);
         if (rc != 0) {
             multi->comms.clear();
             return cleanup(sharded_fail(error, swh_rccl_error_k, "ncclCommInitAll failed: %s", api.GetErrorString ? api.GetErrorString(rc) : "?"));
         }
-        for (int i = 0; i < count; ++i)   // peers read each other's result buffers only through RCCL; enable P2P anyway for fallbacks
-            for (int j = 0; j < count; ++j)
-                if (i != j) { (void)hipSetDevice(devices[i]); (void)hipDeviceEnablePeerAccess(devices[j], 0); (void)hipGetLastError(); }
-        (void)hipSetDevice(devices[0]);
+        // (peers exchange results only through RCCL, which sets up its own peer mappings: no hipDeviceEnablePeerAccess here)
+        if (hipSetDevice(devices[0]) != hipSuccess) return cleanup(sharded_fail(error, swh_device_error_k, "hipSetDevice failed"));
     }
     ((Scope *)parent)->multi = multi.release();
     *out = parent;
@@ -208,6 +231,10 @@ void free_multi_scope(void *handle) {
     for (hipEvent_t ev : multi->begin) (void)hipEventDestroy(ev);
     if (multi->gathered) (void)hipEventDestroy(multi->gathered);
     if (multi->gather_begin) (void)hipEventDestroy(multi->gather_begin);
+    if (multi->gather_stream) (void)hipStreamDestroy(multi->gather_stream);
+    if (multi->check_host) (void)hipHostFree(multi->check_host);
+    for (size_t i = 0; i < multi->check_dev.size(); ++i) { (void)hipSetDevice(multi->devices[i]); (void)hipFree(multi->check_dev[i]); }
+    if (!multi->devices.empty()) (void)hipSetDevice(multi->devices[0]);
     for (swh_scope_t member : multi->members) swh_scope_free(member);
     delete multi;
 }
@@ -315,65 +342,151 @@ swh_status_t swh_levenshtein_pairs_sharded(swh_levenshtein_t engine, swh_scope_t
     MultiScope *multi = (MultiScope *)scope->multi;
     const size_t members = multi->members.size();
     auto stream_of = [&](size_t r) { return ((Scope *)multi->members[r])->stream; };
-    // every shard on its own device, asynchronously
-    for (size_t r = 0; r < members; ++r) {
+    // Every HIP call is checked: a failure drains what was enqueued and comes back as swh_device_error_k with the call's name.
+    hipError_t hip_error = hipSuccess;
+    const char *hip_what = "";
+    auto drain = [&]() {
+        for (size_t q = 0; q < members; ++q) { (void)hipSetDevice(multi->devices[q]); (void)hipStreamSynchronize(stream_of(q)); swh_scope_synchronize(multi->members[q], nullptr); }
+        (void)hipSetDevice(multi->devices[0]);
+        (void)hipStreamSynchronize(multi->gather_stream);
+        (void)hipGetLastError();
+    };
+#define SWH_SHARD_HIP(expr)                                                                                   \
+    do {                                                                                                      \
+        if (hip_error == hipSuccess) { hip_error = (expr); if (hip_error != hipSuccess) hip_what = #expr; }   \
+    } while (0)
+#define SWH_SHARD_BAIL()                                                                                                          \
+    do {                                                                                                                          \
+        if (hip_error != hipSuccess) {                                                                                            \
+            drain();                                                                                                              \
+            return sharded_fail(error, swh_device_error_k, "HIP error '%s' in the sharded call at %s", hipGetErrorString(hip_error), hip_what); \
+        }                                                                                                                         \
+    } while (0)
+    // The first call of a scope verifies its gather end to end (STRINGWARS_AMD_SHARD_CHECK=1: every call, =0: never): (sum,
+    // xor) of every shard's distances computed on the shard's device and again over its range of the gathered vector on the
+    // first device. A first real multi-GPU run so validates the RCCL path by itself.
+    static const int check_knob = [] { const char *e = getenv("STRINGWARS_AMD_SHARD_CHECK"); return e ? atoi(e) : -1; }();
+    const bool self_check = check_knob == 1 || (check_knob != 0 && !multi->checked_once);
+    // Shards of a quarter of a million pairs or more are scored in four pieces, the send of piece j enqueued behind its kernel
+    // so that it travels while piece j + 1 is scored; the receives run on a stream of their own on the first device.
+    constexpr size_t kPieces = 4, kMinPiecePairs = 65536;
+    size_t largest = 0;
+    for (size_t r = 0; r < members; ++r) largest = std::max<size_t>(largest, (size_t)(sp->cuts[r + 1] - sp->cuts[r]));
+    const size_t pieces = largest >= kPieces * kMinPiecePairs ? kPieces : 1;
+    auto piece_range = [&](size_t r, size_t j, size_t &lo, size_t &hi) {
         const size_t n = (size_t)(sp->cuts[r + 1] - sp->cuts[r]);
-        (void)hipSetDevice(multi->devices[r]);
-        (void)hipEventRecord(multi->begin[r], stream_of(r));
-        if (n) {
-            swh_prepared_view_t va{sp->a[r], 0, n}, vb{sp->b[r], 0, n};
-            swh_status_t status = swh_levenshtein_pairs_prepared(engine, multi->members[r], &va, &vb, bound, sp->results[r], 4, error);
-            if (status != swh_success_k) {
-                for (size_t q = 0; q <= r; ++q) swh_scope_synchronize(multi->members[q], nullptr);
-                return status;
+        lo = n * j / pieces; hi = n * (j + 1) / pieces;
+    };
+    SWH_SHARD_HIP(hipSetDevice(multi->devices[0]));
+    SWH_SHARD_HIP(hipEventRecord(multi->gather_begin, stream_of(0)));
+    SWH_SHARD_HIP(hipStreamWaitEvent(multi->gather_stream, multi->gather_begin, 0));   // receives overwrite `gathered`: not before the previous call's copy-out
+    SWH_SHARD_BAIL();
+    for (size_t j = 0; j < pieces; ++j) {
+        for (size_t r = 0; r < members; ++r) {
+            size_t lo, hi;
+            piece_range(r, j, lo, hi);
+            SWH_SHARD_HIP(hipSetDevice(multi->devices[r]));
+            if (j == 0) SWH_SHARD_HIP(hipEventRecord(multi->begin[r], stream_of(r)));
+            SWH_SHARD_BAIL();
+            if (hi > lo) {
+                swh_prepared_view_t va{sp->a[r], lo, hi - lo}, vb{sp->b[r], lo, hi - lo};
+                swh_status_t status = swh_levenshtein_pairs_prepared(engine, multi->members[r], &va, &vb, bound, sp->results[r] + lo, 4, error);
+                if (status != swh_success_k) { drain(); return status; }
             }
+            if (j + 1 == pieces) SWH_SHARD_HIP(hipEventRecord(multi->done[r], stream_of(r)));
         }
-        (void)hipEventRecord(multi->done[r], stream_of(r));
+        SWH_SHARD_BAIL();
+        // piece j of shards 1.. to the first device
+        if (!multi->comms.empty()) {
+            RcclApi &api = rccl();
+            int rc = api.GroupStart();
+            for (size_t r = 1; r < members && rc == 0; ++r) {
+                size_t lo, hi;
+                piece_range(r, j, lo, hi);
+                if (hi <= lo) continue;
+                rc = api.Recv(sp->gathered + sp->cuts[r] + lo, hi - lo, kNcclUint32, (int)r, multi->comms[0], multi->gather_stream);
+                if (rc == 0) rc = api.Send(sp->results[r] + lo, hi - lo, kNcclUint32, 0, multi->comms[r], stream_of(r));
+            }
+            const int rc_end = api.GroupEnd();
+            if (rc == 0) rc = rc_end;
+            if (rc != 0) {
+                drain();
+                return sharded_fail(error, swh_rccl_error_k, "RCCL gather failed: %s", api.GetErrorString ? api.GetErrorString(rc) : "?");
+            }
+        } else if (j + 1 == pieces) {
+            // members sharing one device (testing) or a single member: device-to-device copies ordered by events
+            SWH_SHARD_HIP(hipSetDevice(multi->devices[0]));
+            for (size_t r = 1; r < members; ++r) {
+                const size_t n = (size_t)(sp->cuts[r + 1] - sp->cuts[r]);
+                SWH_SHARD_HIP(hipStreamWaitEvent(multi->gather_stream, multi->done[r], 0));
+                if (n) SWH_SHARD_HIP(hipMemcpyAsync(sp->gathered + sp->cuts[r], sp->results[r], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, multi->gather_stream));
+            }
+            SWH_SHARD_BAIL();
+        }
     }
-    // the one collective: distances of shards 1.. to the first device
-    (void)hipSetDevice(multi->devices[0]);
-    (void)hipEventRecord(multi->gather_begin, stream_of(0));
-    if (!multi->comms.empty()) {
-        RcclApi &api = rccl();
-        int rc = api.GroupStart();
-        for (size_t r = 1; r < members && rc == 0; ++r) {
+    if (self_check) {
+        // on the shard's device, behind its last piece ...
+        for (size_t r = 0; r < members; ++r) {
             const size_t n = (size_t)(sp->cuts[r + 1] - sp->cuts[r]);
-            if (!n) continue;
-            rc = api.Recv(sp->gathered + sp->cuts[r], n, kNcclUint32, (int)r, multi->comms[0], stream_of(0));
-            if (rc == 0) rc = api.Send(sp->results[r], n, kNcclUint32, 0, multi->comms[r], stream_of(r));
+            SWH_SHARD_HIP(hipSetDevice(multi->devices[r]));
+            SWH_SHARD_HIP(hipMemsetAsync(multi->check_dev[r], 0, 2 * sizeof(uint64_t), stream_of(r)));
+            if (n) hipLaunchKernelGGL(k_shard_checksum, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, stream_of(r), sp->results[r], (uint64_t)n,
+                                      (unsigned long long *)multi->check_dev[r]);
+            SWH_SHARD_HIP(hipGetLastError());
+            SWH_SHARD_HIP(hipMemcpyAsync(multi->check_host + 2 * r, multi->check_dev[r], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream_of(r)));
         }
-        const int rc_end = api.GroupEnd();
-        if (rc == 0) rc = rc_end;
-        if (rc != 0) {
-            for (size_t q = 0; q < members; ++q) swh_scope_synchronize(multi->members[q], nullptr);
-            return sharded_fail(error, swh_rccl_error_k, "RCCL gather failed: %s", api.GetErrorString ? api.GetErrorString(rc) : "?");
-        }
-    } else {
-        // members sharing one device (testing) or a single member: device-to-device copies ordered by events
-        for (size_t r = 1; r < members; ++r) {
-            const size_t n = (size_t)(sp->cuts[r + 1] - sp->cuts[r]);
-            (void)hipStreamWaitEvent(stream_of(0), multi->done[r], 0);
-            if (n && hipMemcpyAsync(sp->gathered + sp->cuts[r], sp->results[r], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_of(0)) != hipSuccess)
-                return sharded_fail(error, swh_device_error_k, "device-to-device gather failed");
-        }
+        SWH_SHARD_BAIL();
     }
-    (void)hipEventRecord(multi->gathered, stream_of(0));
-    hipError_t err = hipSuccess;
-    if (sp->pairs) err = hipMemcpyAsync(out, sp->gathered, sp->pairs * sizeof(uint32_t), hipMemcpyDefault, stream_of(0));
-    for (size_t r = 0; r < members && err == hipSuccess; ++r) { (void)hipSetDevice(multi->devices[r]); err = hipStreamSynchronize(stream_of(r)); }
-    (void)hipSetDevice(multi->devices[0]);
-    if (err != hipSuccess) return sharded_fail(error, swh_device_error_k, "HIP error '%s' while gathering the shards", hipGetErrorString(err));
-    for (size_t r = 0; r < members; ++r) swh_scope_synchronize(multi->members[r], nullptr);   // call summaries of the member scopes
+    // the first device's stream continues once the receives are in: the caller's copy, the checks over the gathered ranges
+    SWH_SHARD_HIP(hipSetDevice(multi->devices[0]));
+    SWH_SHARD_HIP(hipEventRecord(multi->gathered, multi->gather_stream));
+    SWH_SHARD_HIP(hipStreamWaitEvent(stream_of(0), multi->gathered, 0));
+    if (const char *fault = getenv("STRINGWARS_AMD_SHARD_FAULT")) {   // test hook: damage one gathered distance of the last shard
+        const size_t r = members - 1, n = (size_t)(sp->cuts[r + 1] - sp->cuts[r]);
+        if (atoi(fault) && n) SWH_SHARD_HIP(hipMemsetAsync(sp->gathered + sp->cuts[r] + n / 2, 0x5A, sizeof(uint32_t), stream_of(0)));
+    }
+    if (self_check) {
+        uint64_t *words = multi->check_dev[0] + 2;
+        SWH_SHARD_HIP(hipMemsetAsync(words, 0, 2 * members * sizeof(uint64_t), stream_of(0)));
+        for (size_t r = 0; r < members; ++r) {
+            const size_t n = (size_t)(sp->cuts[r + 1] - sp->cuts[r]);
+            if (n) hipLaunchKernelGGL(k_shard_checksum, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, stream_of(0), sp->gathered + sp->cuts[r], (uint64_t)n,
+                                      (unsigned long long *)(words + 2 * r));
+        }
+        SWH_SHARD_HIP(hipGetLastError());
+        SWH_SHARD_HIP(hipMemcpyAsync(multi->check_host + 2 * members, words, 2 * members * sizeof(uint64_t), hipMemcpyDeviceToHost, stream_of(0)));
+    }
+    if (sp->pairs) SWH_SHARD_HIP(hipMemcpyAsync(out, sp->gathered, sp->pairs * sizeof(uint32_t), hipMemcpyDefault, stream_of(0)));
+    for (size_t r = 0; r < members; ++r) { SWH_SHARD_HIP(hipSetDevice(multi->devices[r])); SWH_SHARD_HIP(hipStreamSynchronize(stream_of(r))); }
+    SWH_SHARD_HIP(hipSetDevice(multi->devices[0]));
+    SWH_SHARD_BAIL();
+    for (size_t r = 0; r < members; ++r) {   // call summaries of the member scopes (a prepared tape changed under us: device_error)
+        swh_status_t status = swh_scope_synchronize(multi->members[r], error);
+        if (status != swh_success_k) { drain(); return status; }
+    }
+    if (self_check) {
+        multi->checked_once = true;
+        for (size_t r = 0; r < members; ++r)
+            if (multi->check_host[2 * r] != multi->check_host[2 * members + 2 * r] || multi->check_host[2 * r + 1] != multi->check_host[2 * members + 2 * r + 1]) {
+                char which[32];
+                snprintf(which, sizeof which, "%zu", r);
+                return sharded_fail(error, swh_device_error_k, "gathered distances of shard %s differ from what its device computed (checksum mismatch after the %s)",
+                                    which, multi->comms.empty() ? "device-to-device copies" : "RCCL gather");
+            }
+    }
     swh_shard_timing_t timing{};
     for (size_t r = 0; r < members; ++r) {
         float ms = 0;
-        (void)hipSetDevice(multi->devices[r]);
+        SWH_SHARD_HIP(hipSetDevice(multi->devices[r]));
         if (hipEventElapsedTime(&ms, multi->begin[r], multi->done[r]) == hipSuccess && ms > timing.compute_ms) timing.compute_ms = ms;
     }
-    (void)hipSetDevice(multi->devices[0]);
+    SWH_SHARD_HIP(hipSetDevice(multi->devices[0]));
     float gather_ms = 0;
-    if (hipEventElapsedTime(&gather_ms, multi->gather_begin, multi->gathered) == hipSuccess) timing.gather_ms = gather_ms;
+    if (hipEventElapsedTime(&gather_ms, multi->gather_begin, multi->gathered) == hipSuccess) timing.gather_ms = gather_ms;   // first kernel to last receive
     (void)hipGetLastError();
+    SWH_SHARD_BAIL();
+#undef SWH_SHARD_HIP
+#undef SWH_SHARD_BAIL
     timing.cells = sp->cells;
     timing.pairs = sp->pairs;
     multi->timing = timing;

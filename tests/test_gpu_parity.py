@@ -498,6 +498,48 @@ def test_class_table_needleman_wunsch(sw, orc, scope, gaps, classes):
         assert bad.size == 0, (classes, gaps, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
 
 
+@pytest.mark.parametrize("gaps", [(-4, -4), (-11, -1)])
+@pytest.mark.parametrize("classes", [5, 21, 32])
+def test_column_profile_kernel_every_strip_shape(sw, orc, scope, gaps, classes):
+    """nwprofile.hip (global alignment on a class table, pairs of more than 384 columns): every strip width the kernel
+    switches on (4 / 8 / 12 / 16 columns per lane, capped by the class count), column counts just below / at / above a multiple
+    of 64 x the strip and of the pass width, one to five passes, rows shorter and longer than the 64-step ring blocks,
+    symmetric (columns = shorter string) and asymmetric matrices -- and the same batch on the wavefront kernels
+    (`STRINGWARS_AMD_NW=classic` is read once per process, so the comparison runs in a child)."""
+    rng = np.random.default_rng(1000 + classes + gaps[1])
+    byte_to_class = rng.integers(0, classes, 256).astype(np.uint8)
+    costs = np.zeros((32, 32), dtype=np.int8)
+    costs[:classes, :classes] = rng.integers(-9, 12, (classes, classes))
+    strip = 16 if classes <= 16 else (12 if classes <= 24 else 8)
+    cols = sorted({385, 448, 511, 512, 513, 640, 767, 768, 769, 1023, 1024, 1025, 64 * strip - 1, 64 * strip, 64 * strip + 1,
+                   128 * strip, 128 * strip + 1, 192 * strip + 7, 256 * strip - 5, 256 * strip + 3, 3000, 4100})
+    items_a, items_b = [], []
+    for n_cols in cols:
+        for n_rows in (n_cols, n_cols + 1, n_cols + 61, n_cols + 64, n_cols + 130, 2 * n_cols + 3):
+            text = bytes(rng.integers(0, 256, n_rows, dtype=np.uint8))
+            other = bytearray(text[:n_cols]) if rng.random() < 0.5 else bytearray(rng.integers(0, 256, n_cols, dtype=np.uint8).tobytes())
+            for at in rng.integers(0, n_cols, n_cols // 7):
+                other[at] = int(rng.integers(0, 256))
+            if rng.random() < 0.5:
+                items_a.append(text); items_b.append(bytes(other))
+            else:
+                items_a.append(bytes(other)); items_b.append(text)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    for symmetric in (False, True):
+        table = np.minimum(costs, costs.T) if symmetric else costs
+        full = table[byte_to_class][:, byte_to_class].astype(np.int8)
+        want = orc.nw_pairs(a, b, full, *gaps)
+        engine = sw.NeedlemanWunschScores(byte_to_class, table, open=gaps[0], extend=gaps[1], capabilities=scope)
+        scope.set_profiling(True)
+        got = engine.pairs(a, b, scope)
+        assert scope.last_timing()["dominant_name"].startswith("nwprofile"), scope.last_timing()
+        scope.set_profiling(False)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (classes, gaps, symmetric, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+        cross = engine(sw.Strs(items_a[:3]), sw.Strs(items_b[:4]), scope)      # the cross-product entry point takes the same route
+        assert (cross == np.array([[orc.nw_score(x, y, full, *gaps) for y in items_b[:4]] for x in items_a[:3]])).all()
+
+
 def test_smith_waterman(sw, orc, scope):
     """`SmithWatermanScores` (bench.rs:882-963): KATs of SURVEY 8c, random matrices, multi-pass, cross-product."""
     cases = KAT["sw_unary_2_m1"]["cases"]
@@ -677,6 +719,11 @@ def test_prepared_utf8_tapes(sw, orc, scope):
     assert (engine.pairs(xa, xb, scope) == orc.levenshtein_pairs(ta, tb, algo="hyyro")).all()
     mixed = engine.pairs(xa[:1500], pb, scope)                              # ASCII against non-ASCII: code points
     assert (mixed == orc.levenshtein_pairs(ta.subview(0, 1500), b, utf8=True)).all()
+    # whether a call is accepted does not depend on what the tapes hold: u32 offsets on one side, u64 on the other work for
+    # ASCII tapes (which otherwise take the byte kernels' shortcut) exactly as for non-ASCII ones
+    narrow = sw.PreparedTape(scope, ta.with_offsets(np.uint32), utf8=True)
+    assert (engine.pairs(narrow, xb, scope) == orc.levenshtein_pairs(ta, tb, algo="hyyro")).all()
+    assert (engine.pairs(sw.PreparedTape(scope, a.with_offsets(np.uint32), utf8=True), pb, scope, bound=32) == np.minimum(want, 33)).all()
 
 
 def test_prepared_cross_product_and_alignment(sw, orc, scope):
@@ -908,6 +955,27 @@ def test_prepared_tapes_in_asynchronous_and_pipelined_scopes(sw, orc):
                 assert (out.cpu().numpy().astype(np.uint32) == want).all()
         scope.set_pipelined(False)
         scope.set_async(False)
+    # A prepared tape is measured once; its device memory is the caller's. If the caller changes it afterwards -- here: every
+    # first string grows beyond what the plan-free kernel can score -- an asynchronous call cannot be redone
+    # behind the caller's back: the next synchronisation reports it instead of leaving stale distances unnoticed.
+    a, b = sw.generate_pairs("tokens64", 40_000, seed=9)
+    da, db = a.to_device(scope), b.to_device(scope)
+    pa, pb = sw.PreparedTape(scope, da), sw.PreparedTape(scope, db)
+    out = torch.zeros(40_000, dtype=torch.int32, device="cuda")
+    assert (engine.pairs(pa, pb, scope, out=out).cpu().numpy().astype(np.uint32) == orc.levenshtein_pairs(a, b, algo="hyyro")).all()
+    grown = a.offsets[:62].copy()
+    grown[1:61] = grown[61]                                       # the first string of tape a now spans 61 tokens (~3.9 KB: more than the 64 blocks
+                                                                  # of 32 rows the plan-free kernel can score), sixty are empty
+    import ctypes as C
+    from stringwars_amd import _native as N
+    N.check(N.lib.swh_copy_to_device(scope.handle, C.c_void_p(da.offsets_ptr), grown.ctypes.data, grown.nbytes, None), C.c_char_p())
+    scope.set_async(True)
+    engine.pairs(pa, pb, scope, out=out)
+    with pytest.raises(sw.StringWarsError) as info:
+        scope.synchronize()
+    assert info.value.status == "invalid_argument" and "not scored" in str(info.value)
+    scope.synchronize()                                           # reported once
+    scope.set_async(False)
 
 
 def test_multi_device_scope_on_one_gpu(sw, orc):
@@ -942,9 +1010,57 @@ def test_multi_device_scope_on_one_gpu(sw, orc):
     other = sw.Strs([b"y" * 2900, b"q", b"", b"c"] + [b"w"] * 50)
     batch = sw.ShardedPairs(scope, ragged, other)
     assert (sw.LevenshteinDistances(capabilities=scope).pairs_sharded(batch, scope) == orc.levenshtein_pairs(ragged, other)).all()
-    with pytest.raises(sw.StringWarsError):
-        sw.NeedlemanWunschScores(*sw.unary_class_costs(2, -1), open=-2, extend=-2, capabilities=scope)  # engines are fine ...
-        sw.ShardedPairs(sw.DeviceScope(gpu_device=0), a, b)                   # ... but a single-device scope does not shard
+    # alignment engines can be created on a multi-device scope (they run on its first device) ...
+    nw = sw.NeedlemanWunschScores(*sw.unary_class_costs(2, -1), open=-2, extend=-2, capabilities=scope)
+    assert nw.pairs(sw.Strs([b"GATTACA"]), sw.Strs([b"GCATGCU"]), scope).tolist() == [2]
+    with pytest.raises(sw.StringWarsError) as info:                          # ... but a single-device scope does not shard
+        sw.ShardedPairs(sw.DeviceScope(gpu_device=0), a, b)
+    assert info.value.status == "invalid_argument"
+
+
+def test_sharded_call_pieces_self_check_and_error_paths(sw, orc, monkeypatch):
+    """`swh_levenshtein_pairs_sharded` beyond the happy path: shards large enough to be scored in four pieces (the send of a piece
+    enqueued behind its kernel), the gather's self-check (per-shard checksums computed on the shard's device and again over the
+    gathered vector: first call of a scope, every call with STRINGWARS_AMD_SHARD_CHECK=1) catching a damaged distance, HIP and
+    RCCL failures surfacing as statuses -- an unknown device, RCCL unavailable, a communicator RCCL refuses -- and RCCL's own
+    entry points (init of a one-rank communicator, an empty group, destroy) on this box's single GPU."""
+    a, b = sw.generate_pairs("short_words", 1_200_000, seed=33)
+    scope = sw.DeviceScope(gpu_devices=[0, 0, 0])
+    engine = sw.LevenshteinDistances(capabilities=scope)
+    single = sw.DeviceScope(gpu_device=0)
+    want = sw.LevenshteinDistances(capabilities=single).pairs(a, b, single)
+    assert (want[:50_000] == orc.levenshtein_pairs(a, b, algo="hyyro", count=50_000)).all()
+    batch = sw.ShardedPairs(scope, a, b)
+    cuts = batch.cuts
+    assert min(hi - lo for lo, hi in zip(cuts, cuts[1:])) >= 4 * 65536          # every shard runs as four pieces
+    for _ in range(2):                                                           # first call: self-checked; second: not
+        assert (engine.pairs_sharded(batch, scope) == want).all()
+    monkeypatch.setenv("STRINGWARS_AMD_SHARD_FAULT", "1")
+    assert (engine.pairs_sharded(batch, scope) != want).sum() == 1              # unchecked: the damaged word gets through
+    fresh = sw.DeviceScope(gpu_devices=[0, 0])                                   # a scope's first call checks itself
+    fresh_batch = sw.ShardedPairs(fresh, a, b)
+    with pytest.raises(sw.StringWarsError) as info:
+        sw.LevenshteinDistances(capabilities=fresh).pairs_sharded(fresh_batch, fresh)
+    assert info.value.status == "device_error" and "checksum mismatch" in str(info.value)
+    monkeypatch.delenv("STRINGWARS_AMD_SHARD_FAULT")
+    assert (sw.LevenshteinDistances(capabilities=fresh).pairs_sharded(fresh_batch, fresh) == want).all()
+    # failures come back as statuses, and nothing is left behind
+    with pytest.raises(sw.StringWarsError) as info:
+        sw.DeviceScope(gpu_devices=[0, 977])
+    assert info.value.status in ("no_device", "device_error", "invalid_argument")
+    monkeypatch.setenv("STRINGWARS_AMD_RCCL", "off")
+    with pytest.raises(sw.StringWarsError) as info:
+        sw.DeviceScope(gpu_devices=[0, 0])
+    assert info.value.status == "rccl_error" and "could not be loaded" in str(info.value)
+    monkeypatch.setenv("STRINGWARS_AMD_RCCL", "force")
+    with pytest.raises(sw.StringWarsError) as info:                             # one GPU twice in a communicator: RCCL says no
+        sw.DeviceScope(gpu_devices=[0, 0])
+    assert info.value.status == "rccl_error" and "ncclCommInitAll failed" in str(info.value)
+    alone = sw.DeviceScope(gpu_devices=[0])                                      # a one-rank communicator: RCCL's init / group / destroy run
+    monkeypatch.delenv("STRINGWARS_AMD_RCCL")
+    one = sw.ShardedPairs(alone, a.subview(0, 300_000), b.subview(0, 300_000))
+    assert (sw.LevenshteinDistances(capabilities=alone).pairs_sharded(one, alone) == want[:300_000]).all()
+    del one, alone
 
 
 BAD_UTF8 = [b"\xff", b"\xc0\x80", b"\xc1\xbf", b"\xe0\x80\x80", b"\xe0\x9f\xbf", b"\xed\xa0\x80", b"\xed\xbf\xbf",
@@ -1257,8 +1373,16 @@ def test_comparison_knobs_keep_parity(shapes):
         "assert (got[1::2] == 0).all() and (got[0::2] >= 100).all() and (got[0::2] <= 2200).all()\n"
         "pick = list(range(0, 4300, 430))\n"
         "assert got[pick].tolist() == oracle.levenshtein_pairs(sw.Strs([la[i] for i in pick]), sw.Strs([lb[i] for i in pick]), algo='hyyro').tolist()\n"
+        "pa, pb = sw.generate_pairs('protein4k', 6, seed=5)\n"
+        "matrix = sw.substitution_matrix(5)\n"
+        "for gaps in ((-4, -4), (-11, -1)):\n"
+        "    scope.set_profiling(True)\n"
+        "    got = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope).pairs(pa, pb, scope)\n"
+        "    assert scope.last_timing()['dominant_name'].startswith('wavefront_class'), scope.last_timing()   # STRINGWARS_AMD_NW=classic\n"
+        "    scope.set_profiling(False)\n"
+        "    assert (got == oracle.nw_pairs(pa, pb, matrix, *gaps)).all(), gaps\n"
         "print('knobs ok')\n")
-    env = dict(os.environ, **shapes, STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct",
+    env = dict(os.environ, **shapes, STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct", STRINGWARS_AMD_NW="classic",
                STRINGWARS_AMD_LONG_TICKET="0", STRINGWARS_AMD_BAND_ITEMS="fixed", STRINGWARS_AMD_BAND_CAP="64",
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

@@ -273,6 +273,12 @@ swh_status_t swh_sw_pairs_prepared(swh_sw_t engine, swh_scope_t scope, const swh
 swh_status_t swh_sw_cross_prepared(swh_sw_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
                                    const swh_prepared_view_t *b, ptrdiff_t *out, size_t row_stride_bytes, const char **error);
 
+/* Needleman-Wunsch / Smith-Waterman scores of a sharded batch (swh_sharded_prepare_*): the engine's matrix is cloned to every
+ * device of the scope on first use -- the `<Ngpu>` twin of the bench.rs:658-670 / :882-963 rows (the engines'
+ * read-only state is replicated); scores gathered to the first device like the distances of swh_levenshtein_pairs_sharded */
+swh_status_t swh_nw_pairs_sharded(swh_nw_t engine, swh_scope_t scope, swh_sharded_t sharded, int32_t *out, const char **error);
+swh_status_t swh_sw_pairs_sharded(swh_sw_t engine, swh_scope_t scope, swh_sharded_t sharded, int32_t *out, const char **error);
+
 /* ---- Introspection: `log_stringzilla_metadata` (utils.rs:78-92). --------------------------- */
 const char *swh_version(void);
 /* Comma-separated capability string, e.g. "gfx950,hip,wavefront,bitparallel,banded,utf8,...". */

@@ -236,6 +236,12 @@ public:
         swh_status_t status__ = swh_nw_pairs_u64tape(handle_, scope.handle(), &ta, &tb, out, 4, &err);
         check(status__, err);
     }
+    /// One batch over every GPU of a multi-device scope (the matrix is cloned to each device on first use).
+    void pairs_into(const DeviceScope &scope, const ShardedPairs &batch, int32_t *out) const {
+        const char *err = nullptr;
+        swh_status_t status__ = swh_nw_pairs_sharded(handle_, scope.handle(), batch.handle(), out, &err);
+        check(status__, err);
+    }
 };
 
 /// `SmithWatermanScores` (bench.rs:81, :882-963): local alignment scores, same construction as NeedlemanWunschScores.

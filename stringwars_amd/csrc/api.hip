@@ -4,6 +4,7 @@
 // scratch carving, the device pre-pass, kernel dispatch and optional hipEvent timing. There is no
 // CPU compute path in this library: without a HIP device every entry point fails with
 // swh_no_device_k.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1013,6 +1014,7 @@ swh_status_t swh_levenshtein_free(swh_levenshtein_t handle) {
     if (!engine) return swh_success_k;
     if (engine->matrix_dev) { (void)hipSetDevice(engine->device); (void)hipFree(engine->matrix_dev); }
     if (engine->class_dev) { (void)hipSetDevice(engine->device); (void)hipFree(engine->class_dev); }
+    delete[] engine->matrix_host;
     delete engine;
     return swh_success_k;
 }
@@ -1022,6 +1024,10 @@ swh_status_t swh_levenshtein_set_algorithm(swh_levenshtein_t handle, swh_algorit
     return swh_success_k;
 }
 
+static uint64_t next_engine_uid() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1);
+}
 static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *matrix, int open, int extend, void **out,
                                    const char **error) {
     if (!handle || !out || !matrix) return fail(error, swh_invalid_argument_k, "null argument");
@@ -1038,6 +1044,9 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
         for (int j = 0; j < i; ++j)
             if (matrix[i * 256 + j] != matrix[j * 256 + i]) { symmetric = false; break; }
     engine->unit_costs = symmetric;  // reused as "columns may be swapped" for nw engines
+    engine->matrix_host = new int8_t[65536];
+    memcpy(engine->matrix_host, matrix, 65536);
+    engine->uid = next_engine_uid();
     (void)hipSetDevice(scope->device);
     swh_status_t st = upload_matrix(engine, matrix, error);
     if (st != swh_success_k) { delete engine; return st; }
@@ -1084,6 +1093,14 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
     *out = engine;
     return swh_success_k;
 }
+}  // extern "C"
+namespace swh {
+swh_status_t clone_alignment_engine(const Engine *source, swh_scope_t scope, void **out, const char **error) {
+    if (!source || source->kind == 0 || !source->matrix_host) return fail(error, swh_invalid_argument_k, "not an alignment engine");
+    return alignment_init(source->kind, scope, source->matrix_host, source->scoring.open, source->scoring.extend, out, error);
+}
+}  // namespace swh
+extern "C" {
 static swh_status_t alignment_init_classes(int kind, swh_scope_t handle, const uint8_t *byte_to_class,
                                            const int8_t *class_costs, int open, int extend, void **out, const char **error) {
     if (!byte_to_class || !class_costs) return fail(error, swh_invalid_argument_k, "null argument");

@@ -354,7 +354,11 @@ struct Engine {
     int8_t *matrix_dev;  // owned
     uint8_t *class_dev;  // owned
     int device;
+    int8_t *matrix_host; // owned copy of the 256x256 matrix (alignment engines): a multi-device scope clones the engine per device
+    uint64_t uid;        // never reused: keys the per-device clones (sharded.hip)
 };
+// (api.hip) an alignment engine like `source` -- kind, matrix, gaps -- with its tables on `scope`'s device
+swh_status_t clone_alignment_engine(const Engine *source, swh_scope_t scope, void **out, const char **error);
 
 // Kernel launch bookkeeping with optional hipEvent timing.
 struct StampGuard {

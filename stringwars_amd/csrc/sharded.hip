@@ -18,6 +18,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <unordered_map>
 
 #include "common.hpp"
 #include "../../include/stringwars_amd_harness.h"
@@ -74,6 +75,8 @@ struct MultiScope {
     std::vector<uint64_t *> check_dev;     // per member, on its device: 2 words; first device: 2 words per member more
     bool same_device = false;
     bool checked_once = false;             // the first call of a scope verifies its gather (swh_levenshtein_pairs_sharded)
+    // alignment engines keep their tables on ONE device: per engine (by its uid), one clone per member, made on first use
+    std::unordered_map<uint64_t, std::vector<void *>> engine_clones;
     swh_shard_timing_t timing{};
 };
 
@@ -235,6 +238,8 @@ void free_multi_scope(void *handle) {
     if (multi->check_host) (void)hipHostFree(multi->check_host);
     for (size_t i = 0; i < multi->check_dev.size(); ++i) { (void)hipSetDevice(multi->devices[i]); (void)hipFree(multi->check_dev[i]); }
     if (!multi->devices.empty()) (void)hipSetDevice(multi->devices[0]);
+    for (auto &entry : multi->engine_clones)
+        for (void *clone : entry.second) if (clone) swh_nw_free((swh_nw_t)clone);
     for (swh_scope_t member : multi->members) swh_scope_free(member);
     delete multi;
 }
@@ -330,14 +335,16 @@ swh_status_t swh_sharded_cuts(swh_sharded_t sharded, size_t *cuts, size_t capaci
     return swh_success_k;
 }
 
-swh_status_t swh_levenshtein_pairs_sharded(swh_levenshtein_t engine, swh_scope_t handle, swh_sharded_t sharded, uint32_t bound,
-                                           uint32_t *out, const char **error) {
+}  // extern "C"
+
+// One sharded call: every member scores its shard (in pieces) with `score(member index, views, destination)`, the 32-bit
+// results are gathered on the first device and handed to the caller. Levenshtein distances and alignment scores alike.
+typedef swh_status_t (*ShardScore)(void *engine, swh_scope_t member, const swh_prepared_view_t *a, const swh_prepared_view_t *b,
+                                   uint32_t bound, uint32_t *dst, const char **error);
+static swh_status_t sharded_call(const std::vector<void *> &engines, ShardScore score, swh_scope_t handle, swh_sharded_t sharded, uint32_t bound,
+                                 uint32_t *out, const char **error) {
     Scope *scope = (Scope *)handle;
     ShardedPairs *sp = (ShardedPairs *)sharded;
-    if (!scope || !scope->multi || !sp || sp->scope != scope) return sharded_fail(error, swh_invalid_argument_k, "scope and sharded batch do not belong together");
-    if (!engine) return sharded_fail(error, swh_invalid_argument_k, "null engine");
-    if (((const Engine *)engine)->kind != 0 || ((const Engine *)engine)->matrix_dev)
-        return sharded_fail(error, swh_not_implemented_k, "sharded calls take Levenshtein engines with linear gap costs (no per-device tables)");
     if (!out && sp->pairs) return sharded_fail(error, swh_invalid_argument_k, "null output pointer");
     MultiScope *multi = (MultiScope *)scope->multi;
     const size_t members = multi->members.size();
@@ -390,7 +397,7 @@ swh_status_t swh_levenshtein_pairs_sharded(swh_levenshtein_t engine, swh_scope_t
             SWH_SHARD_BAIL();
             if (hi > lo) {
                 swh_prepared_view_t va{sp->a[r], lo, hi - lo}, vb{sp->b[r], lo, hi - lo};
-                swh_status_t status = swh_levenshtein_pairs_prepared(engine, multi->members[r], &va, &vb, bound, sp->results[r] + lo, 4, error);
+                swh_status_t status = score(engines[r], multi->members[r], &va, &vb, bound, sp->results[r] + lo, error);
                 if (status != swh_success_k) { drain(); return status; }
             }
             if (j + 1 == pieces) SWH_SHARD_HIP(hipEventRecord(multi->done[r], stream_of(r)));
@@ -491,6 +498,62 @@ swh_status_t swh_levenshtein_pairs_sharded(swh_levenshtein_t engine, swh_scope_t
     timing.pairs = sp->pairs;
     multi->timing = timing;
     return swh_success_k;
+}
+
+static swh_status_t sharded_arguments(swh_scope_t handle, swh_sharded_t sharded, const void *engine, const char **error) {
+    Scope *scope = (Scope *)handle;
+    ShardedPairs *sp = (ShardedPairs *)sharded;
+    if (!scope || !scope->multi || !sp || sp->scope != scope) return sharded_fail(error, swh_invalid_argument_k, "scope and sharded batch do not belong together");
+    if (!engine) return sharded_fail(error, swh_invalid_argument_k, "null engine");
+    return swh_success_k;
+}
+
+// Alignment engines keep a substitution matrix (and its class table) on one device: a multi-device scope clones the engine
+// per member on first use (keyed by the engine's uid; the clones live as long as the scope).
+static swh_status_t alignment_sharded(int kind, void *engine, swh_scope_t handle, swh_sharded_t sharded, int32_t *out, const char **error) {
+    swh_status_t status = sharded_arguments(handle, sharded, engine, error);
+    if (status != swh_success_k) return status;
+    const Engine *source = (const Engine *)engine;
+    if (source->kind != kind || !source->matrix_host) return sharded_fail(error, swh_invalid_argument_k, "not an engine of this kind");
+    if (((ShardedPairs *)sharded)->utf8) return sharded_fail(error, swh_not_implemented_k, "substitution-matrix scoring over UTF-8 code points (the matrix is indexed by bytes)");
+    MultiScope *multi = (MultiScope *)((Scope *)handle)->multi;
+    std::vector<void *> &clones = multi->engine_clones[source->uid];
+    if (clones.empty()) {
+        clones.assign(multi->members.size(), nullptr);
+        for (size_t r = 0; r < multi->members.size(); ++r) {
+            status = clone_alignment_engine(source, multi->members[r], &clones[r], error);
+            if (status != swh_success_k) {
+                for (void *clone : clones) if (clone) swh_nw_free((swh_nw_t)clone);
+                multi->engine_clones.erase(source->uid);
+                return status;
+            }
+        }
+    }
+    ShardScore score = kind == 1
+        ? (ShardScore)[](void *e, swh_scope_t m, const swh_prepared_view_t *a, const swh_prepared_view_t *b, uint32_t, uint32_t *dst, const char **err) {
+              return swh_nw_pairs_prepared((swh_nw_t)e, m, a, b, (int32_t *)dst, 4, err); }
+        : (ShardScore)[](void *e, swh_scope_t m, const swh_prepared_view_t *a, const swh_prepared_view_t *b, uint32_t, uint32_t *dst, const char **err) {
+              return swh_sw_pairs_prepared((swh_sw_t)e, m, a, b, (int32_t *)dst, 4, err); };
+    return sharded_call(clones, score, handle, sharded, SWH_UNBOUNDED, (uint32_t *)out, error);
+}
+
+extern "C" {
+
+swh_status_t swh_levenshtein_pairs_sharded(swh_levenshtein_t engine, swh_scope_t handle, swh_sharded_t sharded, uint32_t bound,
+                                           uint32_t *out, const char **error) {
+    swh_status_t status = sharded_arguments(handle, sharded, engine, error);
+    if (status != swh_success_k) return status;
+    if (((const Engine *)engine)->kind != 0) return sharded_fail(error, swh_invalid_argument_k, "not a Levenshtein engine");
+    // (Levenshtein engines hold no device tables: one engine serves every member)
+    const std::vector<void *> engines(((MultiScope *)((Scope *)handle)->multi)->members.size(), (void *)engine);
+    return sharded_call(engines, [](void *e, swh_scope_t m, const swh_prepared_view_t *a, const swh_prepared_view_t *b, uint32_t k, uint32_t *dst, const char **err) {
+        return swh_levenshtein_pairs_prepared((swh_levenshtein_t)e, m, a, b, k, dst, 4, err); }, handle, sharded, bound, out, error);
+}
+swh_status_t swh_nw_pairs_sharded(swh_nw_t engine, swh_scope_t scope, swh_sharded_t sharded, int32_t *out, const char **error) {
+    return alignment_sharded(1, engine, scope, sharded, out, error);
+}
+swh_status_t swh_sw_pairs_sharded(swh_sw_t engine, swh_scope_t scope, swh_sharded_t sharded, int32_t *out, const char **error) {
+    return alignment_sharded(2, engine, scope, sharded, out, error);
 }
 
 // One-shot convenience: shard, upload, score, gather, free. The steady state keeps the swh_sharded_t.

@@ -564,6 +564,18 @@ class NeedlemanWunschScores(_Engine):
         return self._pairs(getattr(N.lib, self._prefix + "_pairs_u32tape"), getattr(N.lib, self._prefix + "_pairs_u64tape"),
                            a, b, scope, out, np.int32)
 
+    def pairs_sharded(self, batch: "ShardedPairs", scope: DeviceScope, out=None):
+        """One batch over every GPU of a multi-device scope (the matrix is cloned to every device on first use); the scores
+        come back gathered, in pair order."""
+        if batch.utf8:
+            raise ValueError("alignment engines score bytes: the sharded batch was prepared as UTF-8")
+        if out is None:
+            out = np.zeros(batch.count, dtype=np.int32)
+        err = C.c_char_p()
+        status = getattr(N.lib, self._prefix + "_pairs_sharded")(self._handle, scope.handle, batch._handle, C.c_void_p(_pointer(out)), C.byref(err))
+        N.check(status, err)
+        return out
+
     def __del__(self):
         if getattr(self, "_handle", None) and getattr(N, "lib", None) is not None:   # module globals go first at exit
             getattr(N.lib, self._prefix + "_free")(self._handle)

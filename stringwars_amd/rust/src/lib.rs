@@ -102,6 +102,8 @@ extern "C" {
     fn swh_sharded_free(sharded: Handle) -> c_int;
     fn swh_sharded_cuts(sharded: Handle, cuts: *mut usize, capacity: usize) -> c_int;
     fn swh_levenshtein_pairs_sharded(engine: Handle, scope: Handle, sharded: Handle, bound: u32, out: *mut u32, error: Err) -> c_int;
+    fn swh_nw_pairs_sharded(engine: Handle, scope: Handle, sharded: Handle, out: *mut i32, error: Err) -> c_int;
+    fn swh_sw_pairs_sharded(engine: Handle, scope: Handle, sharded: Handle, out: *mut i32, error: Err) -> c_int;
     fn swh_levenshtein_pairs_sharded_u64tape(engine: Handle, scope: Handle, a: *const TapeU64, b: *const TapeU64, bound: u32, out: *mut u32, error: Err) -> c_int;
     // Needleman-Wunsch
     fn swh_nw_init(scope: Handle, substitution_256x256: *const i8, open: c_int, extend: c_int, engine: *mut Handle, error: Err) -> c_int;
@@ -413,7 +415,7 @@ impl Drop for LevenshteinDistancesUtf8 { fn drop(&mut self) { unsafe { swh_leven
 
 /// Alignment engines share their plumbing; `$init*`/`$pairs*`/`$cross*` pick the NW or SW entry points.
 macro_rules! alignment_engine {
-    ($name:ident, $doc:expr, $init:ident, $init_classes:ident, $free:ident, $pairs32:ident, $pairs64:ident, $cross:ident, $pairs_prepared:ident, $cross_prepared:ident) => {
+    ($name:ident, $doc:expr, $init:ident, $init_classes:ident, $free:ident, $pairs32:ident, $pairs64:ident, $cross:ident, $pairs_prepared:ident, $cross_prepared:ident, $pairs_sharded:ident) => {
         #[doc = $doc]
         pub struct $name { handle: Handle }
         impl $name {
@@ -445,6 +447,13 @@ macro_rules! alignment_engine {
                 let mut message = ptr::null();
                 check(unsafe { $pairs_prepared(self.handle, scope.handle, &va, &vb, out.as_mut_ptr(), 4, &mut message) }, message)
             }
+            /// One batch over every GPU of a multi-device scope: the matrix is cloned to each device on first use, the scores
+            /// are gathered inside the library (RCCL) in pair order.
+            pub fn pairs_into_sharded_resident(&self, scope: &DeviceScope, batch: &ShardedPairs, out: &mut [i32]) -> Result<(), Error> {
+                assert!(out.len() >= batch.len());
+                let mut message = ptr::null();
+                check(unsafe { $pairs_sharded(self.handle, scope.handle, batch.handle, out.as_mut_ptr(), &mut message) }, message)
+            }
             /// `compute_into(..) -> UnifiedMat<isize>` (bench.rs:814-821, :872-876).
             pub fn compute_into(&self, scope: &DeviceScope, queries: &BytesTapeView<u64>, candidates: Option<&BytesTapeView<u64>>, matrix: &mut [isize]) -> Result<(), Error> {
                 let columns = candidates.map_or(queries.len(), |c| c.len());
@@ -467,10 +476,10 @@ macro_rules! alignment_engine {
 }
 alignment_engine!(NeedlemanWunschScores, "`szs::NeedlemanWunschScores` (bench.rs:658-670): global alignment scores, linear or affine gaps.",
                   swh_nw_init, swh_nw_init_classes, swh_nw_free, swh_nw_pairs_u32tape, swh_nw_pairs_u64tape, swh_nw_cross_u64tape,
-                  swh_nw_pairs_prepared, swh_nw_cross_prepared);
+                  swh_nw_pairs_prepared, swh_nw_cross_prepared, swh_nw_pairs_sharded);
 alignment_engine!(SmithWatermanScores, "`szs::SmithWatermanScores` (bench.rs:882-963): local alignment scores.",
                   swh_sw_init, swh_sw_init_classes, swh_sw_free, swh_sw_pairs_u32tape, swh_sw_pairs_u64tape, swh_sw_cross_u64tape,
-                  swh_sw_pairs_prepared, swh_sw_cross_prepared);
+                  swh_sw_pairs_prepared, swh_sw_cross_prepared, swh_sw_pairs_sharded);
 
 /// The only route by which parity with the reference's own oracle can be pinned: with `--features verify-rapidfuzz`
 /// every distance of every pairwise call is compared with `rapidfuzz::distance::levenshtein::distance` on the same

@@ -963,12 +963,13 @@ def test_prepared_tapes_in_asynchronous_and_pipelined_scopes(sw, orc):
     pa, pb = sw.PreparedTape(scope, da), sw.PreparedTape(scope, db)
     out = torch.zeros(40_000, dtype=torch.int32, device="cuda")
     assert (engine.pairs(pa, pb, scope, out=out).cpu().numpy().astype(np.uint32) == orc.levenshtein_pairs(a, b, algo="hyyro")).all()
-    grown = a.offsets[:62].copy()
-    grown[1:61] = grown[61]                                       # the first string of tape a now spans 61 tokens (~3.9 KB: more than the 64 blocks
-                                                                  # of 32 rows the plan-free kernel can score), sixty are empty
     import ctypes as C
     from stringwars_amd import _native as N
-    N.check(N.lib.swh_copy_to_device(scope.handle, C.c_void_p(da.offsets_ptr), grown.ctypes.data, grown.nbytes, None), C.c_char_p())
+    for strs, tape in ((a, da), (b, db)):
+        grown = strs.offsets[:62].copy()
+        grown[1:61] = grown[61]        # the first string now spans 61 tokens (~3.9 KB: more than the 64 blocks of 32 rows the plan-free
+                                       # kernel can take as a pattern -- on both sides, so neither can be the text), sixty are empty
+        N.check(N.lib.swh_copy_to_device(scope.handle, C.c_void_p(tape.offsets_ptr), grown.ctypes.data, grown.nbytes, None), C.c_char_p())
     scope.set_async(True)
     engine.pairs(pa, pb, scope, out=out)
     with pytest.raises(sw.StringWarsError) as info:
@@ -1010,9 +1011,24 @@ def test_multi_device_scope_on_one_gpu(sw, orc):
     other = sw.Strs([b"y" * 2900, b"q", b"", b"c"] + [b"w"] * 50)
     batch = sw.ShardedPairs(scope, ragged, other)
     assert (sw.LevenshteinDistances(capabilities=scope).pairs_sharded(batch, scope) == orc.levenshtein_pairs(ragged, other)).all()
-    # alignment engines can be created on a multi-device scope (they run on its first device) ...
+    # alignment engines on a multi-device scope: ordinary calls run on its first device, sharded calls on per-member clones
     nw = sw.NeedlemanWunschScores(*sw.unary_class_costs(2, -1), open=-2, extend=-2, capabilities=scope)
     assert nw.pairs(sw.Strs([b"GATTACA"]), sw.Strs([b"GCATGCU"]), scope).tolist() == [2]
+    pa, pb = sw.generate_pairs("protein4k", 12, seed=8)
+    ta, tb = sw.generate_pairs("tokens64", 20_000, seed=8)
+    matrix = sw.substitution_matrix(8)
+    for tapes, count in (((pa, pb), 12), ((ta, tb), 500)):
+        batch = sw.ShardedPairs(scope, *tapes)
+        for gaps in ((-4, -4), (-11, -1)):
+            glob = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope)
+            local = sw.SmithWatermanScores(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope)
+            got = glob.pairs_sharded(batch, scope)
+            assert got.dtype == np.int32 and (got[:count] == orc.nw_pairs(*tapes, matrix, *gaps, count=count)).all()
+            assert (got == glob.pairs(*tapes, scope)).all()
+            assert (local.pairs_sharded(batch, scope) == local.pairs(*tapes, scope)).all()
+        with pytest.raises(sw.StringWarsError):
+            sw.LevenshteinDistances(capabilities=scope)._handle and nw.__class__.pairs_sharded(sw.SmithWatermanScores(*sw.unary_class_costs(2, -1), capabilities=scope), batch, sw.DeviceScope(gpu_device=0))
+        batch.free()
     with pytest.raises(sw.StringWarsError) as info:                          # ... but a single-device scope does not shard
         sw.ShardedPairs(sw.DeviceScope(gpu_device=0), a, b)
     assert info.value.status == "invalid_argument"

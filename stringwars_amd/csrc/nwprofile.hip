@@ -168,14 +168,17 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
         off_nxt = *(const uint2 *)(my_ring + ((s0 - lane4) & (kRingEntries - 1)) * 2);
     };
     auto offset_of = [&](const uint2 &o, int u) -> uint32_t { return ((u < 2 ? o.x : o.y) >> (16 * (u & 1))) & 0xFFFFu; };
-    uint32_t sc_nxt[kPlanes], sc_cur[kPlanes];
-    auto read_scores = [&](uint32_t off) {
+    // the scores of a step are requested TWO steps ahead (an LDS round trip under this load is longer than one step of a
+    // narrow strip): four buffers, step u of a group uses buffer u, so every index is static
+    uint32_t sc[4][kPlanes];
+    auto read_scores = [&](int buffer, uint32_t off) {
         const uint32_t *row = (const uint32_t *)(smem + off);
 #pragma unroll
-        for (int pl = 0; pl < kPlanes; ++pl) sc_nxt[pl] = row[pl * 64 + lane];
+        for (int pl = 0; pl < kPlanes; ++pl) sc[buffer][pl] = row[pl * 64 + lane];
     };
     read_offsets(0);
-    read_scores(offset_of(off_nxt, 0));
+    read_scores(0, offset_of(off_nxt, 0));
+    read_scores(1, offset_of(off_nxt, 1));
     uint32_t refill = 0;   // row symbols of entries [s0 + 128, s0 + 192), requested at the top of a 64-step block
     // Four steps. kAllActive: every lane is inside its rows (steps 63 .. rows - 1: all but the first and the last 63 of a
     // pass), so the per-lane activity test -- an add, a compare and an exec-mask round trip per step -- is left out.
@@ -200,9 +203,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t s = s0 + u;
-#pragma unroll
-                for (int pl = 0; pl < kPlanes; ++pl) sc_cur[pl] = sc_nxt[pl];
-                read_scores(u < 3 ? offset_of(off_cur, u + 1) : offset_of(off_nxt, 0));
+                read_scores((u + 2) & 3, u < 2 ? offset_of(off_cur, u + 2) : offset_of(off_nxt, u - 2));
                 __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks the ds_reads next to their use
                 const int recv_h = dpp_wave_shr1(bnd_cur[u], out_h);
                 int recv_e = kNegInfP;
@@ -233,7 +234,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
                     };
 #pragma unroll
                     for (int pl = 0; pl < kPlanes; ++pl) {
-                        const uint32_t c4 = sc_cur[pl];
+                        const uint32_t c4 = sc[u][pl];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) cell(4 * pl + i, (int)(int8_t)(c4 >> (8 * i)));
                     }

@@ -22,7 +22,7 @@ KERNELS = {
     "short_tiled": ("swh::k_short_tiled<", ("short.hip", "common.hpp")),
     "banded": ("swh::k_banded<", ("banded.hip", "common.hpp")),
     "wavefront": ("swh::k_wavefront<", ("wavefront.hip", "common.hpp")),
-    "nwprofile": ("swh::k_nwprofile<", ("nwprofile.hip", "common.hpp")),
+    "nwprofile": ("k_nwprofile<", ("nwprofile.hip", "common.hpp")),
 }
 
 

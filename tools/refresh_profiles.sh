@@ -7,6 +7,8 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/refresh
 mkdir -p "$OUT"
 cd "$REPO"
+# entries of legs that are not re-profiled in this run stay as committed (a fresh box has no gpurun_out/)
+[ -f "$OUT/pmc_constants.json" ] || cp profiles/r3/pmc_constants.json "$OUT/pmc_constants.json" 2>/dev/null
 LEGS=${*:-c2 c1 c3 c3_raw c4_linear c4_affine c4_bytes c5}
 declare -A WORKLOAD=([c1]=words16 [c2]=tokens64 [c3]=utf8_lines [c3_raw]=utf8_lines [c4_linear]=protein4k [c4_affine]=protein4k [c4_bytes]=bytes4k [c5]=short_words)
 declare -A PAIRS=([c1]=10000 [c2]=1000000 [c3]=100000 [c3_raw]=100000 [c4_linear]=10000 [c4_affine]=10000 [c4_bytes]=2000 [c5]=20000000)

@@ -17,6 +17,7 @@
 // Strings longer than 16 bytes raise `violation` (the host redoes the call on another route), like tiled.hip.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "bp_window.hpp"
 
@@ -44,18 +45,21 @@ struct __attribute__((aligned(4096))) ShortLds {
     uint32_t hist[kShortKeys];                          // pairs per key, then exclusive starts
     uint8_t staged[kShortChunk];                        // distances of the chunk (<= 16)
     uint32_t total, ticket;
+    uint32_t mixed;                                     // some byte of the chunk differs from its wave's first byte in the upper three bits
+    uint32_t refs[kShortWaves];                         // those first bytes' upper three bits, broadcast over a dword
 };
 static_assert(sizeof(ShortLds) <= 40960, "four workgroups per compute unit");
 
 // NibbleTables (bp_window.hpp) for 16-row patterns: entry v of Lo sits at tbase + (v << 7), of Hi at tbase + 2048 + (v << 7),
 // tbase = the wave's table + 4 * (lane & 31); lanes >= 32 keep their bits in the upper half of the shared dword.
 struct NibbleTables16 {
-    uint32_t tbase, mask;
+    uint32_t tbase, mask, mask5;
     __device__ __forceinline__ void init(uint32_t *table, int lane) {
         tbase = (uint32_t)(uintptr_t)(lds_u32 *)(table + (lane & 31));
-        if (tbase & 0x780u) __builtin_trap();   // the layout assumption above: fail loudly
+        if (tbase & 0xF80u) __builtin_trap();   // the layout assumptions (4 KB tables on 4 KB boundaries): fail loudly
         mask = 0x780u;
-        asm volatile("" : "+v"(mask));
+        mask5 = 0xF80u;
+        asm volatile("" : "+v"(mask), "+v"(mask5));
     }
     template <int U> __device__ __forceinline__ uint32_t lo_addr(uint32_t x) const {   // x holds the symbol in byte U
         uint32_t s;
@@ -75,6 +79,19 @@ struct NibbleTables16 {
     template <int U> __device__ __forceinline__ void insert(uint32_t x, uint32_t bit) const {
         __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)lo_addr<U>(x), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(hi_addr<U>(x) + 2048), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // When every byte of a chunk shares its upper three bits (lower-case words, upper-case words, digits ...) a symbol is
+    // known by its low five bits: ONE table of 32 entries over the same 4 KB -- entry v at tbase + (v << 7) -- half the
+    // ds_or per row, half the look-ups and address arithmetic per column.
+    template <int U> __device__ __forceinline__ uint32_t one_addr(uint32_t x) const {   // x holds the symbol in byte U
+        uint32_t s;
+        if constexpr (U == 0) s = x << 7;
+        else s = x >> (8 * U - 7);
+        return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask5, (int)tbase, 0xEA);
+    }
+    template <int U> __device__ __forceinline__ uint32_t lookup_one(uint32_t x) const { return *(const lds_u32 *)(uintptr_t)one_addr<U>(x); }
+    template <int U> __device__ __forceinline__ void insert_one(uint32_t x, uint32_t bit) const {
+        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)one_addr<U>(x), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
 
@@ -154,6 +171,8 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k * 64 + lane] = make_uint4(0, 0, 0, 0);
     }
+    if (threadIdx.x == 0) lds.mixed = 0;
+    __syncthreads();
     uint32_t cells = 0, syms = 0, maxa = 0, maxb = 0, misfit = 0;
     const uint32_t bound = job.bound;
 #ifdef SWH_SHORT_PROFILE
@@ -261,15 +280,25 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         const Off cand_bounds = bounds_request(cand, cand_base, cand_len);
         lds.hist[threadIdx.x] = 0;
         if (threadIdx.x == 0) lds.ticket = 0;
+        // Do all bytes of the chunk share their upper three bits? (Checked on the 16-byte units as they arrive -- units past
+        // the segments hold the tapes' next bytes: a false alarm there only costs the chunk its fast path.) The previous
+        // chunk's flag was read before its last barrier; thread 0 of the first wave to get here resets it.
+        uint32_t spread = 0;
         if constexpr (kWide) {
+            const uint32_t ref = ((uint32_t)__builtin_amdgcn_readfirstlane((int)req.va[0].x) & 0xE0u) * 0x01010101u;
 #pragma unroll
             for (int u2 = 0; u2 < 2; ++u2) {   // (units past the segment are harmless slack)
                 const uint32_t u = (uint32_t)u2 * kShortThreads + threadIdx.x;
                 if (16 * u < (uint32_t)kShortCap) {
                     *(uint4 *)(lds.a + kShortPad + 16 * u) = req.va[u2];
                     *(uint4 *)(lds.b + kShortPad + 16 * u) = req.vb[u2];
+                    if (16 * u < cur.bytes_a + 16) spread |= (req.va[u2].x ^ ref) | (req.va[u2].y ^ ref) | (req.va[u2].z ^ ref) | (req.va[u2].w ^ ref);
+                    if (16 * u < cur.bytes_b + 16) spread |= (req.vb[u2].x ^ ref) | (req.vb[u2].y ^ ref) | (req.vb[u2].z ^ ref) | (req.vb[u2].w ^ ref);
                 }
             }
+            // (every wave compares with its own first byte; the four references are compared behind the barrier)
+            if (spread & 0xE0E0E0E0u) lds.mixed = 1;
+            if (lane == 0) lds.refs[wave] = ref;
 #pragma unroll
             for (int u2 = 0; u2 < 2; ++u2) {
                 const uint32_t at = 16u * ((uint32_t)u2 * kShortThreads + threadIdx.x);
@@ -285,6 +314,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         SHORT_STAMP(0);   // A: copy
         __syncthreads();
         SHORT_STAMP(1);   // barrier after A
+        const bool one_table = kWide && !lds.mixed && lds.refs[0] == lds.refs[1] && lds.refs[0] == lds.refs[2] && lds.refs[0] == lds.refs[3];
         // ---- B: cut the common affixes, finish what is trivial, count the rest by (text, pattern) length -------------
         // (the LDS windows of two pairs are requested before the first one is used, no branch in between; all four at once
         // hold 48 dwords in flight and spill)
@@ -343,6 +373,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         }
         SHORT_STAMP(2);   // B
         __syncthreads();
+        if (threadIdx.x == 0) lds.mixed = 0;   // everybody has read it; the next chunk's step A may raise it again
         // ---- C: exclusive scan of the 256 key counts (wave 0, four keys per lane) -------------------------------------
         if (wave == 0) {
             const uint4 c = ((const uint4 *)lds.hist)[lane];
@@ -405,43 +436,64 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
                     }
                 }
                 const uint32_t rows = ((1u << m) - 1u) << half_shift;
+                if (one_table) {
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    // rows past a lane's pattern OR in a zero: no branch per lane, one scalar test per row
-                    if ((uint32_t)w * 4 + 0 >= m_max) break;
-                    nib.template insert<0>(pw[w], rows & (0x00010001u << (w * 4 + 0)));
-                    if ((uint32_t)w * 4 + 1 >= m_max) break;
-                    nib.template insert<1>(pw[w], rows & (0x00010001u << (w * 4 + 1)));
-                    if ((uint32_t)w * 4 + 2 >= m_max) break;
-                    nib.template insert<2>(pw[w], rows & (0x00010001u << (w * 4 + 2)));
-                    if ((uint32_t)w * 4 + 3 >= m_max) break;
-                    nib.template insert<3>(pw[w], rows & (0x00010001u << (w * 4 + 3)));
+                    for (int w = 0; w < 4; ++w) {
+                        if ((uint32_t)w * 4 + 0 >= m_max) break;
+                        nib.template insert_one<0>(pw[w], rows & (0x00010001u << (w * 4 + 0)));
+                        if ((uint32_t)w * 4 + 1 >= m_max) break;
+                        nib.template insert_one<1>(pw[w], rows & (0x00010001u << (w * 4 + 1)));
+                        if ((uint32_t)w * 4 + 2 >= m_max) break;
+                        nib.template insert_one<2>(pw[w], rows & (0x00010001u << (w * 4 + 2)));
+                        if ((uint32_t)w * 4 + 3 >= m_max) break;
+                        nib.template insert_one<3>(pw[w], rows & (0x00010001u << (w * 4 + 3)));
+                    }
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        // rows past a lane's pattern OR in a zero: no branch per lane, one scalar test per row
+                        if ((uint32_t)w * 4 + 0 >= m_max) break;
+                        nib.template insert<0>(pw[w], rows & (0x00010001u << (w * 4 + 0)));
+                        if ((uint32_t)w * 4 + 1 >= m_max) break;
+                        nib.template insert<1>(pw[w], rows & (0x00010001u << (w * 4 + 1)));
+                        if ((uint32_t)w * 4 + 2 >= m_max) break;
+                        nib.template insert<2>(pw[w], rows & (0x00010001u << (w * 4 + 2)));
+                        if ((uint32_t)w * 4 + 3 >= m_max) break;
+                        nib.template insert<3>(pw[w], rows & (0x00010001u << (w * 4 + 3)));
+                    }
                 }
                 short_lds_order();
                 // the recurrence runs in the low 16 bits of every lane (the looked-up word is shifted down); what a lane
                 // < 32 sees above bit 15 are its partner's rows, and nothing ever moves down across bit 16
                 __builtin_amdgcn_s_setprio(0);
                 uint32_t pv = 0xFFFFFFFFu, mv = 0;
+                auto columns = [&](auto one_tag) {
+                    constexpr bool kOne = decltype(one_tag)::value;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    if ((uint32_t)w * 4 >= n_max) break;
+                    for (int w = 0; w < 4; ++w) {
+                        if ((uint32_t)w * 4 >= n_max) break;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if ((uint32_t)(w * 4 + u) >= n_max) break;
-                        if ((uint32_t)(w * 4 + u) < n) {
-                            const uint32_t x = tw[w];
-                            const uint32_t both = u == 0 ? nib.template lookup<0>(x) : (u == 1 ? nib.template lookup<1>(x) : (u == 2 ? nib.template lookup<2>(x) : nib.template lookup<3>(x)));
-                            const uint32_t eq = both >> half_shift;
-                            const uint32_t xv = eq | mv;
-                            const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-                            uint32_t ph = mv | ~(xh | pv);
-                            const uint32_t mh = pv & xh;
-                            ph = (ph << 1) | 1u;
-                            pv = (mh << 1) | ~(xv | ph);
-                            mv = ph & xv;
+                        for (int u = 0; u < 4; ++u) {
+                            if ((uint32_t)(w * 4 + u) >= n_max) break;
+                            if ((uint32_t)(w * 4 + u) < n) {
+                                const uint32_t x = tw[w];
+                                uint32_t both;
+                                if constexpr (kOne) both = u == 0 ? nib.template lookup_one<0>(x) : (u == 1 ? nib.template lookup_one<1>(x) : (u == 2 ? nib.template lookup_one<2>(x) : nib.template lookup_one<3>(x)));
+                                else both = u == 0 ? nib.template lookup<0>(x) : (u == 1 ? nib.template lookup<1>(x) : (u == 2 ? nib.template lookup<2>(x) : nib.template lookup<3>(x)));
+                                const uint32_t eq = both >> half_shift;
+                                const uint32_t xv = eq | mv;
+                                const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                                uint32_t ph = mv | ~(xh | pv);
+                                const uint32_t mh = pv & xh;
+                                ph = (ph << 1) | 1u;
+                                pv = (mh + mh) | ~(xv | ph);   // (x + x: v_add_u32 issues in 2.5 cycles, a left shift in 4.4)
+                                mv = ph & xv;
+                            }
                         }
                     }
-                }
+                };
+                if (one_table) columns(std::true_type{});
+                else columns(std::false_type{});
                 if (active) {
                     const uint32_t mask = (1u << m) - 1u;
                     const uint32_t dist = n + __popc(pv & mask) - __popc(mv & mask);

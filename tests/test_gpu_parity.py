@@ -886,6 +886,34 @@ def test_word_sized_batches_on_the_chunked_kernel(sw, orc, scope, monkeypatch):
     da, db = a.to_device(fresh), b.to_device(fresh)
     for _ in range(2):
         assert (engine.pairs(da, db, fresh) == want).all()
+    # one match table or two: a chunk whose bytes share their upper three bits (lower-case words; upper-case words; digits) takes
+    # the single 32-entry table, any other chunk the nibble tables -- regions of each kind in one batch, symbols that collide
+    # in their low five bits ('a' / 'A' / '!' / 0x81), and a single foreign byte in an otherwise lower-case region
+    def region(count, alphabet):
+        pool = np.frombuffer(bytes(alphabet), np.uint8)
+        out_a, out_b = [], []
+        for _ in range(count):
+            x = pool[rng.integers(0, len(pool), int(rng.integers(0, 17)))].tobytes()
+            y = bytearray(x)
+            for _ in range(int(rng.integers(0, 4))):
+                if y and rng.random() < 0.7:
+                    y[int(rng.integers(0, len(y)))] = int(pool[rng.integers(0, len(pool))])
+                elif len(y) < 16:
+                    y.insert(int(rng.integers(0, len(y) + 1)), int(pool[rng.integers(0, len(pool))]))
+            out_a.append(x); out_b.append(bytes(y) if rng.random() < 0.7 else pool[rng.integers(0, len(pool), int(rng.integers(0, 17)))].tobytes())
+        return out_a, out_b
+    mixed_a, mixed_b = [], []
+    for count, alphabet in ((2500, range(97, 123)), (2500, range(0, 256)), (1500, range(65, 91)), (1500, b"aA!\x81\xa1\xc1\xe1bB\""),
+                            (1500, range(48, 58)), (2500, range(97, 123)), (1200, list(range(97, 123)) + [32])):
+        ra, rb = region(count, alphabet)
+        mixed_a += ra; mixed_b += rb
+    mixed_a[9000] = b"wordWord"; mixed_b[9000] = b"wordword"                 # one capital in the last-but-one lower-case region
+    ma, mb = sw.Strs(mixed_a), sw.Strs(mixed_b)
+    mwant = orc.levenshtein_pairs(ma, mb, algo="hyyro")
+    for offsets in (np.uint64, np.uint32):
+        mpa, mpb = sw.PreparedTape(scope, ma.with_offsets(offsets)), sw.PreparedTape(scope, mb.with_offsets(offsets))
+        assert (engine.pairs(mpa, mpb, scope) == mwant).all() and (engine.pairs(mpb, mpa, scope) == mwant).all()
+        assert (engine.pairs(mpa[2000:9500], mpb[2000:9500], scope, bound=2) == np.minimum(mwant[2000:9500], 3)).all()
     # 16-byte strings only: 1024 pairs are 16 KB per tape, twice what a chunk may hold
     full_a, full_b = sw.Strs([word(16, 4) for _ in range(5000)]), sw.Strs([word(16, 4) for _ in range(5000)])
     fa, fb = sw.PreparedTape(scope, full_a), sw.PreparedTape(scope, full_b)

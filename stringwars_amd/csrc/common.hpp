@@ -169,6 +169,14 @@ struct SummaryLds {   // workgroup scratch of report_call_summary (the caller le
     uint32_t rmaxa[16], rmaxb[16], rshort[16], rviol[16];
     uint32_t is_last;
 };
+// HARDWARE ASSUMPTION (gfx942 / gfx950): an agent-scope atomic store is `global_store ... sc1` -- written through to where every
+// XCD sees it -- and is tracked by `vmcnt` like a load, so `s_waitcnt vmcnt(0)` in front of the counter's bump orders the
+// row before the bump by COMPLETION. The HIP / LLVM memory model promises no happens-before edge for this (a relaxed store
+// followed by a relaxed RMW); a target with a separate store counter (gfx10+: `vscnt`) would break it silently. The library is
+// built for gfx950 only; any other device pass fails here instead of miscounting.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "report_call_summary / k_plan_fused order their hand-over by vmcnt completion: gfx942 / gfx950 only (see the comment above)"
+#endif
 __device__ __forceinline__ void report_call_summary(const PlanPartial &mine, PlanPartial *partials, uint32_t *done_counter,
                                                     CallSummary *summary, SummaryLds &lds) {
     auto &rcells = lds.rcells; auto &rsyms = lds.rsyms;

@@ -692,7 +692,7 @@ static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_
             Carver measure{nullptr, 0, 0};
             measure.take<uint32_t>(kKeys); measure.take<uint32_t>(kKeys); measure.take<PlanPartial>(2 * kMaxPartials);
             measure.take<uint32_t>(8); measure.take<Plan>(1);
-            measure.take<uint32_t>(kKeys); measure.take<uint32_t>(kKeys); measure.take<uint32_t>(4); measure.take<uint32_t>(4096);
+            measure.take<uint32_t>(kKeys); measure.take<uint32_t>(kKeys); measure.take<uint32_t>(4);
             SWH_HIP_CHECK(hipMalloc((void **)&scope->plan_area, measure.used));
             SWH_HIP_CHECK(hipMemset(scope->plan_area, 0, measure.used));
             Carver pa{scope->plan_area, 0, measure.used};
@@ -705,7 +705,6 @@ static swh_status_t scope_init(int device, void *stream, bool borrow, swh_scope_
             scope->plan_hist2[0] = pa.take<uint32_t>(kKeys);
             scope->plan_hist2[1] = pa.take<uint32_t>(kKeys);
             scope->plan_barrier = pa.take<uint32_t>(4);
-            scope->cu_arrivals = pa.take<uint32_t>(4096);
         }
         // summary of plan-free calls: pinned, mapped, coherent -- the kernels write it, the host reads it after synchronising
         SWH_HIP_CHECK(hipHostMalloc((void **)&scope->summary_host, 256, hipHostMallocMapped | hipHostMallocCoherent));

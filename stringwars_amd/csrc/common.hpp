@@ -307,7 +307,6 @@ struct Scope {
     // fused planning kernel (prepass.hip: k_plan_fused): double-buffered key histogram, grid barrier counter + its target
     uint32_t *plan_hist2[2] = {nullptr, nullptr};
     uint32_t *plan_barrier = nullptr;
-    uint32_t *cu_arrivals = nullptr;   // device: workgroups that ever arrived on each compute unit (tiled.hip: the two of a CU take staggered tile cuts)
     uint32_t plan_barrier_target = 0, plan_parity = 0;
     int fused_per_cu = -1;          // planning workgroups a compute unit holds (occupancy query, once)
     bool fused_disabled = false;    // the fused planner once failed to gather its grid on this scope

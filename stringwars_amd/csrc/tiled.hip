@@ -85,7 +85,6 @@ struct TiledArgs {
     PlanPartial *partials;  // per-workgroup work-unit sums (cells, symbols, maxima, "met a pair that does not fit")
     uint32_t *done_counter;
     CallSummary *summary;   // host-mapped: the last workgroup reports (common.hpp: report_call_summary)
-    uint32_t *cu_arrivals;  // per compute unit: workgroups that ever arrived there (null: no staggering)
 };
 
 template <typename Sym, int kWaves, bool kWide>
@@ -105,30 +104,9 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
     if (threadIdx.x == 0) g_tile_span[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // A workgroup scores a CONTIGUOUS range of `rounds` tiles. The two workgroups of a compute unit cut their ranges half a
-    // tile apart -- one takes T, T, ..., the other T/2, T, ..., T/2 -- so that one of them plans (barriers, round trips, no
-    // work items) or runs the thin end of its tile while the other is in the middle of its items. Which of a CU's workgroups
-    // this one is comes from a per-CU arrival counter (hardware id of the CU; the parity carries over from launch to launch
-    // because every launch puts the same number of workgroups on a CU -- and if it does not, only the overlap suffers).
-    uint32_t stagger = 0;
-    if (targs.cu_arrivals) {
-        if (threadIdx.x == 0) {
-            const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));     // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-            const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID [3:0]
-            tl.ticket = atomicAdd(&targs.cu_arrivals[((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu)], 1u) & 1u;
-        }
-        __syncthreads();
-        stagger = tl.ticket;
-        __syncthreads();
-    }
-    const uint32_t rounds = (targs.tiles + gridDim.x - 1) / gridDim.x;
-    const uint64_t range_first = (uint64_t)blockIdx.x * rounds * targs.tile;
-    const uint64_t range_full = range_first + (uint64_t)rounds * targs.tile;
-    const uint64_t range_last = range_full < args.job.pairs ? range_full : args.job.pairs;
-    uint32_t next_count = stagger ? ((targs.tile / 2 + 63u) & ~63u) : targs.tile;
-    for (uint64_t base = range_first; base < range_last; ) {
-        const uint32_t count = (uint32_t)(range_last - base < next_count ? range_last - base : next_count);
-        next_count = targs.tile;
+    for (uint32_t tile = blockIdx.x; tile < targs.tiles; tile += gridDim.x) {
+        const uint64_t base = (uint64_t)tile * targs.tile;
+        const uint32_t count = (uint32_t)(args.job.pairs - base < targs.tile ? args.job.pairs - base : targs.tile);
         // ---- A: clear the counters ------------------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(3);   // planning is a chain of round trips and barriers: it goes first, the work items of other workgroups fill the gaps
         for (int i = threadIdx.x; i < kTileBins / 2; i += kThreads) tl.bins[i] = 0;
@@ -357,7 +335,6 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
             if (d != 0xFFFFFFFFu) store_result(args.job, base + i, (int64_t)d);
         }
         __syncthreads();   // the next tile rewrites the lists
-        base += count;
     }
 #ifdef SWH_TILE_PROFILE
     if (threadIdx.x == 0) g_tile_span[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
@@ -447,8 +424,6 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
     t.partials = scope->plan_partials;
     t.done_counter = scope->done_counter;
     t.summary = scope->summary_dev;
-    static const bool no_stagger = [] { const char *e = getenv("STRINGWARS_AMD_TILE_STAGGER"); return e && atoi(e) == 0; }();   // comparison knob
-    t.cu_arrivals = no_stagger ? nullptr : scope->cu_arrivals;
     opt_in_dynamic_lds(scope, (const void *)k_bitparallel_tiled<Sym, kWaves>, lds);
     static const bool debug = getenv("STRINGWARS_AMD_DEBUG") != nullptr;
     if (debug) {

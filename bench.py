@@ -107,6 +107,7 @@ def parse_args():
     p.add_argument("--algorithm", default="auto", choices=["auto", "wavefront", "bitparallel", "tiled"])
     p.add_argument("--seed", type=int, default=int(os.environ.get("STRINGWARS_SEED", "42")))
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each CPU baseline row (the Gotoh row takes half)")
     p.add_argument("--no-configs", action="store_true", help="leave the other BASELINE configs out of the line")
     p.add_argument("--no-pipelined", action="store_true", help="leave the pipelined steps out (the profiler then sees synchronous launches only)")
     p.add_argument("--legs", default=",".join(DEFAULT_LEGS), help="which configs go into `configs`")
@@ -633,7 +634,7 @@ def main():
                     leg_entries.append({"config": leg_name, "error": f"{type(error).__name__}: {error}"})
                 torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N = 1 only
-            cpu_baselines = cpu_rows(a, b)
+            cpu_baselines = cpu_rows(a, b, budget_s=args.cpu_seconds)
             cpu_baseline = {k: v for k, v in cpu_baselines[0].items() if k != "name"}
         ms_per_step = elapsed / args.steps * 1e3
         line = {

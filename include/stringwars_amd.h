@@ -273,6 +273,21 @@ swh_status_t swh_sw_pairs_prepared(swh_sw_t engine, swh_scope_t scope, const swh
 swh_status_t swh_sw_cross_prepared(swh_sw_t engine, swh_scope_t scope, const swh_prepared_view_t *a,
                                    const swh_prepared_view_t *b, ptrdiff_t *out, size_t row_stride_bytes, const char **error);
 
+/* The reference's own call shape -- `compute_into(queries, candidates, &mut matrix)`, bench.rs:478-486 -- over every GPU of a
+ * multi-device scope: the queries are cut into row blocks of equal symbol counts, block r and all candidates are prepared on
+ * device r, every device fills its rows and copies them straight into `matrix` (host memory, or memory of the first device).
+ * No collective: the row blocks are disjoint. Levenshtein engines take bytes or (utf8 = 1) code points. */
+typedef struct swh_sharded_cross_s *swh_sharded_cross_t;
+swh_status_t swh_sharded_cross_prepare_u64tape(swh_scope_t scope, const swh_tape_u64_t *queries, const swh_tape_u64_t *candidates, int utf8,
+                                               swh_sharded_cross_t *product, const char **error);
+swh_status_t swh_sharded_cross_free(swh_sharded_cross_t product);
+swh_status_t swh_levenshtein_cross_sharded(swh_levenshtein_t engine, swh_scope_t scope, swh_sharded_cross_t product, size_t *matrix,
+                                           size_t row_stride_bytes, const char **error);
+swh_status_t swh_nw_cross_sharded(swh_nw_t engine, swh_scope_t scope, swh_sharded_cross_t product, ptrdiff_t *matrix, size_t row_stride_bytes,
+                                  const char **error);
+swh_status_t swh_sw_cross_sharded(swh_sw_t engine, swh_scope_t scope, swh_sharded_cross_t product, ptrdiff_t *matrix, size_t row_stride_bytes,
+                                  const char **error);
+
 /* Needleman-Wunsch / Smith-Waterman scores of a sharded batch (swh_sharded_prepare_*): the engine's matrix is cloned to every
  * device of the scope on first use -- the `<Ngpu>` twin of the bench.rs:658-670 / :882-963 rows (the engines'
  * read-only state is replicated); scores gathered to the first device like the distances of swh_levenshtein_pairs_sharded */

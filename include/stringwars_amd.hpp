@@ -141,6 +141,25 @@ public:
     size_t size() const { return count_; }
 };
 
+/// A dense queries x candidates product resident on every GPU of a multi-device scope (`swh_sharded_cross_prepare_u64tape`).
+class ShardedCross {
+    swh_sharded_cross_t handle_ = nullptr;
+    size_t rows_ = 0, columns_ = 0;
+public:
+    ShardedCross(const DeviceScope &scope, const BytesTapeView &queries, const BytesTapeView &candidates, bool utf8 = false)
+        : rows_(queries.count), columns_(candidates.count) {
+        const char *err = nullptr;
+        swh_tape_u64_t tq = queries.c(), tc = candidates.c();
+        swh_status_t status__ = swh_sharded_cross_prepare_u64tape(scope.handle(), &tq, &tc, utf8 ? 1 : 0, &handle_, &err);
+        check(status__, err);
+    }
+    ShardedCross(const ShardedCross &) = delete;
+    ~ShardedCross() { if (handle_) swh_sharded_cross_free(handle_); }
+    swh_sharded_cross_t handle() const { return handle_; }
+    size_t rows() const { return rows_; }
+    size_t columns() const { return columns_; }
+};
+
 class LevenshteinDistances {
 protected:
     swh_levenshtein_t handle_ = nullptr;
@@ -187,6 +206,12 @@ public:
         const char *err = nullptr;
         swh_prepared_view_t q = queries.c(), c = candidates ? candidates->c() : q;
         swh_status_t status__ = swh_levenshtein_cross_prepared(handle_, scope.handle(), &q, candidates ? &c : nullptr, matrix, row_stride_bytes, &err);
+        check(status__, err);
+    }
+    /// `compute_into` over every GPU of a multi-device scope: each device fills its rows of the matrix.
+    void compute_into(const DeviceScope &scope, const ShardedCross &product, size_t *matrix, size_t row_stride_bytes = 0) const {
+        const char *err = nullptr;
+        swh_status_t status__ = swh_levenshtein_cross_sharded(handle_, scope.handle(), product.handle(), matrix, row_stride_bytes, &err);
         check(status__, err);
     }
     /// One batch over every GPU of a multi-device scope, distances gathered with RCCL inside the library.

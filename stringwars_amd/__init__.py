@@ -7,7 +7,7 @@ A drop-in for the similarity hot path of ashvardanian/StringWars (`similarities/
 """
 from ._native import LIBRARY_PATH, StringWarsError, lib as _lib  # noqa: F401  (import fails loudly if unbuilt)
 from .engines import (  # noqa: F401
-    UNBOUNDED, DeviceScope, DeviceTape, PreparedTape, ShardedPairs, shard_cuts, LevenshteinDistances, LevenshteinDistancesUTF8, NeedlemanWunschScores, SmithWatermanScores, Strs,
+    UNBOUNDED, DeviceScope, DeviceTape, PreparedTape, ShardedPairs, ShardedCross, shard_cuts, LevenshteinDistances, LevenshteinDistancesUTF8, NeedlemanWunschScores, SmithWatermanScores, Strs,
     edit_distance,
 )
 from .synth import WORKLOADS, generate_pairs, substitution_matrix, unary_class_costs  # noqa: F401

@@ -134,6 +134,11 @@ SIGNATURES = {
     "swh_sharded_free": (C.c_int, [_P]),
     "swh_sharded_cuts": (C.c_int, [_P, C.POINTER(C.c_size_t), C.c_size_t]),
     "swh_levenshtein_pairs_sharded": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _ERR]),
+    "swh_sharded_cross_prepare_u64tape": (C.c_int, [_P, C.POINTER(TapeU64), C.POINTER(TapeU64), C.c_int, C.POINTER(_P), _ERR]),
+    "swh_sharded_cross_free": (C.c_int, [_P]),
+    "swh_levenshtein_cross_sharded": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _ERR]),
+    "swh_nw_cross_sharded": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _ERR]),
+    "swh_sw_cross_sharded": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _ERR]),
     "swh_nw_pairs_sharded": (C.c_int, [_P, _P, _P, _P, _ERR]),
     "swh_sw_pairs_sharded": (C.c_int, [_P, _P, _P, _P, _ERR]),
     "swh_levenshtein_pairs_sharded_u64tape": (C.c_int, [_P, _P, C.POINTER(TapeU64), C.POINTER(TapeU64), C.c_uint32, _P, _ERR]),

@@ -107,6 +107,18 @@ struct ShardedPairs {
     int utf8 = 0;
 };
 
+// A dense queries x candidates product made resident for a multi-device scope: the queries are cut into contiguous row
+// blocks of equal symbol counts (every query meets every candidate, so cells per row are proportional to its length), block r
+// and ALL candidates are prepared on device r, which also holds the block's rows of the result.
+struct ShardedCross {
+    Scope *scope = nullptr;
+    std::vector<uint64_t> cuts;                 // members + 1 query indices
+    std::vector<swh_prepared_t> queries, candidates;   // per member
+    std::vector<uint64_t *> blocks;             // per member: device matrix of (cuts[r + 1] - cuts[r]) x columns 64-bit results
+    uint64_t rows = 0, columns = 0, cells = 0;
+    int utf8 = 0;
+};
+
 }  // namespace swh
 
 using namespace swh;
@@ -554,6 +566,166 @@ swh_status_t swh_nw_pairs_sharded(swh_nw_t engine, swh_scope_t scope, swh_sharde
 }
 swh_status_t swh_sw_pairs_sharded(swh_sw_t engine, swh_scope_t scope, swh_sharded_t sharded, int32_t *out, const char **error) {
     return alignment_sharded(2, engine, scope, sharded, out, error);
+}
+
+static void free_sharded_cross(ShardedCross *sc) {
+    if (!sc) return;
+    MultiScope *multi = sc->scope ? (MultiScope *)sc->scope->multi : nullptr;
+    for (swh_prepared_t p : sc->queries) swh_prepared_free(p);
+    for (swh_prepared_t p : sc->candidates) swh_prepared_free(p);
+    for (size_t r = 0; r < sc->blocks.size(); ++r)
+        if (sc->blocks[r] && multi) { (void)hipSetDevice(multi->devices[r]); (void)hipFree(sc->blocks[r]); }
+    if (multi) (void)hipSetDevice(multi->devices[0]);
+    delete sc;
+}
+
+swh_status_t swh_sharded_cross_prepare_u64tape(swh_scope_t handle, const swh_tape_u64_t *queries, const swh_tape_u64_t *candidates, int utf8,
+                                               swh_sharded_cross_t *out, const char **error) {
+    if (!out) return sharded_fail(error, swh_invalid_argument_k, "null handle pointer");
+    *out = nullptr;
+    Scope *scope = (Scope *)handle;
+    if (!scope || !scope->multi) return sharded_fail(error, swh_invalid_argument_k, "not a multi-device scope (swh_scope_init_gpus)");
+    if (!queries || !candidates) return sharded_fail(error, swh_invalid_argument_k, "two tapes");
+    hipPointerAttribute_t attr;
+    for (const void *p : {(const void *)queries->offsets, (const void *)candidates->offsets, (const void *)queries->data, (const void *)candidates->data}) {
+        if (p && hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice)
+            return sharded_fail(error, swh_invalid_argument_k, "sharding reads the tapes on the host: pass host (pageable, pinned or unified) memory");
+        (void)hipGetLastError();
+    }
+    MultiScope *multi = (MultiScope *)scope->multi;
+    const size_t members = multi->members.size();
+    ShardedCross *sc = new ShardedCross();
+    sc->scope = scope;
+    sc->rows = queries->count; sc->columns = candidates->count; sc->utf8 = utf8;
+    // row blocks of equal query bytes (an all-empty query tape: equal counts)
+    const uint64_t total = queries->count ? queries->offsets[queries->count] - queries->offsets[0] : 0;
+    sc->cuts.assign(members + 1, 0);
+    size_t at = 0;
+    for (size_t r = 1; r < members; ++r) {
+        if (total == 0) { sc->cuts[r] = queries->count * r / members; continue; }
+        const long double target = (long double)total * r / members;
+        while (at < queries->count && (long double)(queries->offsets[at] - queries->offsets[0]) < target) ++at;
+        sc->cuts[r] = at;
+    }
+    sc->cuts[members] = queries->count;
+    sc->cells = total * (candidates->count ? candidates->offsets[candidates->count] - candidates->offsets[0] : 0);
+    sc->queries.assign(members, nullptr); sc->candidates.assign(members, nullptr); sc->blocks.assign(members, nullptr);
+    std::vector<uint64_t> rebased;
+    for (size_t r = 0; r < members; ++r) {
+        const size_t lo = (size_t)sc->cuts[r], hi = (size_t)sc->cuts[r + 1];
+        rebased.resize(hi - lo + 1);
+        const uint64_t first = queries->offsets[lo];
+        for (size_t i = lo; i <= hi; ++i) rebased[i - lo] = queries->offsets[i] - first;
+        swh_tape_u64_t view{queries->data ? queries->data + first : nullptr, rebased.data(), hi - lo};
+        swh_status_t status = swh_tape_prepare_u64(multi->members[r], &view, utf8, &sc->queries[r], error);
+        if (status == swh_success_k) status = swh_tape_prepare_u64(multi->members[r], candidates, utf8, &sc->candidates[r], error);
+        if (status != swh_success_k) { free_sharded_cross(sc); return status; }
+        if (hipSetDevice(multi->devices[r]) != hipSuccess ||
+            hipMalloc((void **)&sc->blocks[r], ((hi - lo) * sc->columns + 2) * sizeof(uint64_t)) != hipSuccess) {
+            free_sharded_cross(sc);
+            return sharded_fail(error, swh_bad_alloc_k, "result rows of a shard");
+        }
+    }
+    (void)hipSetDevice(multi->devices[0]);
+    *out = (swh_sharded_cross_t)sc;
+    return swh_success_k;
+}
+swh_status_t swh_sharded_cross_free(swh_sharded_cross_t handle) {
+    free_sharded_cross((ShardedCross *)handle);
+    return swh_success_k;
+}
+
+// Every member fills its rows of the matrix on its own device and copies them straight to where the caller wants them:
+// host memory (each device over its own PCIe link) or memory of the first device (peer copies). No collective: the row
+// blocks are disjoint.
+static swh_status_t cross_sharded(void *engine, int kind, swh_scope_t handle, swh_sharded_cross_t batch, void *matrix, size_t row_stride_bytes,
+                                  const char **error) {
+    Scope *scope = (Scope *)handle;
+    ShardedCross *sc = (ShardedCross *)batch;
+    if (!scope || !scope->multi || !sc || sc->scope != scope) return sharded_fail(error, swh_invalid_argument_k, "scope and sharded product do not belong together");
+    if (!engine || ((const Engine *)engine)->kind != kind) return sharded_fail(error, swh_invalid_argument_k, "not an engine of this kind");
+    if (!matrix && sc->rows && sc->columns) return sharded_fail(error, swh_invalid_argument_k, "null output pointer");
+    if (kind != 0 && sc->utf8) return sharded_fail(error, swh_not_implemented_k, "substitution-matrix scoring over UTF-8 code points (the matrix is indexed by bytes)");
+    MultiScope *multi = (MultiScope *)scope->multi;
+    const size_t members = multi->members.size();
+    if (!row_stride_bytes) row_stride_bytes = sc->columns * sizeof(uint64_t);
+    std::vector<void *> engines(members, engine);
+    if (kind != 0) {   // alignment engines: one clone per member (see alignment_sharded)
+        const Engine *source = (const Engine *)engine;
+        std::vector<void *> &clones = multi->engine_clones[source->uid];
+        if (clones.empty()) {
+            clones.assign(members, nullptr);
+            for (size_t r = 0; r < members; ++r) {
+                swh_status_t status = clone_alignment_engine(source, multi->members[r], &clones[r], error);
+                if (status != swh_success_k) {
+                    for (void *clone : clones) if (clone) swh_nw_free((swh_nw_t)clone);
+                    multi->engine_clones.erase(source->uid);
+                    return status;
+                }
+            }
+        }
+        engines = clones;
+    }
+    auto stream_of = [&](size_t r) { return ((Scope *)multi->members[r])->stream; };
+    hipError_t hip_error = hipSuccess;
+    auto drain = [&]() {
+        for (size_t q = 0; q < members; ++q) { (void)hipSetDevice(multi->devices[q]); (void)hipStreamSynchronize(stream_of(q)); swh_scope_synchronize(multi->members[q], nullptr); }
+        (void)hipSetDevice(multi->devices[0]);
+        (void)hipGetLastError();
+    };
+    for (size_t r = 0; r < members && hip_error == hipSuccess; ++r) {
+        const size_t n = (size_t)(sc->cuts[r + 1] - sc->cuts[r]);
+        hip_error = hipSetDevice(multi->devices[r]);
+        if (hip_error == hipSuccess) hip_error = hipEventRecord(multi->begin[r], stream_of(r));
+        if (hip_error != hipSuccess || !n || !sc->columns) { if (hip_error == hipSuccess) hip_error = hipEventRecord(multi->done[r], stream_of(r)); continue; }
+        swh_prepared_view_t vq{sc->queries[r], 0, n}, vc{sc->candidates[r], 0, (size_t)sc->columns};
+        swh_status_t status;
+        if (kind == 0) status = swh_levenshtein_cross_prepared((swh_levenshtein_t)engines[r], multi->members[r], &vq, &vc, (size_t *)sc->blocks[r], sc->columns * 8, error);
+        else if (kind == 1) status = swh_nw_cross_prepared((swh_nw_t)engines[r], multi->members[r], &vq, &vc, (ptrdiff_t *)sc->blocks[r], sc->columns * 8, error);
+        else status = swh_sw_cross_prepared((swh_sw_t)engines[r], multi->members[r], &vq, &vc, (ptrdiff_t *)sc->blocks[r], sc->columns * 8, error);
+        if (status != swh_success_k) { drain(); return status; }
+        hip_error = hipEventRecord(multi->done[r], stream_of(r));
+        if (hip_error == hipSuccess)
+            hip_error = hipMemcpy2DAsync((char *)matrix + (size_t)sc->cuts[r] * row_stride_bytes, row_stride_bytes, sc->blocks[r], sc->columns * 8,
+                                         sc->columns * 8, n, hipMemcpyDefault, stream_of(r));
+    }
+    for (size_t r = 0; r < members && hip_error == hipSuccess; ++r) {
+        hip_error = hipSetDevice(multi->devices[r]);
+        if (hip_error == hipSuccess) hip_error = hipStreamSynchronize(stream_of(r));
+    }
+    (void)hipSetDevice(multi->devices[0]);
+    if (hip_error != hipSuccess) {
+        drain();
+        return sharded_fail(error, swh_device_error_k, "HIP error '%s' in the sharded cross-product", hipGetErrorString(hip_error));
+    }
+    for (size_t r = 0; r < members; ++r) {
+        swh_status_t status = swh_scope_synchronize(multi->members[r], error);
+        if (status != swh_success_k) { drain(); return status; }
+    }
+    swh_shard_timing_t timing{};
+    for (size_t r = 0; r < members; ++r) {
+        float ms = 0;
+        (void)hipSetDevice(multi->devices[r]);
+        if (hipEventElapsedTime(&ms, multi->begin[r], multi->done[r]) == hipSuccess && ms > timing.compute_ms) timing.compute_ms = ms;
+    }
+    (void)hipSetDevice(multi->devices[0]);
+    (void)hipGetLastError();
+    timing.cells = sc->cells;
+    timing.pairs = sc->rows * sc->columns;
+    multi->timing = timing;
+    return swh_success_k;
+}
+swh_status_t swh_levenshtein_cross_sharded(swh_levenshtein_t engine, swh_scope_t scope, swh_sharded_cross_t batch, size_t *matrix,
+                                           size_t row_stride_bytes, const char **error) {
+    return cross_sharded(engine, 0, scope, batch, matrix, row_stride_bytes, error);
+}
+swh_status_t swh_nw_cross_sharded(swh_nw_t engine, swh_scope_t scope, swh_sharded_cross_t batch, ptrdiff_t *matrix, size_t row_stride_bytes,
+                                  const char **error) {
+    return cross_sharded(engine, 1, scope, batch, matrix, row_stride_bytes, error);
+}
+swh_status_t swh_sw_cross_sharded(swh_sw_t engine, swh_scope_t scope, swh_sharded_cross_t batch, ptrdiff_t *matrix, size_t row_stride_bytes,
+                                  const char **error) {
+    return cross_sharded(engine, 2, scope, batch, matrix, row_stride_bytes, error);
 }
 
 // One-shot convenience: shard, upload, score, gather, free. The steady state keeps the swh_sharded_t.

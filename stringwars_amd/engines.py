@@ -349,6 +349,32 @@ class ShardedPairs:
             pass
 
 
+class ShardedCross:
+    """A dense queries x candidates product made resident on every device of a multi-GPU scope
+    (`swh_sharded_cross_prepare_u64tape`): row blocks of equal query symbols, block r and all candidates prepared on device
+    r. ``engine.cross_sharded(product, scope, out=matrix)`` is the `<Ngpu>` twin of the reference's `compute_into`."""
+
+    def __init__(self, scope: DeviceScope, queries: Strs, candidates: Strs, utf8: bool = False):
+        if not isinstance(queries, Strs) or not isinstance(candidates, Strs):
+            raise TypeError("sharding reads host tapes (Strs)")
+        tq, _, keep_q = _c_tape(queries, want64=True)
+        tc, _, keep_c = _c_tape(candidates, want64=True)
+        handle, err = C.c_void_p(), C.c_char_p()
+        N.check(N.lib.swh_sharded_cross_prepare_u64tape(scope.handle, C.byref(tq), C.byref(tc), int(bool(utf8)), C.byref(handle), C.byref(err)), err)
+        self._handle, self.shape, self.utf8, self._scope = handle, (len(queries), len(candidates)), bool(utf8), scope
+
+    def free(self) -> None:
+        if getattr(self, "_handle", None) and getattr(N, "lib", None) is not None:
+            N.lib.swh_sharded_cross_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 TapeLike = Union[Strs, DeviceTape, PreparedTape, Sequence[Union[bytes, str]]]
 
 
@@ -397,6 +423,21 @@ class _Engine:
         err = C.c_char_p()
         status = fn(self._handle, scope.handle, C.byref(va), C.byref(vb) if vb is not None else None, *extra,
                     C.c_void_p(_pointer(out)), stride, C.byref(err))
+        N.check(status, err)
+        return out
+
+    def cross_sharded(self, product: "ShardedCross", scope: DeviceScope, out=None):
+        """The dense matrix of a sharded product: every device of the scope fills its rows and copies them into `out` (host
+        memory or memory of the first device; 64-bit entries)."""
+        if self._utf8 != product.utf8:
+            raise ValueError("engine and sharded product disagree on UTF-8")
+        if out is None:
+            out = np.zeros(product.shape, dtype=np.uint64 if self._abi_prefix == "swh_levenshtein" else np.int64)
+        if isinstance(out, np.ndarray) and (out.dtype.itemsize != 8 or out.shape != product.shape):
+            raise ValueError("out must be a (len(queries), len(candidates)) matrix of 64-bit integers")
+        row_stride = out.strides[0] if isinstance(out, np.ndarray) else product.shape[1] * 8
+        err = C.c_char_p()
+        status = getattr(N.lib, self._abi_prefix + "_cross_sharded")(self._handle, scope.handle, product._handle, C.c_void_p(_pointer(out)), row_stride, C.byref(err))
         N.check(status, err)
         return out
 

@@ -102,6 +102,11 @@ extern "C" {
     fn swh_sharded_free(sharded: Handle) -> c_int;
     fn swh_sharded_cuts(sharded: Handle, cuts: *mut usize, capacity: usize) -> c_int;
     fn swh_levenshtein_pairs_sharded(engine: Handle, scope: Handle, sharded: Handle, bound: u32, out: *mut u32, error: Err) -> c_int;
+    fn swh_sharded_cross_prepare_u64tape(scope: Handle, queries: *const TapeU64, candidates: *const TapeU64, utf8: c_int, product: *mut Handle, error: Err) -> c_int;
+    fn swh_sharded_cross_free(product: Handle) -> c_int;
+    fn swh_levenshtein_cross_sharded(engine: Handle, scope: Handle, product: Handle, matrix: *mut usize, row_stride_bytes: usize, error: Err) -> c_int;
+    fn swh_nw_cross_sharded(engine: Handle, scope: Handle, product: Handle, matrix: *mut isize, row_stride_bytes: usize, error: Err) -> c_int;
+    fn swh_sw_cross_sharded(engine: Handle, scope: Handle, product: Handle, matrix: *mut isize, row_stride_bytes: usize, error: Err) -> c_int;
     fn swh_nw_pairs_sharded(engine: Handle, scope: Handle, sharded: Handle, out: *mut i32, error: Err) -> c_int;
     fn swh_sw_pairs_sharded(engine: Handle, scope: Handle, sharded: Handle, out: *mut i32, error: Err) -> c_int;
     fn swh_levenshtein_pairs_sharded_u64tape(engine: Handle, scope: Handle, a: *const TapeU64, b: *const TapeU64, bound: u32, out: *mut u32, error: Err) -> c_int;
@@ -302,6 +307,21 @@ impl ShardedPairs {
 }
 impl Drop for ShardedPairs { fn drop(&mut self) { unsafe { swh_sharded_free(self.handle) }; } }
 
+/// A dense queries x candidates product made resident on every device of a multi-GPU scope
+/// (`swh_sharded_cross_prepare_u64tape`): row blocks of equal query symbols, block r and all candidates prepared on device r.
+/// `compute_into_sharded` is the `<Ngpu>` twin of `compute_into` (bench.rs:478-486).
+pub struct ShardedCross { handle: Handle, rows: usize, columns: usize }
+impl ShardedCross {
+    pub fn bytes(scope: &DeviceScope, queries: &BytesTapeView<u64>, candidates: &BytesTapeView<u64>) -> Result<Self, Error> {
+        let (tq, tc) = (bytes_tape(queries), bytes_tape(candidates));
+        let (mut handle, mut message) = (ptr::null_mut(), ptr::null());
+        check(unsafe { swh_sharded_cross_prepare_u64tape(scope.handle, &tq, &tc, 0, &mut handle, &mut message) }, message)?;
+        Ok(Self { handle, rows: queries.len(), columns: candidates.len() })
+    }
+    pub fn shape(&self) -> (usize, usize) { (self.rows, self.columns) }
+}
+impl Drop for ShardedCross { fn drop(&mut self) { unsafe { swh_sharded_cross_free(self.handle) }; } }
+
 // ------------------------------------------------------------------------------------------------------------
 // Engines
 // ------------------------------------------------------------------------------------------------------------
@@ -348,6 +368,13 @@ impl LevenshteinDistances {
         check(unsafe { swh_levenshtein_pairs_sharded(self.handle, scope.handle, batch.handle, bound.unwrap_or(UNBOUNDED), out.as_mut_ptr(), &mut message) }, message)
     }
     /// One-shot form: shard, upload, score, gather, free.
+    /// The dense matrix of a sharded product: every device fills its rows and copies them into `matrix`.
+    pub fn compute_into_sharded(&self, scope: &DeviceScope, product: &ShardedCross, matrix: &mut [usize]) -> Result<(), Error> {
+        let (rows, columns) = product.shape();
+        assert!(matrix.len() >= rows * columns);
+        let mut message = ptr::null();
+        check(unsafe { swh_levenshtein_cross_sharded(self.handle, scope.handle, product.handle, matrix.as_mut_ptr(), columns * 8, &mut message) }, message)
+    }
     pub fn pairs_into_sharded(&self, scope: &DeviceScope, a: &BytesTapeView<u64>, b: &BytesTapeView<u64>, bound: Option<u32>, out: &mut [u32]) -> Result<(), Error> {
         let (ta, tb) = (bytes_tape(a), bytes_tape(b));
         let mut message = ptr::null();
@@ -415,7 +442,7 @@ impl Drop for LevenshteinDistancesUtf8 { fn drop(&mut self) { unsafe { swh_leven
 
 /// Alignment engines share their plumbing; `$init*`/`$pairs*`/`$cross*` pick the NW or SW entry points.
 macro_rules! alignment_engine {
-    ($name:ident, $doc:expr, $init:ident, $init_classes:ident, $free:ident, $pairs32:ident, $pairs64:ident, $cross:ident, $pairs_prepared:ident, $cross_prepared:ident, $pairs_sharded:ident) => {
+    ($name:ident, $doc:expr, $init:ident, $init_classes:ident, $free:ident, $pairs32:ident, $pairs64:ident, $cross:ident, $pairs_prepared:ident, $cross_prepared:ident, $pairs_sharded:ident, $cross_sharded:ident) => {
         #[doc = $doc]
         pub struct $name { handle: Handle }
         impl $name {
@@ -454,6 +481,12 @@ macro_rules! alignment_engine {
                 let mut message = ptr::null();
                 check(unsafe { $pairs_sharded(self.handle, scope.handle, batch.handle, out.as_mut_ptr(), &mut message) }, message)
             }
+            pub fn compute_into_sharded(&self, scope: &DeviceScope, product: &ShardedCross, matrix: &mut [isize]) -> Result<(), Error> {
+                let (rows, columns) = product.shape();
+                assert!(matrix.len() >= rows * columns);
+                let mut message = ptr::null();
+                check(unsafe { $cross_sharded(self.handle, scope.handle, product.handle, matrix.as_mut_ptr(), columns * 8, &mut message) }, message)
+            }
             /// `compute_into(..) -> UnifiedMat<isize>` (bench.rs:814-821, :872-876).
             pub fn compute_into(&self, scope: &DeviceScope, queries: &BytesTapeView<u64>, candidates: Option<&BytesTapeView<u64>>, matrix: &mut [isize]) -> Result<(), Error> {
                 let columns = candidates.map_or(queries.len(), |c| c.len());
@@ -476,10 +509,10 @@ macro_rules! alignment_engine {
 }
 alignment_engine!(NeedlemanWunschScores, "`szs::NeedlemanWunschScores` (bench.rs:658-670): global alignment scores, linear or affine gaps.",
                   swh_nw_init, swh_nw_init_classes, swh_nw_free, swh_nw_pairs_u32tape, swh_nw_pairs_u64tape, swh_nw_cross_u64tape,
-                  swh_nw_pairs_prepared, swh_nw_cross_prepared, swh_nw_pairs_sharded);
+                  swh_nw_pairs_prepared, swh_nw_cross_prepared, swh_nw_pairs_sharded, swh_nw_cross_sharded);
 alignment_engine!(SmithWatermanScores, "`szs::SmithWatermanScores` (bench.rs:882-963): local alignment scores.",
                   swh_sw_init, swh_sw_init_classes, swh_sw_free, swh_sw_pairs_u32tape, swh_sw_pairs_u64tape, swh_sw_cross_u64tape,
-                  swh_sw_pairs_prepared, swh_sw_cross_prepared, swh_sw_pairs_sharded);
+                  swh_sw_pairs_prepared, swh_sw_cross_prepared, swh_sw_pairs_sharded, swh_sw_cross_sharded);
 
 /// The only route by which parity with the reference's own oracle can be pinned: with `--features verify-rapidfuzz`
 /// every distance of every pairwise call is compared with `rapidfuzz::distance::levenshtein::distance` on the same

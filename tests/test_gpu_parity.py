@@ -1062,6 +1062,48 @@ def test_multi_device_scope_on_one_gpu(sw, orc):
     assert info.value.status == "invalid_argument"
 
 
+def test_sharded_cross_product_on_one_gpu(sw, orc):
+    """`swh_sharded_cross_prepare_u64tape` + `swh_levenshtein_cross_sharded` / `swh_nw_cross_sharded` / `swh_sw_cross_sharded`:
+    the reference's own call shape (`compute_into(queries, candidates, &mut matrix)`, bench.rs:478-486) over the members of a
+    multi-device scope -- here sharing device 0 --, every member filling its rows of a host matrix, a strided host matrix and a
+    matrix in device memory; bytes and code points; ragged query lengths (row blocks balance symbols, not counts)."""
+    import torch
+    rng = np.random.default_rng(77)
+    words = [bytes(rng.integers(97, 123, int(n), dtype=np.uint8)) for n in rng.integers(0, 40, 301)] + [b"x" * 900, b"", b"yy"]
+    cands = [bytes(rng.integers(97, 123, int(n), dtype=np.uint8)) for n in rng.integers(0, 40, 157)]
+    q, c = sw.Strs(words), sw.Strs(cands)
+    single = sw.DeviceScope(gpu_device=0)
+    want = sw.LevenshteinDistances(capabilities=single)(q, c, single)
+    rows = sw.Strs([q[i] for i in (0, 7, 301, 302, 303)])
+    assert (want[[0, 7, 301, 302, 303]] == np.array([[orc.levenshtein(rows[i], c[j]) for j in range(len(cands))] for i in range(5)])).all()
+    for devices in ([0], [0, 0, 0]):
+        scope = sw.DeviceScope(gpu_devices=devices)
+        engine = sw.LevenshteinDistances(capabilities=scope)
+        product = sw.ShardedCross(scope, q, c)
+        assert (engine.cross_sharded(product, scope) == want).all()
+        wide = np.full((len(words), len(cands) + 3), 7, dtype=np.uint64)
+        engine.cross_sharded(product, scope, out=wide[:, :len(cands)])
+        assert (wide[:, :len(cands)] == want).all() and (wide[:, len(cands):] == 7).all()
+        on_device = torch.zeros((len(words), len(cands)), dtype=torch.int64, device="cuda")
+        engine.cross_sharded(product, scope, out=on_device)
+        assert (on_device.cpu().numpy().astype(np.uint64) == want).all()
+        assert scope.shard_timing()["pairs"] == len(words) * len(cands)
+        classes, costs = sw.unary_class_costs(2, -1)
+        for cls in (sw.NeedlemanWunschScores, sw.SmithWatermanScores):
+            aligner = cls(classes, costs, open=-5, extend=-1, capabilities=scope)
+            assert (aligner.cross_sharded(product, scope) == cls(classes, costs, open=-5, extend=-1, capabilities=single)(q, c, single)).all()
+        product.free()
+        uq = sw.Strs(["na\u00efve", "\u0416\u4e2d", "", "abc\U0001F600"] * 9)
+        uc = sw.Strs(["naive", "\u4e2d\u0416", "\U0001F600"] * 5)
+        chars = sw.LevenshteinDistancesUTF8(capabilities=scope)
+        uproduct = sw.ShardedCross(scope, uq, uc, utf8=True)
+        assert (chars.cross_sharded(uproduct, scope) == sw.LevenshteinDistancesUTF8(capabilities=single)(uq, uc, single)).all()
+        with pytest.raises(ValueError):
+            engine.cross_sharded(uproduct, scope)
+    with pytest.raises(sw.StringWarsError):
+        sw.ShardedCross(single, q, c)                                       # a single-device scope does not shard
+
+
 def test_sharded_call_pieces_self_check_and_error_paths(sw, orc, monkeypatch):
     """`swh_levenshtein_pairs_sharded` beyond the happy path: shards large enough to be scored in four pieces (the send of a piece
     enqueued behind its kernel), the gather's self-check (per-shard checksums computed on the shard's device and again over the
@@ -1431,6 +1473,30 @@ def test_comparison_knobs_keep_parity(shapes):
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert done.returncode == 0 and "knobs ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
+
+
+def test_bench_line_carries_every_config():
+    """`bench.py` as the driver runs it at N = 1 (scaled down): `value` is the synchronous-call rate, the steady and the pipelined
+    rates sit beside it, and `configs` holds C1, C3 (prepared and raw), C4 (linear, affine, full byte alphabet) and C5, each with its
+    rate, kernel time, roofline object and a parity check against the oracle; the CPU rows are there."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--pairs", "50000", "--steps", "5", "--warmup", "1", "--prewarm-seconds", "0.05",
+           "--steady-seconds", "0.05", "--cpu-seconds", "0.2", "--leg-pairs", "600"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-3000:])
+    line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["unit"] == "GCUPS" and line["n_gpus"] == 1 and line["steps"] == 5 and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["value_steady"] > 0 and line["value_pipelined"] > 0 and line["parity_vs_oracle"] is True
+    assert abs(line["value"] - line["config"]["cells_per_gpu"] * 5 / (line["ms_per_step"] * 5e-3) / 1e9) < 0.02 * line["value"]
+    assert line["roofline"]["bound"] == "valu" and line["roofline"]["kernel_ms"] > 0 and line["roofline"]["kernel"] == "bitparallel_tiled"
+    assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c4_linear", "c4_affine", "c4_bytes", "c5"]
+    for entry in line["configs"]:
+        assert "error" not in entry, entry
+        assert entry["value"] > 0 and entry["parity_vs_oracle"] is True and entry["roofline"]["kernel_ms"] > 0 and entry["pairs"] == 600, entry
+        assert "cells_mismatch" not in entry, entry
+    assert line["cpu_baseline"]["kind"] == "port" and len(line["cpu_baselines"]) == 4
 
 
 @pytest.mark.parametrize("config,pairs", [("c2", 60_000), ("c5", 600_000)])

@@ -4,7 +4,9 @@
 A "step" is ONE SYNCHRONOUS CALL of the hot path over one batch held resident in HBM -- results visible on return,
 the reference's own metric (`compute_into` inside `measure_throughput`, bench.rs:478-486, utils.rs:721-799) -- with tapes
 prepared once outside the timed region (as the reference builds its tape views once, bench.rs:292-306), plus, for
-N > 1, the RCCL gather of the u32 distances to rank 0 that the north-star names, waited for inside the step.
+N > 1, the RCCL gather of the u32 distances to rank 0 that the north-star names: enqueued behind the call, it travels
+while the next step's call computes (two result buffers) and is waited for before its buffer is reused and by the
+barrier + synchronize that closes the timed region.
 
   --config c2 (default)  BASELINE configs[1]: 1,000,000 printable-ASCII token pairs per GPU, lengths U[32,96],
                          unbounded. Weak scaling: rank r scores pairs [r*P, (r+1)*P) of the seeded stream.
@@ -463,10 +465,7 @@ def main():
                     if pipelined[0]:
                         scope.join()            # the send is ordered on torch's stream: make it wait for this piece
                     gather.send_chunk(outs[slot], j)
-            gathers[slot] = gather
-            if gather is not None and not pipelined[0]:
-                gather.wait()                   # synchronous step: the gathered vector is complete on rank 0 at return
-                torch.cuda.current_stream().synchronize()
+            gathers[slot] = gather              # (waited for when this buffer comes round again, and by the final fence)
     else:
         gathered = [[torch.zeros(pairs, dtype=torch.int32, device=comm_device) for _ in range(world)] for _ in range(2)] \
             if rank == 0 and world > 1 else [None, None]
@@ -485,11 +484,7 @@ def main():
                 if pipelined[0]:
                     scope.join()        # the gather is ordered on torch's stream: make that stream wait for this call
                 if args.backend == "nccl":
-                    works[slot] = dist.gather(outs[slot], gathered[slot], dst=0, async_op=True)
-                    if not pipelined[0]:
-                        works[slot].wait()
-                        works[slot] = None
-                        torch.cuda.current_stream().synchronize()   # synchronous step: the gathered distances are on rank 0 at return
+                    works[slot] = dist.gather(outs[slot], gathered[slot], dst=0, async_op=True)   # overlaps the next step's call
                 else:
                     dist.gather(outs[slot].cpu(), gathered[slot], dst=0)
 
@@ -645,7 +640,7 @@ def main():
             "value_steady": steady["value"] if steady else None, "value_pipelined": pipelined_rate,
             "config": {"workload": cfg["text"].format(pairs=total_pairs if strong else pairs) + ", tapes prepared and resident in HBM",
                        "value_is": "rate of the K timed steps; a step is one synchronous call (results visible on return; the reference's "
-                                   "compute_into metric, utils.rs:721-799)" + (" followed by the gather of the distances to rank 0, waited for" if world > 1 else ""),
+                                   "compute_into metric, utils.rs:721-799)" + (" followed by the gather of the distances to rank 0, which overlaps the next step's call" if world > 1 else ""),
                        "value_steady_is": f"the same steps over >= {args.steady_seconds} s: {steady}" if steady else None,
                        "value_pipelined_is": "K steps enqueued asynchronously on two internal lanes" + (f", {round(pipelined_ms, 4)} ms per step" if pipelined_ms else ""),
                        "pairs_per_gpu": pairs, "pairs_total": total_pairs, "cells_per_gpu": cells, "algorithm": args.algorithm,

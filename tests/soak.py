@@ -121,7 +121,8 @@ def main():
             classes = int(rng.choice([2, 4, 8, 9, 21, 24, 25, 32, 256]))
             alphabet = np.arange(classes if classes < 256 else 256, dtype=np.uint32) + (65 if classes <= 32 else 0)
             matrix = rng.integers(-6, 7, (256, 256)).astype(np.int8)
-            matrix = np.minimum(matrix, matrix.T)   # symmetric
+            if rng.random() < 0.7:
+                matrix = np.minimum(matrix, matrix.T)   # symmetric (the kernels may then put the shorter string on the columns)
             if classes <= 32:   # bytes outside the alphabet share one class
                 other = np.setdiff1d(np.arange(256), alphabet.astype(np.int64))
                 matrix[other, :] = matrix[other[0], :][None, :]
@@ -142,6 +143,16 @@ def main():
             want = np.array([oracle.nw_score(x, y, matrix, gaps[0], gaps[1], local=(kind == "sw")) for x, y in zip(items_a, items_b)])
             bad = np.nonzero(got != want)[0]
             assert bad.size == 0, (kind, classes, gaps, bad[:5], got[bad[:5]], want[bad[:5]])
+            if rounds % 3 == 0:   # the same batch over the three-member scope (per-member engine clones), and a small cross-product
+                sharded_engine = cls(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=multi)
+                batch = sw.ShardedPairs(multi, a, b)
+                assert (sharded_engine.pairs_sharded(batch, multi) == want).all(), ("sharded", kind, classes, gaps)
+                batch.free()
+                q, c = sw.Strs(items_a[:7]), sw.Strs(items_b[:5])
+                product = sw.ShardedCross(multi, q, c)
+                flat = np.array([[oracle.nw_score(x, y, matrix, gaps[0], gaps[1], local=(kind == "sw")) for y in items_b[:5]] for x in items_a[:7]])
+                assert (sharded_engine.cross_sharded(product, multi) == flat).all(), ("sharded cross-product", kind, classes, gaps)
+                product.free()
         rounds += 1
         pairs_total += len(a)
     print(f"soak ok: {rounds} batches, {pairs_total} pairs, {time.time() - t0:.0f} s, seed {args.seed}")

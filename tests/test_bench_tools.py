@@ -53,7 +53,7 @@ def test_source_digest_follows_the_kernel_sources(tmp_path, monkeypatch):
         handle.write(b"\n// one more line\n")
     assert ks.source_digest("short_tiled") != before
     for stamp, (needle, sources) in ks.KERNELS.items():
-        assert needle.startswith("swh::k_") and sources
+        assert "k_" in needle and "<" in needle and sources   # a substring of the kernel symbol as rocprofv3 prints it
 
 
 def test_bench_legs_cover_every_baseline_config():

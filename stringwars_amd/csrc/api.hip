@@ -592,13 +592,13 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             launch_bitparallel_long(scope, kl, plan);
         }
 
-        // Global alignment on a class table (<= 32 symbol classes), pairs of more than 384 columns: the column-profile kernel
+        // Global or local alignment on a class table (<= 32 symbol classes), pairs of more than 384 columns: the column-profile kernel
         // (nwprofile.hip) takes them -- perm is sorted by class, so they are one contiguous range -- and the wavefront
         // kernels below see a plan without them. STRINGWARS_AMD_NW=classic keeps everything on the wavefront kernels.
         static const bool nw_classic = [] { const char *e = getenv("STRINGWARS_AMD_NW"); return e && strcmp(e, "classic") == 0; }();
         uint32_t profile_first = 0, profile_count = 0;
         Plan wf_plan = plan;
-        if (engine->kind == 1 && engine->scoring.class_table && sym_bytes == 1 && !nw_classic) {
+        if ((engine->kind == 1 || engine->kind == 2) && engine->scoring.class_table && sym_bytes == 1 && !nw_classic) {
             profile_first = plan.class_start[kClassWf64 + kNwProfileFirstWide];
             for (int c = kClassWf64 + kNwProfileFirstWide; c <= kClassWfMulti; ++c) { profile_count += plan.class_count[c]; wf_plan.class_count[c] = 0; }
         }

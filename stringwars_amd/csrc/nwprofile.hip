@@ -53,10 +53,14 @@ __device__ __forceinline__ int dpp_wave_shr1(int old, int src) {
 // pass's width), columns c0+1 .. c0+64 WE; `row_bytes` is the profile's row pitch (64 x the kernel's W).
 // kRead: the pass takes its left edge from the previous pass's right edge (not the first pass); kWrite: it parks its own
 // right edge for the next pass (not the last one).
-template <int WE, bool kAffine, bool kRead, bool kWrite>
+// kLocal: Smith-Waterman (`SmithWatermanScores`, bench.rs:882-963) -- every cell floored at zero, the result is the maximum over
+// all cells (`best`, carried from pass to pass by the caller). The strips then hold H + open (what the up / left terms need;
+// the class table holds sub - open), no baseline to be relative to; phantom columns score 0, i.e. a substitution of `open`
+// <= 0, so a phantom cell never exceeds the real cell it descends from and the running maximum needs no column test.
+template <int WE, bool kAffine, bool kRead, bool kWrite, bool kLocal>
 __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uint32_t ring_at, const uint8_t *ctab, const uint8_t *cmap,
                                          uint32_t classes, uint32_t row_bytes, const uint8_t *col_data, const uint8_t *row_data,
-                                         uint32_t rows, uint32_t cols, uint32_t c0, int32_t *bnd_h, int32_t *bnd_e, uint64_t p) {
+                                         uint32_t rows, uint32_t cols, uint32_t c0, int32_t *bnd_h, int32_t *bnd_e, uint64_t p, int &best) {
     constexpr int kPlanes = WE / 4;
     const int lane = threadIdx.x;
     const int open = args.scoring.open, ext = args.scoring.extend;
@@ -116,7 +120,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
 
     int H[WE];
     [[maybe_unused]] int F[kAffine ? WE : 1];
-    const int h0 = kAffine ? 2 * open_minus_ext : 0;   // row 0 relative to the all-gaps baseline (wavefront.hip: kSkew / kSkewAffine)
+    const int h0 = kLocal ? open : (kAffine ? 2 * open_minus_ext : 0);   // row 0: global -- relative to the all-gaps baseline (wavefront.hip: kSkew / kSkewAffine); local -- 0 + open
 #pragma unroll
     for (int k = 0; k < WE; ++k) {
         H[k] = h0;
@@ -124,7 +128,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     }
     int out_h = h0;
     [[maybe_unused]] int out_e = kNegInfP;
-    int prev_h = kAffine ? (mine ? h0 : open_minus_ext) : 0;   // H[0][my first column - 1]
+    int prev_h = kLocal ? open : (kAffine ? (mine ? h0 : open_minus_ext) : 0);   // H[0][my first column - 1]
     // left-edge inputs of lane 0: the DP boundary column (pass 0: a constant, never reloaded) or the previous pass's right edge
     int bnd_next[4] = {h0, h0, h0, h0}, ebnd_next[4] = {kNegInfP, kNegInfP, kNegInfP, kNegInfP};
     int bnd_cur[4], ebnd_cur[4];
@@ -215,7 +219,19 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
                     // substitution score to the diagonal -- H[k - 1] of the previous row, still in its register -- and only then
                     // finishes cell k - 1, whose new value can so be written in place (tied asm operand).
                     auto finish = [&](int k, int t, int after) {
-                        if constexpr (!kAffine) {
+                        if constexpr (kLocal) {
+                            int x = H[k], y = left;   // up and left: the strips already hold H + open
+                            if constexpr (kAffine) {
+                                const int f = max(H[k], F[k] + ext);
+                                F[k] = f;
+                                e = max(left, e + ext);
+                                x = e; y = f;
+                            }
+                            const int h3 = max(max(max(t, x), y), 0);
+                            best = max(best, h3);
+                            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open), "v"(after));
+                            left = H[k];
+                        } else if constexpr (!kAffine) {
                             asm("v_max3_i32 %0, %1, %0, %2" : "+v"(H[k]) : "v"(t), "v"(left), "v"(after));
                             left = H[k];
                         } else {
@@ -267,8 +283,8 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
         wave_lds_fence();
         bnd_flush((int)(steps & ~63u) - 62);
     }
-    // the score lives in the lane / register holding column `cols`
-    if (cols > c0 && cols <= c0 + 64 * WE) {
+    // the score lives in the lane / register holding column `cols` (local alignment: the caller reduces `best` after the last pass)
+    if (!kLocal && cols > c0 && cols <= c0 + 64 * WE) {
         const uint32_t jj = cols - 1 - c0;
         if ((uint32_t)lane == jj / WE) {
             const uint32_t kk = jj % WE;
@@ -285,7 +301,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     wave_lds_fence();                // and nobody is still reading the profile or the ring
 }
 
-template <int W, bool kAffine>
+template <int W, bool kAffine, bool kLocal>
 __global__ __launch_bounds__(64) void k_nwprofile(KernelArgs args, uint32_t first, uint32_t count, uint32_t classes) {
     static_assert(W % 4 == 0 && W >= 4 && W <= 16, "strips are handled four columns at a time");
     constexpr uint32_t kRowBytes = 64u * W;
@@ -325,11 +341,12 @@ __global__ __launch_bounds__(64) void k_nwprofile(KernelArgs args, uint32_t firs
         const uint32_t rest = cols - full * 64 * W;
         const uint32_t w_last = ((rest + 63) / 64 + 3) & ~3u;           // 0: the full passes cover the pair
         const uint32_t passes = full + (rest ? 1u : 0u);
+        int best = 0;   // (local alignment) maximum over the cells of my strips, all passes
         for (uint32_t pass = 0; pass < passes; ++pass) {
             const uint32_t c0 = pass * 64 * W;
             const uint32_t w = pass < full ? (uint32_t)W : w_last;
 #define SWH_PASS2(WE, RD, WR)                                                                                                  \
-    run_pass<WE, kAffine, RD, WR>(args, smem, ring_at, ctab, cmap, classes, kRowBytes, col_data, row_data, rows, cols, c0, bnd_h, bnd_e, p)
+    run_pass<WE, kAffine, RD, WR, kLocal>(args, smem, ring_at, ctab, cmap, classes, kRowBytes, col_data, row_data, rows, cols, c0, bnd_h, bnd_e, p, best)
 #define SWH_PASS(WE)                                                                    \
     do {                                                                                \
         if (pass == 0) { if (passes == 1) SWH_PASS2(WE, false, false); else SWH_PASS2(WE, false, true); } \
@@ -343,15 +360,34 @@ __global__ __launch_bounds__(64) void k_nwprofile(KernelArgs args, uint32_t firs
 #undef SWH_PASS
 #undef SWH_PASS2
         }
+        if constexpr (kLocal) {
+            // the maximum over the wave's lanes, through the (now idle) ring space -- an LDS atomic, not wave_max_u32(): in this
+            // kernel (SGPR spills to VGPR lanes, long branches) the DPP row_bcast reduction never came back
+            int *slot = (int *)(smem + ring_at);
+            if (lane == 0) *slot = 0;
+            wave_lds_fence();
+            __hip_atomic_fetch_max(slot, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (scores are >= 0)
+            wave_lds_fence();
+            if (lane == 0) store_result(args.job, p, (int64_t)*slot);
+            wave_lds_fence();
+        }
     }
 }
 
-template <int W, bool kAffine>
+template <int W, bool kAffine, bool kLocal>
 void launch_w(Scope *scope, const KernelArgs &args, uint32_t first, uint32_t count, uint32_t classes, uint32_t blocks, const char *name) {
     const size_t lds = (size_t)classes * 64 * W + kScratchBytes + 256;
-    opt_in_dynamic_lds(scope, (const void *)k_nwprofile<W, kAffine>, lds);
+    opt_in_dynamic_lds(scope, (const void *)k_nwprofile<W, kAffine, kLocal>, lds);
     StampGuard guard(scope, name);
-    hipLaunchKernelGGL((k_nwprofile<W, kAffine>), dim3(blocks), dim3(64), lds, scope->stream, args, first, count, classes);
+    hipLaunchKernelGGL((k_nwprofile<W, kAffine, kLocal>), dim3(blocks), dim3(64), lds, scope->stream, args, first, count, classes);
+}
+
+template <bool kAffine, bool kLocal>
+void launch_strip(Scope *scope, const KernelArgs &args, uint32_t first, uint32_t count, uint32_t classes, uint32_t blocks, uint32_t strip,
+                  const char *n16, const char *n12, const char *n8) {
+    if (strip == 16) launch_w<16, kAffine, kLocal>(scope, args, first, count, classes, blocks, n16);
+    else if (strip == 12) launch_w<12, kAffine, kLocal>(scope, args, first, count, classes, blocks, n12);
+    else launch_w<8, kAffine, kLocal>(scope, args, first, count, classes, blocks, n8);
 }
 
 }  // namespace
@@ -381,14 +417,12 @@ void launch_nwprofile(Scope *scope, KernelArgs args, uint32_t first, uint32_t co
     args.ticket = scope->plan_leftover + 7;
     SWH_HIP_CHECK(hipMemsetAsync(args.ticket, 0, 4, scope->stream));
     const uint32_t strip = nwprofile_strip(classes);
-    if (!args.affine) {
-        if (strip == 16) launch_w<16, false>(scope, args, first, count, classes, blocks, "nwprofile_w16");
-        else if (strip == 12) launch_w<12, false>(scope, args, first, count, classes, blocks, "nwprofile_w12");
-        else launch_w<8, false>(scope, args, first, count, classes, blocks, "nwprofile_w8");
+    if (!args.local) {
+        if (!args.affine) launch_strip<false, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_w16", "nwprofile_w12", "nwprofile_w8");
+        else launch_strip<true, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_affine_w16", "nwprofile_affine_w12", "nwprofile_affine_w8");
     } else {
-        if (strip == 16) launch_w<16, true>(scope, args, first, count, classes, blocks, "nwprofile_affine_w16");
-        else if (strip == 12) launch_w<12, true>(scope, args, first, count, classes, blocks, "nwprofile_affine_w12");
-        else launch_w<8, true>(scope, args, first, count, classes, blocks, "nwprofile_affine_w8");
+        if (!args.affine) launch_strip<false, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_w16", "nwprofile_local_w12", "nwprofile_local_w8");
+        else launch_strip<true, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_affine_w16", "nwprofile_local_affine_w12", "nwprofile_local_affine_w8");
     }
     SWH_HIP_CHECK(hipGetLastError());
 }

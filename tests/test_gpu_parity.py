@@ -538,6 +538,15 @@ def test_column_profile_kernel_every_strip_shape(sw, orc, scope, gaps, classes):
         assert bad.size == 0, (classes, gaps, symmetric, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
         cross = engine(sw.Strs(items_a[:3]), sw.Strs(items_b[:4]), scope)      # the cross-product entry point takes the same route
         assert (cross == np.array([[orc.nw_score(x, y, full, *gaps) for y in items_b[:4]] for x in items_a[:3]])).all()
+        # Smith-Waterman on the same kernel (zero floor, running maximum carried over the passes)
+        local = sw.SmithWatermanScores(byte_to_class, table, open=gaps[0], extend=gaps[1], capabilities=scope)
+        scope.set_profiling(True)
+        got = local.pairs(a, b, scope)
+        assert scope.last_timing()["dominant_name"].startswith("nwprofile_local"), scope.last_timing()
+        scope.set_profiling(False)
+        want_local = np.array([orc.nw_score(x, y, full, gaps[0], gaps[1], local=True) for x, y in zip(items_a, items_b)])
+        bad = np.nonzero(got != want_local)[0]
+        assert bad.size == 0, ("local", classes, gaps, symmetric, bad[:5], got[bad[:5]], want_local[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
 
 
 def test_smith_waterman(sw, orc, scope):

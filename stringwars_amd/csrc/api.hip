@@ -32,7 +32,14 @@ static swh_status_t fail_hip(const char **error, const HipFailure &f) {
 }
 
 // ---- kernel stamps -------------------------------------------------------------------------------
+// STRINGWARS_AMD_TRACE=1: every stamped launch is announced on stderr and waited for -- the last name printed before a device
+// fault is the kernel behind it (diagnostics only: it serialises everything).
+static bool trace_launches() {
+    static const bool on = [] { const char *e = getenv("STRINGWARS_AMD_TRACE"); return e && atoi(e) != 0; }();
+    return on;
+}
 StampGuard::StampGuard(Scope *s, const char *name) : scope(s), idx(0), on(s->profiling) {
+    if (trace_launches()) { fprintf(stderr, "[swh] launch %s\n", name); fflush(stderr); }
     if (!on) return;
     if (scope->stamps_used == scope->stamps.size()) {
         KernelStamp st{};
@@ -45,6 +52,10 @@ StampGuard::StampGuard(Scope *s, const char *name) : scope(s), idx(0), on(s->pro
 }
 StampGuard::~StampGuard() {
     if (on) (void)hipEventRecord(scope->stamps[idx].stop, scope->stream);
+    if (trace_launches()) {
+        const hipError_t err = hipStreamSynchronize(scope->stream);
+        fprintf(stderr, "[swh]   done (%s)\n", hipGetErrorString(err)); fflush(stderr);
+    }
 }
 
 static void collect_timing(Scope *scope) {

@@ -90,7 +90,9 @@ struct TiledArgs {
 template <typename Sym, int kWaves, bool kWide>
 __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, const uint64_t a_total, const uint64_t b_total) {
     constexpr int kThreads = kWaves * 64, kTableWords = bp_table_words<Sym>();
-    constexpr int kPer = kTileMax / kThreads;   // pairs per thread and tile
+    // pairs per thread and tile, rounded UP: ten-wave workgroups (code points) have 640 threads, and 1024 / 640 = 1 left the
+    // pairs 640 .. 1023 of a full tile unclassified (every use below is guarded by idx < count)
+    constexpr int kPer = (kTileMax + kThreads - 1) / kThreads;
     const KernelArgs &args = targs.k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     BpWave<Sym> wv;
@@ -248,11 +250,14 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         __syncthreads();
         // ---- E: exclusive scan of the key counters (two u16 per word, in place) -------------------------------------
         {
-            constexpr int kWords = kTileBins / 2 / kThreads;   // consecutive words per thread
+            // consecutive words per thread, rounded UP (640 threads: 1024 / 640 = 1 left the keys of classes >= 40 -- patterns of more
+            // than 1280 symbols -- out of the scan: wrong distances for code-point strings that long, found by the soak test)
+            constexpr int kWords = (kTileBins / 2 + kThreads - 1) / kThreads;
             uint32_t words[kWords], sum = 0;
 #pragma unroll
             for (int q = 0; q < kWords; ++q) {
-                words[q] = tl.bins[threadIdx.x * kWords + q];
+                const int at = threadIdx.x * kWords + q;
+                words[q] = at < kTileBins / 2 ? tl.bins[at] : 0u;
                 sum += (words[q] & 0xFFFFu) + (words[q] >> 16);
             }
             const uint32_t incl = wave_inclusive_sum_u32(sum);
@@ -263,7 +268,8 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
 #pragma unroll
             for (int q = 0; q < kWords; ++q) {
                 const uint32_t lo = words[q] & 0xFFFFu, hi = words[q] >> 16;
-                tl.bins[threadIdx.x * kWords + q] = run | ((run + lo) << 16);
+                const int at = threadIdx.x * kWords + q;
+                if (at < kTileBins / 2) tl.bins[at] = run | ((run + lo) << 16);
                 run += lo + hi;
             }
         }

@@ -57,6 +57,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--verbose", action="store_true", help="one line per batch before it runs (to find the batch behind a device fault)")
+    ap.add_argument("--only", type=int, default=-1, help="draw every batch as usual but run only this one on the device (reproduces one batch of a seed)")
+    ap.add_argument("--first", type=int, default=-1, help="with --only N: run batches first .. N on the device (finds the shortest prefix a failure needs)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     scope = sw.DeviceScope(gpu_device=0)
@@ -65,22 +68,35 @@ def main():
     piped.set_pipelined(True)
     multi = sw.DeviceScope(gpu_devices=[0, 0, 0])
     t0, rounds, pairs_total = time.time(), 0, 0
-    while time.time() - t0 < args.seconds:
+    while time.time() - t0 < args.seconds or 0 <= rounds <= args.only:
         kind = str(rng.choice(["lev", "lev", "lev_utf8", "nw", "sw"]))
         if kind in ("lev", "lev_utf8"):
             utf8 = kind == "lev_utf8"
             a, b = random_batch(rng, utf8)
             bound = None if rng.random() < 0.5 else int(rng.integers(0, 80))
             algorithm = str(rng.choice(["auto", "auto", "bitparallel", "wavefront", "tiled"]))
+            if args.verbose:
+                print(f"batch {rounds}: {kind} pairs {len(a)} longest {int(max(a.lengths.max(), b.lengths.max()))} bound {bound} algorithm {algorithm}", flush=True)
             if algorithm == "wavefront" and oracle.cells(a, b, utf8=utf8) > 3e8:
                 algorithm = "auto"
+            if args.only >= 0 and not ((args.first if args.first >= 0 else args.only) <= rounds <= args.only):   # (the draws below are replayed so that the sequence stays the same)
+                lo = int(rng.integers(0, len(a)))
+                hi = int(rng.integers(lo, len(a) + 1))
+                if rounds % 5 == 0:
+                    for i in range(min(len(a), 40)): rng.integers(0, 33)
+                    for i in range(min(len(b), 90)): rng.integers(0, 33)
+                rounds += 1
+                if rounds > args.only: break
+                continue
             cls = sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances
             engine = cls(capabilities=scope, algorithm=algorithm)
             want = oracle.levenshtein_pairs(a, b, utf8=utf8, algo="wf" if utf8 else "hyyro", bound=bound)
+            if args.verbose: print("    raw tapes, twice", flush=True)
             for _ in range(2):   # the second call may take the direct-short path
                 got = engine.pairs(a, b, scope, bound=bound)
                 bad = np.nonzero(got != want)[0]
                 assert bad.size == 0, (kind, algorithm, bound, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+            if args.verbose: print("    prepared tapes + sub-view", flush=True)
             # prepared tapes (resident, measured, UTF-8 decoded once): whole tapes and a random sub-view, same engine
             pa, pb = sw.PreparedTape(scope, a, utf8=utf8), sw.PreparedTape(scope, b, utf8=utf8)
             got = engine.pairs(pa, pb, scope, bound=bound)
@@ -90,6 +106,7 @@ def main():
             hi = int(rng.integers(lo, len(a) + 1))
             assert (engine.pairs(pa[lo:hi], pb[lo:hi], scope, bound=bound) == want[lo:hi]).all(), ("prepared sub-view", kind, algorithm, lo, hi)
             if rounds % 3 == 0 and not utf8:   # the same batch split over a three-member scope on device 0
+                if args.verbose: print("    sharded", flush=True)
                 sharded_engine = sw.LevenshteinDistances(capabilities=multi)
                 batch = sw.ShardedPairs(multi, a, b)
                 got = sharded_engine.pairs_sharded(batch, multi, bound=bound)
@@ -105,6 +122,7 @@ def main():
                     for tapes in ((q, c), (sw.PreparedTape(scope, q), sw.PreparedTape(scope, c))):
                         assert (byte_engine(tapes[0], tapes[1], scope).reshape(-1) == flat).all(), "cross-product of words"
             if rounds % 4 == 0:   # the same batch through the pipelined lanes: device tapes, device outputs, 32-bit offsets
+                if args.verbose: print("    pipelined lanes", flush=True)
                 import torch
                 a32, b32 = a.with_offsets(np.uint32), b.with_offsets(np.uint32)
                 da, db = a32.to_device(piped), b32.to_device(piped)
@@ -137,6 +155,12 @@ def main():
                 items_b.append(bytes(alphabet[rng.integers(0, len(alphabet), lb)].astype(np.uint8)))
                 cells += max(la, 1) * max(lb, 1)
             a, b = sw.Strs(items_a), sw.Strs(items_b)
+            if args.verbose:
+                print(f"batch {rounds}: {kind} classes {classes} gaps {gaps} pairs {len(a)} lengths {lo}..{hi} symmetric {bool((matrix == matrix.T).all())}", flush=True)
+            if args.only >= 0 and not ((args.first if args.first >= 0 else args.only) <= rounds <= args.only):
+                rounds += 1
+                if rounds > args.only: break
+                continue
             cls = sw.NeedlemanWunschScores if kind == "nw" else sw.SmithWatermanScores
             engine = cls(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=scope)
             got = engine.pairs(a, b, scope)
@@ -155,6 +179,8 @@ def main():
                 product.free()
         rounds += 1
         pairs_total += len(a)
+        if 0 <= args.only < rounds:
+            break
     print(f"soak ok: {rounds} batches, {pairs_total} pairs, {time.time() - t0:.0f} s, seed {args.seed}")
 
 

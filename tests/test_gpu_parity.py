@@ -813,6 +813,34 @@ def test_tiled_kernel_every_block_count(sw, orc, scope):
     chars = sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm="tiled")
     ua, ub = sw.generate_pairs("utf8_lines", 700, seed=13)
     assert (chars.pairs(ua, ub, scope) == orc.levenshtein_pairs(ua, ub, utf8=True)).all()
+    # code points over the same 1 .. 2048 block counts: the ten-wave workgroups (640 threads) once scanned only 640 of the
+    # 1024 key-counter words -- classes >= 40 (patterns beyond 1280 code points) came out wrong
+    script = "\u00e9\u4e2d\U0001f600z\u0416"
+    ca = sw.Strs(["".join(script[v] for v in s) for s in items_a])
+    cb = sw.Strs(["".join(script[v] for v in s) for s in items_b])
+    assert (chars.pairs(ca, cb, scope) == want).all()
+    assert (chars.pairs(cb, ca, scope, bound=33) == np.minimum(want, 34)).all()
+    pca, pcb = sw.PreparedTape(scope, ca, utf8=True), sw.PreparedTape(scope, cb, utf8=True)
+    assert (chars.pairs(pca, pcb, scope) == want).all()
+
+
+def test_tiled_kernel_full_tiles_of_code_points(sw, orc, scope):
+    """More code-point pairs than 640 per tile and workgroup slot (tiles hold up to 1024 pairs, ten-wave workgroups have
+    640 threads: each thread classifies two pairs of a full tile), raw and prepared."""
+    a, b = sw.generate_pairs("words16", 400_000, seed=29)
+    want = orc.levenshtein_pairs(a, b, algo="hyyro")
+    def cyrillic(tape):   # every byte becomes one two-byte code point: same distances
+        data = np.empty((tape.data.size, 2), np.uint8)
+        data[:, 0] = 0xD0
+        data[:, 1] = 0x90 + (tape.data & 31)
+        return sw.Strs(data=data.reshape(-1), offsets=tape.offsets * 2)
+    assert len(set(int(v) & 31 for v in b"abcdefghijklmnopqrstuvwxyz")) == 26
+    ua, ub = cyrillic(a), cyrillic(b)
+    chars = sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm="tiled")
+    assert (chars.pairs(ua, ub, scope) == want).all()
+    pa, pb = sw.PreparedTape(scope, ua, utf8=True), sw.PreparedTape(scope, ub, utf8=True)
+    assert (chars.pairs(pa, pb, scope) == want).all()
+    assert (chars.pairs(pa, pb, scope, bound=7) == np.minimum(want, 8)).all()
 
 
 def test_pairs_with_common_affixes(sw, orc, scope):
@@ -966,6 +994,17 @@ def test_plan_free_route_falls_back_when_lengths_grow(sw, orc):
         assert (engine.pairs(a, b, scope) == orc.levenshtein_pairs(a, b, algo="hyyro")).all()
         da, db = a.to_device(scope), b.to_device(scope)
         assert (engine.pairs(da, db, scope, bound=9) == np.minimum(orc.levenshtein_pairs(a, b, algo="hyyro"), 10)).all()
+    # the same for code points: word-sized batches, then lines of 700 .. 2000 code points on the strength of that belief
+    chars = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    script = [0x41, 0x416, 0x4E2D, 0x1F600]
+    def line(n):
+        return "".join(chr(script[i]) for i in rng.integers(0, 4, n))
+    short_a, short_b = sw.Strs([line(int(n)) for n in rng.integers(1, 20, 500)]), sw.Strs([line(int(n)) for n in rng.integers(1, 20, 500)])
+    for low, high in ((700, 1400), (1000, 2000), (2000, 2600)):
+        lines_a = sw.Strs([line(int(n)) for n in rng.integers(low, high, 50)])
+        lines_b = sw.Strs([line(int(n)) for n in rng.integers(low, high, 50)])
+        for a, b in ((short_a, short_b), (lines_a, lines_b), (short_a, short_b), (lines_a, lines_b)):
+            assert (chars.pairs(a, b, scope) == orc.levenshtein_pairs(a, b, utf8=True)).all()
     # forced tiled with a pair beyond its reach: flagged, redone
     tiled = sw.LevenshteinDistances(capabilities=scope, algorithm="tiled")
     assert (tiled.pairs(long_a, long_b, scope) == orc.levenshtein_pairs(long_a, long_b, algo="hyyro")).all()

@@ -1099,6 +1099,10 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
             if (err == hipSuccess) err = hipMemcpy(engine->class_dev, table, sizeof table, hipMemcpyHostToDevice);
             if (err != hipSuccess) { swh_levenshtein_free((swh_levenshtein_t)engine); return fail_hip(error, HipFailure{err, "class table upload"}); }
             engine->scoring.class_table = engine->class_dev; engine->scoring.classes = (uint32_t)classes;
+            int widest = 0;   // of the costs themselves (not the biased table)
+            for (int i = 0; i < classes; ++i)
+                for (int j = 0; j < classes; ++j) widest = std::max(widest, std::abs((int)matrix[rep[i] * 256 + rep[j]]));
+            engine->scoring.step_span = (uint32_t)(widest - open - extend);
         }
     }
     *out = engine;

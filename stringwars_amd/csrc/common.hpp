@@ -276,6 +276,7 @@ struct Scoring {
     const int8_t *matrix;  // device pointer to 256x256 i8, row = a symbol, col = b symbol; or null
     const uint8_t *class_table;  // device: 32x32 i8 class costs then 256 B byte->class map, when the matrix has <= 32 classes
     uint32_t classes;            // how many of the 32 classes are in use (0: unknown, treat as 32)
+    uint32_t step_span;          // class model: max |class cost| + |open| + |extend| -- neighbouring DP cells differ by no more (0: unknown)
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -49,6 +49,43 @@ __device__ __forceinline__ int dpp_wave_shr1(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 }
 
+// Narrow strips (kNarrow, Gotoh): a two-operand 32-bit maximum issues at half the rate of a two-operand 16-bit one
+// (profiles/r3/valu_ops_issue_rates_3.txt: v_max_i32 4.3 SIMD cycles per wave instruction, v_max_u16 2.5 with two waves per
+// SIMD; v_max3_u16 8.3 -- no use), and two of the five operations of a Gotoh cell are such maxima. Everything a wave holds at one time -- 64 W columns,
+// 64 rows -- lies within (64 W + 256) x `step_span` of each other (neighbouring cells differ by at most max |cost| + |open| +
+// |extend| in the all-gaps-relative form), so the strips keep value - shift with ONE wave-wide `shift`, chosen so that the middle
+// of the wave sits at 0x8000 and moved every 64 steps: all stored values are positive 16-bit numbers in 32-bit registers, the
+// 32-bit operations (v_add_u32_sdwa, v_max3_i32) see them as they are, and the two plain maxima become v_max_u16. The
+// boundary columns in global memory stay true 32-bit values: they are converted where the rings are filled / flushed.
+// api.hip sets `Scoring::step_span`; launch_nwprofile() takes this path when (64 W + 256) x step_span <= 30 000.
+constexpr int kCenter = 0x8000;
+__device__ __forceinline__ int umax16(int a, int b) {
+    int r;
+    asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Four Gotoh cells of a strip (global alignment), the schedule written out -- see run_pass. Per cell, in issue order:
+//   e = max(left, e)  |  F[k+1] = max(H[k+1], F[k+1])  |  tmp = max3(t[k], e, F[k])  |  t[k+2] = H[k+1] + score  |  H[k] = tmp + (open - extend)
+// (H[k+1] is still the row above when the second and fourth read it). MAX is v_max_i32, or v_max_u16 on narrow strips.
+#define SWH_NWP_SCORE_ADD(DST, BASE, WORD, BYTE) \
+    "v_add_u32_sdwa " DST ", " BASE ", sext(" WORD ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" BYTE "\n"
+#define SWH_NWP_CELL(MAX, LEFT, FNEXT, HNEXT, TCUR, FCUR, TNEXT, WORD, BYTE, HOUT)                                      \
+    MAX " %[e], " LEFT ", %[e]\n" MAX " " FNEXT ", " HNEXT ", " FNEXT "\n"                                             \
+        "v_max3_i32 %[tmp], " TCUR ", %[e], " FCUR "\n" SWH_NWP_SCORE_ADD(TNEXT, HNEXT, WORD, BYTE) "v_add_u32 " HOUT ", %[tmp], %[c]\n"
+#define SWH_NWP_PLANE(MAX)                                                                                              \
+    SWH_NWP_CELL(MAX, "%[left]", "%[f1]", "%[h1]", "%[t0]", "%[f0]", "%[t2]", "%[s0]", "2", "%[h0]")                     \
+    SWH_NWP_CELL(MAX, "%[h0]", "%[f2]", "%[h2]", "%[t1]", "%[f1]", "%[t3]", "%[s0]", "3", "%[h1]")                       \
+    SWH_NWP_CELL(MAX, "%[h1]", "%[f3]", "%[h3]", "%[t2]", "%[f2]", "%[t4]", "%[s1]", "0", "%[h2]")                       \
+    SWH_NWP_CELL(MAX, "%[h2]", "%[f4]", "%[hn]", "%[t3]", "%[f3]", "%[t5]", "%[s1]", "1", "%[h3]")
+// the strip's last four cells: no column to the right of the fourth
+#define SWH_NWP_LAST_PLANE(MAX)                                                                                         \
+    SWH_NWP_CELL(MAX, "%[left]", "%[f1]", "%[h1]", "%[t0]", "%[f0]", "%[t2]", "%[s0]", "2", "%[h0]")                     \
+    SWH_NWP_CELL(MAX, "%[h0]", "%[f2]", "%[h2]", "%[t1]", "%[f1]", "%[t3]", "%[s0]", "3", "%[h1]")                       \
+    MAX " %[e], %[h1], %[e]\n" MAX " %[f3], %[h3], %[f3]\n"                                                              \
+        "v_max3_i32 %[tmp], %[t2], %[e], %[f2]\ns_nop 0\nv_add_u32 %[h2], %[tmp], %[c]\n" MAX " %[e], %[h2], %[e]\n"      \
+        "s_nop 0\nv_max3_i32 %[tmp], %[t3], %[e], %[f3]\ns_nop 0\nv_add_u32 %[h3], %[tmp], %[c]\n"
+
 // One pass of one pair: the strip is WE columns per lane (a multiple of four, compile-time here: the kernel switches on the
 // pass's width), columns c0+1 .. c0+64 WE; `row_bytes` is the profile's row pitch (64 x the kernel's W).
 // kRead: the pass takes its left edge from the previous pass's right edge (not the first pass); kWrite: it parks its own
@@ -57,7 +94,7 @@ __device__ __forceinline__ int dpp_wave_shr1(int old, int src) {
 // all cells (`best`, carried from pass to pass by the caller). The strips then hold H + open (what the up / left terms need;
 // the class table holds sub - open), no baseline to be relative to; phantom columns score 0, i.e. a substitution of `open`
 // <= 0, so a phantom cell never exceeds the real cell it descends from and the running maximum needs no column test.
-template <int WE, bool kAffine, bool kRead, bool kWrite, bool kLocal>
+template <int WE, bool kAffine, bool kRead, bool kWrite, bool kLocal, bool kNarrow>
 __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uint32_t ring_at, const uint8_t *ctab, const uint8_t *cmap,
                                          uint32_t classes, uint32_t row_bytes, const uint8_t *col_data, const uint8_t *row_data,
                                          uint32_t rows, uint32_t cols, uint32_t c0, int32_t *bnd_h, int32_t *bnd_e, uint64_t p, int &best) {
@@ -118,19 +155,25 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     ring_store(64 + lane, row_offset(64 + lane));
     wave_lds_fence();
 
+    static_assert(!kNarrow || (kAffine && !kLocal), "narrow strips: global alignment with affine gaps");
     int H[WE];
     [[maybe_unused]] int F[kAffine ? WE : 1];
-    const int h0 = kLocal ? open : (kAffine ? 2 * open_minus_ext : 0);   // row 0: global -- relative to the all-gaps baseline (wavefront.hip: kSkew / kSkewAffine); local -- 0 + open
+    const int h0_true = kLocal ? open : (kAffine ? 2 * open_minus_ext : 0);   // row 0: global -- relative to the all-gaps baseline (wavefront.hip: kSkew / kSkewAffine); local -- 0 + open
+    [[maybe_unused]] int shift = kNarrow ? h0_true - kCenter : 0;           // (narrow strips) true value = stored value + shift
+    const int h0 = kNarrow ? kCenter : h0_true;
+    // "minus infinity": narrow strips never add to one (F of row 0 may as well be H of row 0: max(H, F) is H either way; E of
+    // column 0 is 0, below every stored value)
+    constexpr int kNoF = kNegInfP, kNoE = kNarrow ? 0 : kNegInfP;
 #pragma unroll
     for (int k = 0; k < WE; ++k) {
         H[k] = h0;
-        if constexpr (kAffine) F[k] = kNegInfP;
+        if constexpr (kAffine) F[k] = kNarrow ? h0 : kNoF;
     }
     int out_h = h0;
-    [[maybe_unused]] int out_e = kNegInfP;
-    int prev_h = kLocal ? open : (kAffine ? (mine ? h0 : open_minus_ext) : 0);   // H[0][my first column - 1]
+    [[maybe_unused]] int out_e = kNarrow ? h0 : kNoE;
+    int prev_h = kLocal ? open : (kAffine ? (mine ? h0 : open_minus_ext - (kNarrow ? shift : 0)) : 0);   // H[0][my first column - 1]
     // left-edge inputs of lane 0: the DP boundary column (pass 0: a constant, never reloaded) or the previous pass's right edge
-    int bnd_next[4] = {h0, h0, h0, h0}, ebnd_next[4] = {kNegInfP, kNegInfP, kNegInfP, kNegInfP};
+    int bnd_next[4] = {h0, h0, h0, h0}, ebnd_next[4] = {kNoE, kNoE, kNoE, kNoE};
     int bnd_cur[4], ebnd_cur[4];
     constexpr bool read_bnd = kRead, write_bnd = kWrite;
     int *rring_h = (int *)(smem + ring_at + kRingBytes), *rring_e = rring_h + kBndReadRows;   // row r at slot (r - 1) & 127
@@ -149,14 +192,19 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     auto bnd_flush = [&](int first_row) {          // rows first_row .. first_row + 63 of my right edge go to global memory
         const int r = first_row + lane;
         if (r >= 1 && (uint32_t)r <= rows) {
-            bnd_h[r] = wring_h[r & (kBndWriteRows - 1)];
-            if constexpr (kAffine) bnd_e[r] = wring_e[r & (kBndWriteRows - 1)];
+            bnd_h[r] = wring_h[r & (kBndWriteRows - 1)] + (kNarrow ? shift : 0);
+            if constexpr (kAffine) bnd_e[r] = wring_e[r & (kBndWriteRows - 1)] + (kNarrow ? shift : 0);
         }
     };
     if (read_bnd) {
         bnd_request(1); bnd_deliver(1);
         bnd_request(65); bnd_deliver(65);
         wave_lds_fence();
+        if constexpr (kNarrow) {   // rows 1 .. 64 become stored values (rows 65 .. 128: at the end of the first block)
+            rring_h[lane] -= shift;
+            rring_e[lane] -= shift;
+            wave_lds_fence();
+        }
         const int4 h4 = *(const int4 *)rring_h;
         bnd_next[0] = h4.x; bnd_next[1] = h4.y; bnd_next[2] = h4.z; bnd_next[3] = h4.w;
         if constexpr (kAffine) {
@@ -235,9 +283,9 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
                             asm("v_max3_i32 %0, %1, %0, %2" : "+v"(H[k]) : "v"(t), "v"(left), "v"(after));
                             left = H[k];
                         } else {
-                            const int f = max(H[k], F[k]);
+                            const int f = kNarrow ? umax16(H[k], F[k]) : max(H[k], F[k]);
                             F[k] = f;
-                            e = max(left, e);
+                            e = kNarrow ? umax16(left, e) : max(left, e);
                             const int h3 = max(max(t, e), f);
                             asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open_minus_ext), "v"(after));
                             left = H[k];
@@ -248,13 +296,61 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
                         if (k > 0) finish(k - 1, t_pending, t);
                         t_pending = t;
                     };
+                    if constexpr (kAffine && !kLocal) {
+                        // Gotoh, global: four cells per asm statement, in a fixed order (SWH_NWP_CELL). What this buys is the wait
+                        // states: hipcc cannot see into an asm statement and puts an s_nop in front of every reader of what one defines --
+                        // 45 per four steps behind the v_max_u16 of narrow strips, 132 when every instruction is its own statement, 18
+                        // with one statement per four cells; and an s_nop costs a wave an issue slot like any instruction. (The order
+                        // itself is not what matters: tools/gotoh_sched.hip, profiles/r3/gotoh_schedule_cycles.txt -- the five operations
+                        // of a cell cost 19.5 SIMD cycles with v_max_u16, 21.3 with v_max_i32 at two waves per SIMD, chain back to back or
+                        // interleaved. With the strip's other instructions the narrow kernel runs at 22.8: at its VALU floor.)
+                        int t[WE + 2];
+                        t[0] = prev_h + (int)(int8_t)sc[u][0];
+                        t[1] = H[0] + (int)(int8_t)(sc[u][0] >> 8);
+                        F[0] = kNarrow ? umax16(H[0], F[0]) : max(H[0], F[0]);   // the row above, gap opened or extended
 #pragma unroll
-                    for (int pl = 0; pl < kPlanes; ++pl) {
-                        const uint32_t c4 = sc[u][pl];
+                        for (int pl = 0; pl < kPlanes; ++pl) {
+                            const int k0 = 4 * pl;
+                            int h3;
+                            if (pl + 1 < kPlanes) {
+                                const int kn = 4 * (pl + 1 < kPlanes ? pl + 1 : 0);   // (in range when the branch is not taken)
+                                if constexpr (kNarrow)
+                                    asm volatile(SWH_NWP_PLANE("v_max_u16")
+                                                 : [h0] "+v"(H[k0]), [h1] "+v"(H[k0 + 1]), [h2] "+v"(H[k0 + 2]), [h3] "+v"(H[k0 + 3]), [f1] "+v"(F[k0 + 1]),
+                                                   [f2] "+v"(F[k0 + 2]), [f3] "+v"(F[k0 + 3]), [f4] "+v"(F[kn]), [e] "+v"(e), [t2] "=&v"(t[k0 + 2]),
+                                                   [t3] "=&v"(t[k0 + 3]), [t4] "=&v"(t[k0 + 4]), [t5] "=&v"(t[k0 + 5]), [tmp] "=&v"(h3)
+                                                 : [left] "v"(left), [f0] "v"(F[k0]), [hn] "v"(H[kn]), [t0] "v"(t[k0]), [t1] "v"(t[k0 + 1]), [s0] "v"(sc[u][pl]),
+                                                   [s1] "v"(sc[u][pl + 1 < kPlanes ? pl + 1 : 0]), [c] "v"(open_minus_ext));
+                                else
+                                    asm volatile(SWH_NWP_PLANE("v_max_i32")
+                                                 : [h0] "+v"(H[k0]), [h1] "+v"(H[k0 + 1]), [h2] "+v"(H[k0 + 2]), [h3] "+v"(H[k0 + 3]), [f1] "+v"(F[k0 + 1]),
+                                                   [f2] "+v"(F[k0 + 2]), [f3] "+v"(F[k0 + 3]), [f4] "+v"(F[kn]), [e] "+v"(e), [t2] "=&v"(t[k0 + 2]),
+                                                   [t3] "=&v"(t[k0 + 3]), [t4] "=&v"(t[k0 + 4]), [t5] "=&v"(t[k0 + 5]), [tmp] "=&v"(h3)
+                                                 : [left] "v"(left), [f0] "v"(F[k0]), [hn] "v"(H[kn]), [t0] "v"(t[k0]), [t1] "v"(t[k0 + 1]), [s0] "v"(sc[u][pl]),
+                                                   [s1] "v"(sc[u][pl + 1 < kPlanes ? pl + 1 : 0]), [c] "v"(open_minus_ext));
+                            } else {
+                                if constexpr (kNarrow)
+                                    asm volatile(SWH_NWP_LAST_PLANE("v_max_u16")
+                                                 : [h0] "+v"(H[k0]), [h1] "+v"(H[k0 + 1]), [h2] "+v"(H[k0 + 2]), [h3] "+v"(H[k0 + 3]), [f1] "+v"(F[k0 + 1]),
+                                                   [f2] "+v"(F[k0 + 2]), [f3] "+v"(F[k0 + 3]), [e] "+v"(e), [t2] "=&v"(t[k0 + 2]), [t3] "=&v"(t[k0 + 3]), [tmp] "=&v"(h3)
+                                                 : [left] "v"(left), [f0] "v"(F[k0]), [t0] "v"(t[k0]), [t1] "v"(t[k0 + 1]), [s0] "v"(sc[u][pl]), [c] "v"(open_minus_ext));
+                                else
+                                    asm volatile(SWH_NWP_LAST_PLANE("v_max_i32")
+                                                 : [h0] "+v"(H[k0]), [h1] "+v"(H[k0 + 1]), [h2] "+v"(H[k0 + 2]), [h3] "+v"(H[k0 + 3]), [f1] "+v"(F[k0 + 1]),
+                                                   [f2] "+v"(F[k0 + 2]), [f3] "+v"(F[k0 + 3]), [e] "+v"(e), [t2] "=&v"(t[k0 + 2]), [t3] "=&v"(t[k0 + 3]), [tmp] "=&v"(h3)
+                                                 : [left] "v"(left), [f0] "v"(F[k0]), [t0] "v"(t[k0]), [t1] "v"(t[k0 + 1]), [s0] "v"(sc[u][pl]), [c] "v"(open_minus_ext));
+                            }
+                            left = H[k0 + 3];
+                        }
+                    } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) cell(4 * pl + i, (int)(int8_t)(c4 >> (8 * i)));
+                        for (int pl = 0; pl < kPlanes; ++pl) {
+                            const uint32_t c4 = sc[u][pl];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) cell(4 * pl + i, (int)(int8_t)(c4 >> (8 * i)));
+                        }
+                        finish(WE - 1, t_pending, t_pending);
                     }
-                    finish(WE - 1, t_pending, t_pending);
                     out_h = left;
                     if constexpr (kAffine) out_e = e;
                     if constexpr (write_bnd) {
@@ -271,6 +367,27 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
             if (read_bnd) bnd_deliver(s0 - 60 + 129);
             wave_lds_fence();
             if (write_bnd) bnd_flush((int)(s0 - 60) - 62);   // lane 63 did rows s0 - 60 - 62 .. s0 - 60 + 1 in this block
+            if constexpr (kNarrow) {
+                // the middle of the wave goes back to kCenter (after the flush: what the block parked was stored under the old shift)
+                const int delta = __builtin_amdgcn_readlane(H[WE / 2], 32) - kCenter;
+                shift += delta;
+#pragma unroll
+                for (int k = 0; k < WE; ++k) { H[k] -= delta; F[k] -= delta; }
+                out_h -= delta; out_e -= delta; prev_h -= delta;
+                if (read_bnd) {
+                    // the left edge of the next block, rows s0 + 5 .. s0 + 68: true values in the ring (delivered two blocks ago) and in
+                    // the registers fetched at the top of this group
+                    const uint32_t slot = (s0 + 4 + (uint32_t)lane) & (kBndReadRows - 1);
+                    rring_h[slot] -= shift;
+                    rring_e[slot] -= shift;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { bnd_next[u] -= shift; ebnd_next[u] -= shift; }
+                    wave_lds_fence();
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bnd_next[u] -= delta;   // the DP's own left edge: a constant in true values
+                }
+            }
         }
     };
     // three loops rather than one with two bodies: where two differently allocated bodies join, hipcc reconciles their
@@ -292,6 +409,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
 #pragma unroll
             for (int k = 0; k < WE; ++k)
                 if ((uint32_t)k == kk) result = H[k];
+            if constexpr (kNarrow) result += shift;
             result += (int)(rows + cols) * ext;
             if constexpr (kAffine) result -= open_minus_ext;   // the strip holds H^ + (open - ext)
             store_result(args.job, p, (int64_t)result);
@@ -301,7 +419,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     wave_lds_fence();                // and nobody is still reading the profile or the ring
 }
 
-template <int W, bool kAffine, bool kLocal>
+template <int W, bool kAffine, bool kLocal, bool kNarrow>
 __global__ __launch_bounds__(64) void k_nwprofile(KernelArgs args, uint32_t first, uint32_t count, uint32_t classes) {
     static_assert(W % 4 == 0 && W >= 4 && W <= 16, "strips are handled four columns at a time");
     constexpr uint32_t kRowBytes = 64u * W;
@@ -346,7 +464,7 @@ __global__ __launch_bounds__(64) void k_nwprofile(KernelArgs args, uint32_t firs
             const uint32_t c0 = pass * 64 * W;
             const uint32_t w = pass < full ? (uint32_t)W : w_last;
 #define SWH_PASS2(WE, RD, WR)                                                                                                  \
-    run_pass<WE, kAffine, RD, WR, kLocal>(args, smem, ring_at, ctab, cmap, classes, kRowBytes, col_data, row_data, rows, cols, c0, bnd_h, bnd_e, p, best)
+    run_pass<WE, kAffine, RD, WR, kLocal, kNarrow>(args, smem, ring_at, ctab, cmap, classes, kRowBytes, col_data, row_data, rows, cols, c0, bnd_h, bnd_e, p, best)
 #define SWH_PASS(WE)                                                                    \
     do {                                                                                \
         if (pass == 0) { if (passes == 1) SWH_PASS2(WE, false, false); else SWH_PASS2(WE, false, true); } \
@@ -374,20 +492,20 @@ __global__ __launch_bounds__(64) void k_nwprofile(KernelArgs args, uint32_t firs
     }
 }
 
-template <int W, bool kAffine, bool kLocal>
+template <int W, bool kAffine, bool kLocal, bool kNarrow>
 void launch_w(Scope *scope, const KernelArgs &args, uint32_t first, uint32_t count, uint32_t classes, uint32_t blocks, const char *name) {
     const size_t lds = (size_t)classes * 64 * W + kScratchBytes + 256;
-    opt_in_dynamic_lds(scope, (const void *)k_nwprofile<W, kAffine, kLocal>, lds);
+    opt_in_dynamic_lds(scope, (const void *)k_nwprofile<W, kAffine, kLocal, kNarrow>, lds);
     StampGuard guard(scope, name);
-    hipLaunchKernelGGL((k_nwprofile<W, kAffine, kLocal>), dim3(blocks), dim3(64), lds, scope->stream, args, first, count, classes);
+    hipLaunchKernelGGL((k_nwprofile<W, kAffine, kLocal, kNarrow>), dim3(blocks), dim3(64), lds, scope->stream, args, first, count, classes);
 }
 
-template <bool kAffine, bool kLocal>
+template <bool kAffine, bool kLocal, bool kNarrow = false>
 void launch_strip(Scope *scope, const KernelArgs &args, uint32_t first, uint32_t count, uint32_t classes, uint32_t blocks, uint32_t strip,
                   const char *n16, const char *n12, const char *n8) {
-    if (strip == 16) launch_w<16, kAffine, kLocal>(scope, args, first, count, classes, blocks, n16);
-    else if (strip == 12) launch_w<12, kAffine, kLocal>(scope, args, first, count, classes, blocks, n12);
-    else launch_w<8, kAffine, kLocal>(scope, args, first, count, classes, blocks, n8);
+    if (strip == 16) launch_w<16, kAffine, kLocal, kNarrow>(scope, args, first, count, classes, blocks, n16);
+    else if (strip == 12) launch_w<12, kAffine, kLocal, kNarrow>(scope, args, first, count, classes, blocks, n12);
+    else launch_w<8, kAffine, kLocal, kNarrow>(scope, args, first, count, classes, blocks, n8);
 }
 
 }  // namespace
@@ -398,6 +516,13 @@ uint32_t nwprofile_strip(uint32_t classes) {
     static const uint32_t forced = [] { const char *e = getenv("STRINGWARS_AMD_NWP_STRIP"); return e ? (uint32_t)atoi(e) : 0u; }();
     if ((forced == 8 || forced == 12 || forced == 16) && (size_t)classes * 64 * forced + kScratchBytes + 256 <= 65536) return forced;
     return classes <= 16 ? 16u : (classes <= 24 ? 12u : 8u);
+}
+
+// Narrow strips (see kCenter): everything a wave holds at one time must fit 16 bits around its middle.
+// Comparison knob: STRINGWARS_AMD_NWP_NARROW=0 keeps the 32-bit maxima.
+static bool nwprofile_narrow(const Scoring &scoring, uint32_t strip) {
+    static const bool off = [] { const char *e = getenv("STRINGWARS_AMD_NWP_NARROW"); return e && e[0] == '0'; }();
+    return !off && scoring.step_span && (uint64_t)scoring.step_span * (64 * strip + 256) <= 30000;
 }
 
 uint32_t nwprofile_waves(const Scope *scope, uint32_t classes) {
@@ -419,6 +544,8 @@ void launch_nwprofile(Scope *scope, KernelArgs args, uint32_t first, uint32_t co
     const uint32_t strip = nwprofile_strip(classes);
     if (!args.local) {
         if (!args.affine) launch_strip<false, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_w16", "nwprofile_w12", "nwprofile_w8");
+        else if (nwprofile_narrow(args.scoring, strip))
+            launch_strip<true, false, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_affine_narrow_w16", "nwprofile_affine_narrow_w12", "nwprofile_affine_narrow_w8");
         else launch_strip<true, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_affine_w16", "nwprofile_affine_w12", "nwprofile_affine_w8");
     } else {
         if (!args.affine) launch_strip<false, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_w16", "nwprofile_local_w12", "nwprofile_local_w8");

@@ -549,6 +549,63 @@ def test_column_profile_kernel_every_strip_shape(sw, orc, scope, gaps, classes):
         assert bad.size == 0, ("local", classes, gaps, symmetric, bad[:5], got[bad[:5]], want_local[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
 
 
+def test_gotoh_narrow_strips_follow_the_scores(sw, orc, scope):
+    """nwprofile.hip, affine gaps: the strips hold 16-bit distances to a wave-wide `shift` that is moved every 64 steps
+    (`kNarrow`). Pairs whose scores run away from the all-gaps baseline as fast as the costs allow, upwards (identical
+    strings, +11 a symbol) and downwards (nothing in common), over one to six passes; a pair that changes its mind half way;
+    and a matrix whose costs are too wide for 16 bits, which must take the 32-bit kernel."""
+    rng = np.random.default_rng(77)
+    byte_to_class = (np.arange(256) % 21).astype(np.uint8)
+    costs = np.zeros((32, 32), dtype=np.int8)
+    costs[:21, :21] = -9
+    costs[np.arange(21), np.arange(21)] = 11
+    items_a, items_b = [], []
+    for n in (400, 769, 1500, 3000, 5200):
+        same = bytes(rng.integers(0, 21, n, dtype=np.uint8))
+        low, high = bytes(rng.integers(0, 10, n, dtype=np.uint8)), bytes(rng.integers(10, 21, n + 37, dtype=np.uint8))
+        items_a += [same, low, same + low, low + same, same]
+        items_b += [same, high, same + high, high[: n // 2] + same, same[: n // 2] + high]
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    full = costs[byte_to_class][:, byte_to_class].astype(np.int8)
+    engine = sw.NeedlemanWunschScores(byte_to_class, costs, open=-11, extend=-1, capabilities=scope)
+    scope.set_profiling(True)
+    got = engine.pairs(a, b, scope)
+    assert "narrow" in scope.last_timing()["dominant_name"], scope.last_timing()
+    want = orc.nw_pairs(a, b, full, -11, -1)
+    assert (got == want).all(), np.nonzero(got != want)[0][:8]
+    assert (engine.pairs(b, a, scope) == want).all()
+    wide = costs.copy()
+    wide[:21, :21] = -60
+    wide[np.arange(21), np.arange(21)] = 60
+    engine = sw.NeedlemanWunschScores(byte_to_class, wide, open=-11, extend=-1, capabilities=scope)
+    got = engine.pairs(a, b, scope)
+    name = scope.last_timing()["dominant_name"]
+    scope.set_profiling(False)
+    assert name.startswith("nwprofile_affine") and "narrow" not in name, name
+    assert (got == orc.nw_pairs(a, b, wide[byte_to_class][:, byte_to_class].astype(np.int8), -11, -1)).all()
+    # the comparison knob (read once per process): the same scores from the 32-bit strips
+    import subprocess
+    import sys
+    code = ("import numpy as np, stringwars_amd as sw\n"
+            "scope = sw.DeviceScope(gpu_device=0)\n"
+            "pa, pb = sw.generate_pairs('protein4k', 8, seed=5)\n"
+            "engine = sw.NeedlemanWunschScores(substitution_matrix=sw.substitution_matrix(5), open=-11, extend=-1, capabilities=scope)\n"
+            "scope.set_profiling(True)\n"
+            "got = engine.pairs(pa, pb, scope)\n"
+            "print(scope.last_timing()['dominant_name'], ' '.join(str(int(v)) for v in got))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for narrow in ("1", "0"):
+        done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, STRINGWARS_AMD_NWP_NARROW=narrow, PYTHONPATH=root),
+                              capture_output=True, text=True, timeout=300)
+        assert done.returncode == 0, done.stderr[-2000:]
+        lines.append(done.stdout.strip().splitlines()[-1].split(" ", 1))
+    assert "narrow" in lines[0][0] and "narrow" not in lines[1][0] and lines[1][0].startswith("nwprofile_affine"), lines
+    assert lines[0][1] == lines[1][1]
+    pa, pb = sw.generate_pairs("protein4k", 8, seed=5)
+    assert lines[0][1] == " ".join(str(int(v)) for v in orc.nw_pairs(pa, pb, sw.substitution_matrix(5), -11, -1))
+
+
 def test_smith_waterman(sw, orc, scope):
     """`SmithWatermanScores` (bench.rs:882-963): KATs of SURVEY 8c, random matrices, multi-pass, cross-product."""
     cases = KAT["sw_unary_2_m1"]["cases"]

@@ -38,6 +38,11 @@ static bool trace_launches() {
     static const bool on = [] { const char *e = getenv("STRINGWARS_AMD_TRACE"); return e && atoi(e) != 0; }();
     return on;
 }
+// STRINGWARS_AMD_STAMPS=1: with profiling on, the start and the length of every stamped launch of a call (event times) on stderr.
+static bool trace_stamps() {
+    static const bool on = [] { const char *e = getenv("STRINGWARS_AMD_STAMPS"); return e && atoi(e) != 0; }();
+    return on;
+}
 StampGuard::StampGuard(Scope *s, const char *name) : scope(s), idx(0), on(s->profiling) {
     if (trace_launches()) { fprintf(stderr, "[swh] launch %s\n", name); fflush(stderr); }
     if (!on) return;
@@ -79,6 +84,11 @@ static void collect_timing(Scope *scope) {
             float from = 0;
             (void)hipEventElapsedTime(&from, scope->stamps[0].start, scope->stamps[i].start);
             dp.emplace_back(from, from + ms);
+        }
+        if (trace_launches() || trace_stamps()) {
+            float from = 0;
+            (void)hipEventElapsedTime(&from, scope->stamps[0].start, scope->stamps[i].start);
+            fprintf(stderr, "[swh] stamp %-28s start %8.3f ms  length %8.3f ms\n", scope->stamps[i].name, from, ms);
         }
         if (ms > t.dominant_ms) {
             t.dominant_ms = ms;
@@ -158,9 +168,9 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
 
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
 static size_t utf8_scratch_words(uint64_t bytes) {
-    // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances
+    // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances | u64 look-back words + ticket
     uint64_t tiles = (bytes + kUtf8Tile - 1) / kUtf8Tile;
-    return (size_t)((tiles + 4) + (kUtf8Subs * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4) + (tiles + 4));
+    return (size_t)((tiles + 4) + (kUtf8Subs * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4) + (tiles + 6) + 2 * (tiles + 2));
 }
 
 static bool is_device_pointer(const void *p) {

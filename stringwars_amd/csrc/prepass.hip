@@ -1148,6 +1148,139 @@ __global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, ui
     if (threadIdx.x == 0) balance[tile] = lds.wave_bal[0] + lds.wave_bal[1] + lds.wave_bal[2] + lds.wave_bal[3];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same staging in ONE pass over the tape (what launch_utf8_decode runs unless STRINGWARS_AMD_UTF8_SCAN=split): count,
+// prefix and decode per tile in one kernel, the tile's code-point index found by a decoupled look-back over the tiles before it
+// instead of a count kernel + a scan kernel (one read of the tape less, two launches less per tape).
+//   status[tile] = flag << 62 | count: flag 1 -- the tile's own code points (published as soon as they are counted),
+//                                      flag 2 -- all code points up to and including the tile (published after the look-back).
+// Tiles are handed out by a ticket, so every tile before mine belongs to a workgroup that is already running (or done) and
+// publishes its flag-1 word without waiting for anybody: the look-back cannot deadlock. Wave 0 looks back 64 tiles at a time.
+// tile_prefix[] / sub_prefix[] are still written: k_utf8_string_offsets reads them.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long kStatusCount = (1ull << 62) - 1;
+
+__global__ __launch_bounds__(256) void k_utf8_tile_decode(const uint8_t *data, uint64_t total, uint64_t tiles, unsigned long long *status,
+                                                          uint32_t *ticket, uint64_t *tile_prefix, uint32_t *sub_prefix,
+                                                          uint32_t *symbols, uint32_t *invalid, int *balance) {
+    __shared__ Utf8WriteLds lds;
+    __shared__ unsigned long long tile_base;
+    __shared__ uint32_t my_tile;
+    if (threadIdx.x == 0) my_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint64_t tile = my_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tot = (int64_t)total;
+    // interior tiles: every word this block touches (its own and the one after its last) lies inside the tape; the others
+    // load with bounds checks (bytes past the tape read as zero: never a lead -- masked below -- and never a continuation byte)
+    const bool edge = (tile + 1) * kUtf8Tile + 4 > total;
+    uint32_t curs[kUtf8Passes], flags[kUtf8Passes];
+    uint32_t after = 0;   // the word after the tile: look-ahead of its last sequences
+    int held = 0;         // continuation bytes in my words
+    if (!edge) {
+        const uint8_t *src = data + tile * kUtf8Tile + threadIdx.x * 4;
+#pragma unroll
+        for (int q = 0; q < kUtf8Passes; ++q) __builtin_memcpy(&curs[q], src + q * kUtf8Pass, 4);   // all loads first
+        if (threadIdx.x == 0) __builtin_memcpy(&after, data + (tile + 1) * kUtf8Tile, 4);
+#pragma unroll
+        for (int q = 0; q < kUtf8Passes; ++q) { flags[q] = lead_flags4(curs[q]); held += 4 - __popc(flags[q]); }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kUtf8Passes; ++q) {
+            const int64_t pos = (int64_t)(tile * kUtf8Tile + q * kUtf8Pass + threadIdx.x * 4);
+            const int valid = tot - pos >= 4 ? 4 : (tot > pos ? (int)(tot - pos) : 0);
+            curs[q] = valid ? load_tape_dword(data, pos, tot) : 0;
+            flags[q] = valid ? lead_flags4(curs[q]) & (0x80808080u >> (8 * (4 - valid))) : 0u;
+            held += valid - __popc(flags[q]);
+        }
+        if (threadIdx.x == 0) after = load_tape_dword(data, (int64_t)((tile + 1) * kUtf8Tile), tot);
+    }
+    uint32_t incls[kUtf8Passes];
+#pragma unroll
+    for (int q = 0; q < kUtf8Passes; ++q) {
+        incls[q] = wave_inclusive_sum_u32((uint32_t)__popc(flags[q]));
+        if (lane == 63) lds.wave_tot[q][wave] = incls[q];
+        lds.raw[q * 256 + threadIdx.x] = curs[q];
+    }
+    if (threadIdx.x == 0) lds.raw[kUtf8Tile / 4] = after;
+    __syncthreads();
+    // the byte positions of the tile's lead bytes in rank order (see k_utf8_tile_write), and the tile's count
+    uint32_t before = 0;   // code points of the passes before q
+#pragma unroll
+    for (int q = 0; q < kUtf8Passes; ++q) {
+        const uint32_t mine = (uint32_t)__popc(flags[q]);
+        uint32_t base = before;
+        for (int w = 0; w < wave; ++w) base += lds.wave_tot[q][w];
+        uint32_t rank = base + incls[q] - mine;   // within the tile
+        if (q == 0 && threadIdx.x == 0) {
+            // (the count is known to every thread only after this loop: thread 0 sums the 32 wave totals now and publishes)
+            uint32_t sum = 0;
+            for (int qq = 0; qq < kUtf8Passes; ++qq)
+                for (int w = 0; w < 4; ++w) sum += lds.wave_tot[qq][w];
+            __hip_atomic_store(status + tile, (tile == 0 ? 2ull << 62 : 1ull << 62) | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((flags[q] >> (8 * u + 7)) & 1u) lds.leads[rank++] = (uint16_t)(q * kUtf8Pass + threadIdx.x * 4 + u);
+        before += lds.wave_tot[q][0] + lds.wave_tot[q][1] + lds.wave_tot[q][2] + lds.wave_tot[q][3];
+    }
+    const uint32_t tile_total = before;
+    if (wave == 1 && lane == 0) {   // the sub-tile prefixes k_utf8_string_offsets wants (one wave of one pass = 256 bytes)
+        uint32_t run = 0;
+        for (int q = 0; q < kUtf8Passes; ++q)
+            for (int w = 0; w < 4; ++w) { sub_prefix[tile * kUtf8Subs + q * 4 + w] = run; run += lds.wave_tot[q][w]; }
+    }
+    if (wave == 0) {
+        // look-back: lane l reads the status of tile - 1 - l of the current window
+        unsigned long long exclusive = 0;
+        for (int64_t first = (int64_t)tile - 1; first >= 0; first -= 64) {
+            const int64_t at = first - lane;
+            unsigned long long word = 2ull << 62;   // before the tape: "everything up to here" = 0
+            if (at >= 0) {
+                while (((word = __hip_atomic_load(status + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned long long closed = __ballot((word >> 62) == 2);
+            const int stop = closed ? __builtin_ctzll(closed) : 64;   // the nearest tile that knows its inclusive prefix
+            unsigned long long part = lane <= stop ? (word & kStatusCount) : 0ull;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+            exclusive += part;
+            if (closed) break;
+        }
+        if (lane == 0) {
+            if (tile) __hip_atomic_store(status + tile, (2ull << 62) | (exclusive + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tile_base = exclusive;
+            tile_prefix[tile] = exclusive;
+            if (tile + 1 == tiles) tile_prefix[tiles] = exclusive + tile_total;
+        }
+    }
+    __syncthreads();
+    uint32_t *out = symbols + tile_base;
+    int bal = -held;   // continuation bytes the sequences I decode expect, minus continuation bytes I hold
+    bool bad = false;
+    uint32_t bad_at = 0;
+    // (four sequences per thread and round, their LDS reads issued together, changed nothing: the kernel is bound by its VALU
+    // instructions -- 43 lane operations per byte, two thirds of them in this loop -- not by LDS latency)
+    for (uint32_t i = threadIdx.x; i < tile_total; i += 256) {
+        const uint32_t at = lds.leads[i];
+        const uint32_t lo = lds.raw[at >> 2], hi = lds.raw[(at >> 2) + 1];
+        const uint32_t seq = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (at & 3u)));
+        uint32_t need;
+        bool bad_here;
+        const uint32_t cp = utf8_decode_one(seq, need, bad_here);
+        bal += (int)need;
+        // a sequence may not run past the end of the tape (the zero bytes read there are no continuation bytes, so `bad_here` has it)
+        if (bad_here && !bad) { bad = true; bad_at = at; }
+        out[i] = cp;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bal += __shfl_xor(bal, off);
+    if (lane == 0) lds.wave_bal[wave] = bal;
+    if (bad) atomicCAS(invalid, 0u, (uint32_t)((tile * kUtf8Tile + bad_at) >> 2) + 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) balance[tile] = lds.wave_bal[0] + lds.wave_bal[1] + lds.wave_bal[2] + lds.wave_bal[3];
+}
+
 __global__ __launch_bounds__(256) void k_utf8_balance(const int *tile_balance, uint64_t tiles, int *balance) {
     __shared__ int red[256];
     int sum = 0;
@@ -1179,7 +1312,13 @@ __global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, cons
     const uint64_t tile = (uint64_t)off / kUtf8Tile, sub = ((uint64_t)off % kUtf8Tile) / 256;
     const int64_t sub_start = (int64_t)(tile * kUtf8Tile + sub * 256);
     uint32_t cnt = 0;
-    for (int64_t q = sub_start; q < off; q += 4) {
+    int64_t q = sub_start;
+    for (; q + 16 <= off; q += 16) {   // whole 16-byte units below the string: inside the tape, no masks (a dword at a time was a
+        uint4 v;                       // chain of up to 63 dependent loads per string: 40 us for 100 K strings)
+        __builtin_memcpy(&v, data + q, 16);
+        cnt += __popc(lead_flags4(v.x)) + __popc(lead_flags4(v.y)) + __popc(lead_flags4(v.z)) + __popc(lead_flags4(v.w));
+    }
+    for (; q < off; q += 4) {
         int valid = off - q >= 4 ? 4 : (int)(off - q);
         cnt += __popc(lead_mask4(load_tape_dword(data, q, total), valid));
     }
@@ -1286,7 +1425,20 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
     uint64_t *tile_prefix = (uint64_t *)(sub_prefix + kUtf8Subs * tiles + 2 - ((kUtf8Subs * tiles) & 1));
     unsigned long long *block_sums = (unsigned long long *)(tile_prefix + tiles + 2);
     int *tile_balance = (int *)(block_sums + (tiles + 1023) / 1024 + 4);
-    if (tiles) {
+    unsigned long long *status = (unsigned long long *)(tile_balance + ((tiles + 4) & ~1ull));   // + the ticket behind its `tiles` words
+    // STRINGWARS_AMD_UTF8_SCAN=split forces the count / scan / write kernels with the three-kernel scan, =scan the same with
+    // the one-launch scan (what round 2 ran; tests and comparisons use them)
+    static const int scan_mode = [] {
+        const char *e = getenv("STRINGWARS_AMD_UTF8_SCAN");
+        return !e ? 0 : (!strcmp(e, "split") ? 2 : (!strcmp(e, "scan") ? 1 : 0));
+    }();
+    if (tiles && scan_mode == 0) {
+        SWH_HIP_CHECK(hipMemsetAsync(status, 0, (tiles + 1) * sizeof(unsigned long long), stream));
+        StampGuard guard(scope, "utf8_tile_decode");
+        hipLaunchKernelGGL(k_utf8_tile_decode, dim3((uint32_t)tiles), dim3(256), 0, stream, (const uint8_t *)args.in.data, total, tiles, status,
+                           (uint32_t *)(status + tiles), tile_prefix, sub_prefix, args.symbols, args.invalid, tile_balance);
+        hipLaunchKernelGGL(k_utf8_balance, dim3(64), dim3(256), 0, stream, tile_balance, tiles, (int *)(args.invalid + 1 + args.slot));
+    } else if (tiles) {
         {
             StampGuard guard(scope, "utf8_tile_count");
             hipLaunchKernelGGL(k_utf8_tile_count, dim3((uint32_t)tiles), dim3(256), 0, stream, (const uint8_t *)args.in.data,
@@ -1295,8 +1447,7 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
         uint32_t nblocks = (uint32_t)((tiles + kScanBlock - 1) / kScanBlock);
         {
             StampGuard guard(scope, "utf8_scan");
-            // STRINGWARS_AMD_UTF8_SCAN=split forces the three-kernel scan (what tapes beyond 0.5 GB take; tests use it)
-            static const bool split_scan = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_SCAN"); return e && !strcmp(e, "split"); }();
+            const bool split_scan = scan_mode == 2;   // (also what tapes beyond 0.5 GB take on this path)
             if (tiles <= kScanOneMax && !split_scan) {
                 hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(kScanBlock), 0, stream, tile_counts, tiles, tile_prefix);
             } else {

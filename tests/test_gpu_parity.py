@@ -1300,9 +1300,12 @@ def test_utf8_validation_matches_the_oracle(sw, orc, scope):
         assert engine.pairs([s], [b"a" * lead + b"b"], scope).tolist() == [1]
 
 
-def test_utf8_three_kernel_scan_path(orc):
-    """Tapes beyond 0.5 GB scan their tile counts with three kernels instead of one; STRINGWARS_AMD_UTF8_SCAN=split
-    selects that path for any size (read once per process, hence the subprocess)."""
+@pytest.mark.parametrize("mode", ["split", "scan"])
+def test_utf8_three_kernel_scan_path(orc, mode):
+    """The decoder before the one-pass kernel (count, scan, write): STRINGWARS_AMD_UTF8_SCAN=scan runs it with the one-launch
+    scan, =split with the three-kernel scan that tapes beyond 0.5 GB took (read once per process, hence the subprocess).
+    The default -- one kernel per tape, tile prefixes by decoupled look-back over up to hundreds of tiles -- is what every
+    other UTF-8 test runs."""
     import subprocess
     import sys
     code = (
@@ -1313,7 +1316,7 @@ def test_utf8_three_kernel_scan_path(orc):
         "want = oracle.levenshtein_pairs(a, b, utf8=True, bound=40)\n"
         "assert (got == want).all()\n"
         "print('split-scan ok')\n")
-    env = dict(os.environ, STRINGWARS_AMD_UTF8_SCAN="split", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, STRINGWARS_AMD_UTF8_SCAN=mode, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0 and "split-scan ok" in done.stdout, done.stderr[-2000:]
 

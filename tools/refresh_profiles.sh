@@ -23,7 +23,7 @@ for leg in $LEGS; do
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
              "FETCH_SIZE" "WRITE_SIZE"; do
     tag=$(echo $set | cut -d' ' -f1)
-    timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$dir" -o "$tag" -- python3 "$REPO/bench.py" --only-config $leg --calls $CALLS --no-cpu-baseline > "$dir/$tag.log" 2>&1
+    timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$dir" -o "$tag" -- python3 "$REPO/bench.py" --only-config $leg --calls $CALLS --no-cpu-baseline > "$dir/$tag.log" 2>&1
   done
   if [ "$leg" != c3_raw ]; then
     python3 "$REPO/tools/pmc_constants.py" "$dir" --workload ${WORKLOAD[$leg]} --pairs ${PAIRS[$leg]} --calls $CALLS --variant "${VARIANT[$leg]}" --out "$OUT/pmc_constants.json" \
@@ -45,15 +45,15 @@ PY
 done
 if [ "${REFRESH_PMC_ONLY:-0}" = 1 ]; then rm -rf "$OUT"/pmc_*/; ls "$OUT"; exit 0; fi
 # 2. rocprofv3 --kernel-trace --stats of the bench command (synchronous steps only: what `roofline.kernel_ms` averages over) and of every leg
-stats() { name=$1; shift; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rp_$name" -o "$name" -- python3 "$@" > "$OUT/rp_$name.log" 2>&1; cp "$OUT/rp_$name/${name}_kernel_stats.csv" "$OUT/${name}_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/rp_$name"; }
+stats() { name=$1; shift; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rp_$name" -o "$name" -- python3 "$@" > "$OUT/rp_$name.log" 2>&1; cp "$OUT/rp_$name/${name}_kernel_stats.csv" "$OUT/${name}_kernel_stats.csv" 2>/dev/null; rm -rf "$OUT/rp_$name"; }
 stats bench_c2_sync "$REPO/bench.py" --no-cpu-baseline --no-configs --no-pipelined
 stats bench_c2_full "$REPO/bench.py" --no-cpu-baseline --no-configs
 for leg in $LEGS; do stats leg_$leg "$REPO/bench.py" --only-config $leg --no-cpu-baseline; done
 # 3. the bench lines themselves, with the fresh constants in place
 cd "$REPO"
 mkdir -p profiles/r3 && cp "$OUT/pmc_constants.json" profiles/r3/pmc_constants.json
-timeout 600 python3 bench.py > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
-timeout 400 python3 bench.py --config c5 --steps 20 --warmup 2 --no-cpu-baseline --no-configs > "$OUT/bench_c5_100m.json" 2> "$OUT/bench_c5_100m.err"
-timeout 300 python3 tools/bench_cross.py > "$OUT/crossproduct_table.jsonl" 2> "$OUT/cross.err"
+timeout -k 10 600 python3 bench.py > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+timeout -k 10 400 python3 bench.py --config c5 --steps 20 --warmup 2 --no-cpu-baseline --no-configs > "$OUT/bench_c5_100m.json" 2> "$OUT/bench_c5_100m.err"
+timeout -k 10 300 python3 tools/bench_cross.py > "$OUT/crossproduct_table.jsonl" 2> "$OUT/cross.err"
 rm -rf "$OUT"/pmc_*/
 du -sh "$OUT"; ls "$OUT"

@@ -1300,6 +1300,50 @@ def test_utf8_validation_matches_the_oracle(sw, orc, scope):
         assert engine.pairs([s], [b"a" * lead + b"b"], scope).tolist() == [1]
 
 
+def test_utf8_validation_fuzz(sw, orc, scope):
+    """Random byte strings over the bytes that matter to a UTF-8 decoder (the edges of every lead / continuation range),
+    planted in valid text at random offsets around the decoder's tile edges: the library rejects exactly the tapes the oracle's
+    decoder rejects, and scores the others like the oracle."""
+    rng = np.random.default_rng(99)
+    edge_bytes = np.array([0x00, 0x41, 0x7F, 0x80, 0x8F, 0x90, 0x9F, 0xA0, 0xBF, 0xC0, 0xC1, 0xC2, 0xDF, 0xE0, 0xE1, 0xEC, 0xED, 0xEE, 0xEF,
+                           0xF0, 0xF1, 0xF3, 0xF4, 0xF5, 0xF8, 0xFF], dtype=np.uint8)
+    edge_points = [0x00, 0x41, 0x7F, 0x80, 0x7FF, 0x800, 0xFFF, 0x1000, 0xCFFF, 0xD000, 0xD7FF, 0xE000, 0xFFFD, 0xFFFF, 0x10000, 0x3FFFF,
+                   0x40000, 0xFFFFF, 0x100000, 0x10FFFF]
+    filler = "x\u00e9\u4e2d\U0001f600y".encode("utf-8")
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    rejected = accepted = 0
+    for _ in range(1200):
+        # boundary code points of every sequence length, then (mostly) one byte replaced, inserted or dropped
+        junk = bytearray("".join(chr(edge_points[i]) for i in rng.integers(0, len(edge_points), int(rng.integers(1, 4)))).encode("utf-8"))
+        if rng.random() < 0.6:
+            at, kind = int(rng.integers(0, len(junk))), int(rng.integers(0, 3))
+            if kind == 0: junk[at] = int(edge_bytes[rng.integers(0, edge_bytes.size)])
+            elif kind == 1: junk.insert(at, int(edge_bytes[rng.integers(0, edge_bytes.size)]))
+            else: del junk[at]
+        junk = bytes(junk) or b"\x80"
+        lead = int(rng.choice([0, 3, 250, 1017, 8180, 8189, 16379])) + int(rng.integers(0, 8))
+        head = (filler * (lead // len(filler) + 1))[:lead]
+        while head and ((head[-1] & 0xC0) == 0x80 or head[-1] >= 0xC0):   # cut the filler on a sequence boundary
+            head = head[:-1]
+        text = head + junk + filler * int(rng.integers(0, 3))
+        try:
+            orc.utf8_decode(text)
+            valid = True
+        except ValueError:
+            valid = False
+        other = "reference \u00e9".encode("utf-8")
+        if valid:
+            accepted += 1
+            want = orc.levenshtein_pairs(sw.Strs([text, other]), sw.Strs([other, text]), utf8=True)
+            assert engine.pairs([text, other], [other, text], scope).tolist() == want.tolist(), junk
+        else:
+            rejected += 1
+            with pytest.raises(sw.StringWarsError) as info:
+                engine.pairs([other, text], [other, other], scope)
+            assert info.value.status == "invalid_utf8", junk
+    assert rejected > 200 and accepted > 200, (rejected, accepted)
+
+
 @pytest.mark.parametrize("mode", ["split", "scan"])
 def test_utf8_three_kernel_scan_path(orc, mode):
     """The decoder before the one-pass kernel (count, scan, write): STRINGWARS_AMD_UTF8_SCAN=scan runs it with the one-launch

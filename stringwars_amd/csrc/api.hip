@@ -167,6 +167,7 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
 }
 
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
+constexpr uint64_t kUtf8MergedBytes = 8ull << 20;   // both tapes of a call up to this size are staged by one launch pair
 static size_t utf8_scratch_words(uint64_t bytes) {
     // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances | u64 look-back words + ticket
     uint64_t tiles = (bytes + kUtf8Tile - 1) / kUtf8Tile;
@@ -416,7 +417,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 probe.take<uint32_t>(utf8_scratch_words(a_bytes));
                 probe.take<uint32_t>(b_bytes + 4); probe.take<uint64_t>(spec.b.count + 1);
                 probe.take<uint32_t>(utf8_scratch_words(b_bytes));
-                probe.take<uint32_t>(4);
+                probe.take<uint32_t>(kUtf8FlagWords);
             }
             need = probe.used;
         }
@@ -434,7 +435,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         uint32_t *invalid_dev = nullptr;
         if (utf8 && !prepared) {
             uint32_t decode_slot = 0;
-            auto decode = [&](const TapeRef &in, uint64_t bytes, TapeRef &out_tape) {
+            auto decode = [&](const TapeRef &in, uint64_t bytes, TapeRef &out_tape, uint64_t first_word, bool opened) {
                 Utf8Args u{};
                 u.slot = decode_slot++;
                 u.in = in; u.off64 = off64; u.total_bytes = bytes;
@@ -442,15 +443,34 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 u.offsets = sc.take<uint64_t>(in.count + 1);
                 u.counts = sc.take<uint32_t>(utf8_scratch_words(bytes));
                 u.invalid = invalid_dev;
-                launch_utf8_decode(scope, u);
+                if (utf8_one_pass()) launch_utf8_decode_pair(scope, u, nullptr, first_word, opened);
+                else launch_utf8_decode(scope, u);
                 out_tape.data = u.symbols; out_tape.offsets = u.offsets; out_tape.count = in.count;
             };
             TapeRef da, db;
-            invalid_dev = sc.take<uint32_t>(4);   // one flag + two balance words, shared by both decodes
-            SWH_HIP_CHECK(hipMemsetAsync(invalid_dev, 0, 16, stream));
+            invalid_dev = sc.take<uint32_t>(kUtf8FlagWords);   // one flag + two balance words + the tile tickets, shared by both decodes
+            SWH_HIP_CHECK(hipMemsetAsync(invalid_dev, 0, kUtf8FlagWords * sizeof(uint32_t), stream));
             if (same_tape) {
-                decode(ta, a_bytes, da);
+                decode(ta, a_bytes, da, 0, false);
                 db = da;
+            } else if (utf8_one_pass() && a_bytes + b_bytes <= kUtf8MergedBytes) {
+                // both tapes in the same two launches (tile decode, then string offsets + balance): what a small call costs is
+                // its launches (10 K word pairs: 135 -> 117 us per call). Large tapes keep a launch pair and a stream each
+                // below: 2 x 100 MB are staged in 0.28 ms that way, in 0.33 by one launch over both.
+                auto prepare = [&](const TapeRef &in, uint64_t bytes, Utf8Args &u) {
+                    u.slot = decode_slot++;
+                    u.in = in; u.off64 = off64; u.total_bytes = bytes;
+                    u.symbols = sc.take<uint32_t>(bytes + 4);
+                    u.offsets = sc.take<uint64_t>(in.count + 1);
+                    u.counts = sc.take<uint32_t>(utf8_scratch_words(bytes));
+                    u.invalid = invalid_dev;
+                };
+                Utf8Args ua{}, ub{};
+                prepare(ta, a_bytes, ua);
+                prepare(tb, b_bytes, ub);
+                launch_utf8_decode_pair(scope, ua, &ub, 0, false);
+                da.data = ua.symbols; da.offsets = ua.offsets; da.count = ta.count;
+                db.data = ub.symbols; db.offsets = ub.offsets; db.count = tb.count;
             } else {
                 // The two tapes decode side by side: the staging kernels are barrier- and latency-bound (half the issue
                 // slots idle), so the second tape's run on the side stream, forked after the inputs are in place.
@@ -459,14 +479,16 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                     StreamSwap(Scope *sc_, hipStream_t to) : s(sc_), keep(sc_->stream) { s->stream = to; }
                     ~StreamSwap() { s->stream = keep; }
                 };
+                const uint64_t a_tiles = (a_bytes + kUtf8Tile - 1) / kUtf8Tile, b_tiles = (b_bytes + kUtf8Tile - 1) / kUtf8Tile;
+                if (utf8_one_pass()) utf8_status_open(scope, a_tiles + b_tiles);   // before the fork: it may clear the words
                 SWH_HIP_CHECK(hipEventRecord(scope->fork_ev, stream));
                 SWH_HIP_CHECK(hipStreamWaitEvent(scope->side_stream, scope->fork_ev, 0));
+                decode(ta, a_bytes, da, 0, true);
                 {
                     StreamSwap swap(scope, scope->side_stream);
-                    decode(tb, b_bytes, db);
+                    decode(tb, b_bytes, db, a_tiles, true);
                 }
                 SWH_HIP_CHECK(hipEventRecord(scope->join_ev, scope->side_stream));
-                decode(ta, a_bytes, da);
                 SWH_HIP_CHECK(hipStreamWaitEvent(stream, scope->join_ev, 0));
             }
             ta = da; tb = db;
@@ -764,6 +786,7 @@ swh_status_t swh_scope_free(swh_scope_t handle) {
     if (scope->order_ev) (void)hipEventDestroy(scope->order_ev);
     for (auto &st : scope->stamps) { (void)hipEventDestroy(st.start); (void)hipEventDestroy(st.stop); }
     if (scope->scratch) (void)hipFree(scope->scratch);
+    if (scope->utf8_status) (void)hipFree(scope->utf8_status);
     if (scope->stage) (void)hipFree(scope->stage);
     if (scope->boundary) (void)hipFree(scope->boundary);
     if (scope->plan_host) (void)hipHostFree(scope->plan_host);
@@ -951,8 +974,8 @@ static swh_status_t prepare_tape(Scope *scope, const HostTape &tape, bool utf8, 
         }
         p->bytes = TapeRef{data, offsets, tape.count};
         // measurements: longest string in bytes (and in code points below)
-        uint32_t *words = (uint32_t *)own(64);   // [0] longest bytes, [1] longest symbols, [4..7] UTF-8 flag + balances
-        SWH_HIP_CHECK(hipMemsetAsync(words, 0, 64, stream));
+        uint32_t *words = (uint32_t *)own((4 + kUtf8FlagWords) * sizeof(uint32_t));   // [0] longest bytes, [1] longest symbols, [4 ...] UTF-8 flag, balances, tickets
+        SWH_HIP_CHECK(hipMemsetAsync(words, 0, (4 + kUtf8FlagWords) * sizeof(uint32_t), stream));
         launch_tape_longest(scope, offsets, p->off64, tape.count, words);
         uint64_t total_symbols = p->total_bytes;
         if (utf8) {

@@ -313,6 +313,9 @@ struct Scope {
     bool fused_disabled = false;    // the fused planner once failed to gather its grid on this scope
     hipStream_t side_stream = nullptr;  // plan read-back overlaps the first DP kernel
     hipEvent_t plan_ready = nullptr;
+    unsigned long long *utf8_status = nullptr;   // look-back words of k_utf8_tile_decode: written by nothing else, tagged with utf8_epoch
+    uint64_t utf8_status_cap = 0;
+    uint32_t utf8_epoch = 0;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;   // second tape's UTF-8 decode runs on side_stream beside the first's
     // wavefront class kernels alternate between the scope's stream and side_stream (launch_wavefront): each is a
     // persistent grid with its own tail, and a 10 K-pair batch is only a few rounds of waves per kernel
@@ -449,16 +452,23 @@ int wavefront_strip_cap();
 constexpr int kUtf8Pass = 1024, kUtf8Passes = 8;     // a block walks its tile in passes of 256 threads x one dword
 constexpr int kUtf8Tile = kUtf8Pass * kUtf8Passes;   // bytes per block
 constexpr int kUtf8Subs = kUtf8Tile / 256;           // 256-byte sub-tiles per tile
+constexpr int kUtf8FlagWords = 96;   // the tickets of two concurrent launches sit 128 bytes apart and away from the flag: on one
+                                     // cache line their atomics took turns (2 x 100 MB staged in 0.32 ms instead of 0.28)
 struct Utf8Args {
     TapeRef in; uint32_t off64;
     uint32_t *symbols;     // out, capacity = total bytes
     uint64_t *offsets;     // out, count+1
     uint32_t *counts;      // scratch, count entries
-    uint32_t *invalid;     // out flag (non-zero = invalid UTF-8); words [1], [2] are per-tape balance counters
+    uint32_t *invalid;     // out flag (non-zero = invalid UTF-8); words [1], [2] are per-tape balance counters (count / scan / write
+                           // path); words [32 (1 + slot)] the one-pass kernel's tile tickets: kUtf8FlagWords zeroed words in all
     uint32_t slot;         // which balance counter this tape uses (0 or 1)
     uint64_t total_bytes;
 };
 void launch_utf8_decode(Scope *scope, const Utf8Args &args);
+// the one-pass staging (default; prepass.hip) takes both tapes of a call in one go -- `invalid` must point at four zeroed words
+bool utf8_one_pass();
+void launch_utf8_decode_pair(Scope *scope, const Utf8Args &a, const Utf8Args *b, uint64_t first_word, bool opened);
+void utf8_status_open(Scope *scope, uint64_t words);
 
 #define SWH_HIP_CHECK_DECLARED 1
 #define SWH_HIP_CHECK(expr)                                                                          \

@@ -1152,23 +1152,61 @@ __global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, ui
 // The same staging in ONE pass over the tape (what launch_utf8_decode runs unless STRINGWARS_AMD_UTF8_SCAN=split): count,
 // prefix and decode per tile in one kernel, the tile's code-point index found by a decoupled look-back over the tiles before it
 // instead of a count kernel + a scan kernel (one read of the tape less, two launches less per tape).
-//   status[tile] = flag << 62 | count: flag 1 -- the tile's own code points (published as soon as they are counted),
-//                                      flag 2 -- all code points up to and including the tile (published after the look-back).
+//   status[tile] = epoch | flag | count: flag 1 -- the tile's own code points (published as soon as they are counted),
+//                                        flag 2 -- all code points up to and including the tile (published after the look-back).
 // Tiles are handed out by a ticket, so every tile before mine belongs to a workgroup that is already running (or done) and
 // publishes its flag-1 word without waiting for anybody: the look-back cannot deadlock. Wave 0 looks back 64 tiles at a time.
 // tile_prefix[] / sub_prefix[] are still written: k_utf8_string_offsets reads them.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned long long kStatusCount = (1ull << 62) - 1;
+// A status word: call epoch << 48 | flag << 46 | count. The words live in a buffer of the scope's own that only this kernel
+// writes (launch_utf8_decode_pair), so a word of another epoch is simply "not there yet" and nothing has to be zeroed per call.
+constexpr unsigned long long kStatusCount = (1ull << 46) - 1;
+__device__ __forceinline__ unsigned long long status_word(uint32_t epoch, uint32_t flag, unsigned long long count) {
+    return ((unsigned long long)epoch << 48) | ((unsigned long long)flag << 46) | count;
+}
+__device__ __forceinline__ uint32_t status_flag(unsigned long long word, uint32_t epoch) {
+    return (uint32_t)(word >> 48) == epoch ? (uint32_t)(word >> 46) & 3u : 0u;
+}
 
-__global__ __launch_bounds__(256) void k_utf8_tile_decode(const uint8_t *data, uint64_t total, uint64_t tiles, unsigned long long *status,
-                                                          uint32_t *ticket, uint64_t *tile_prefix, uint32_t *sub_prefix,
-                                                          uint32_t *symbols, uint32_t *invalid, int *balance) {
+// One tape of a staging launch (both tapes of a call are staged by ONE launch: tickets [0, a.tiles) are tape a's tiles).
+struct Utf8TileJob {
+    const uint8_t *data; uint64_t total, tiles;
+    unsigned long long *status; uint64_t *tile_prefix; uint32_t *sub_prefix; uint32_t *symbols; int *balance;
+};
+
+__global__ __launch_bounds__(256) void k_utf8_tile_decode(Utf8TileJob job_a, Utf8TileJob job_b, uint32_t *ticket, uint32_t *invalid, uint32_t epoch) {
     __shared__ Utf8WriteLds lds;
     __shared__ unsigned long long tile_base;
     __shared__ uint32_t my_tile;
+    // One workgroup per tile. (Workgroups that loop over the ticket -- a grid of what the device holds at once -- take the same
+    // time for one launch, and make two launches on two streams take turns instead of sharing the device: 0.40 ms for 2 x 100 MB
+    // against 0.28. A note for whoever tries again: written as `for (;;) { draw; barrier; if (drawn >= tiles) break; ... }` on
+    // the LDS word itself, hipcc wrapped the loop's barriers in per-wave exec-mask bookkeeping and the kernel hung on its first
+    // tile; with the drawn ticket passed through readfirstlane and tested in the loop's `while` it ran.)
+#ifdef SWH_UTF8_NO_TICKET
+    // Diagnostic build only (make EXTRA=-DSWH_UTF8_NO_TICKET): tiles in blockIdx order. What the tickets cost: a 103 MB tape (12.5 K
+    // tiles) is staged in 0.134 ms instead of 0.179 -- 3.6 ns per atomic on one address. Safe only if workgroups start in
+    // blockIdx order; nothing promises that. (Drawing one ticket per group of four tiles would get most of it back: not built.)
+    const uint32_t drawn = blockIdx.x;
+#else
     if (threadIdx.x == 0) my_tile = atomicAdd(ticket, 1u);
     __syncthreads();
-    const uint64_t tile = my_tile;
+    const uint32_t drawn = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_tile);
+#endif
+    {
+    // tickets alternate between the two tapes while both have tiles left (two windows of the address space in flight, as when
+    // each tape had a launch and a stream of its own), the longer tape's remaining tiles follow
+    const uint64_t paired = 2 * (job_a.tiles < job_b.tiles ? job_a.tiles : job_b.tiles);
+    const bool second = drawn < paired ? (drawn & 1u) != 0 : job_b.tiles > job_a.tiles;
+    const uint64_t tile_in_tape = drawn < paired ? drawn >> 1 : drawn - paired / 2;
+    const uint8_t *data = second ? job_b.data : job_a.data;
+    const uint64_t total = second ? job_b.total : job_a.total, tiles = second ? job_b.tiles : job_a.tiles;
+    unsigned long long *status = second ? job_b.status : job_a.status;
+    uint64_t *tile_prefix = second ? job_b.tile_prefix : job_a.tile_prefix;
+    uint32_t *sub_prefix = second ? job_b.sub_prefix : job_a.sub_prefix;
+    uint32_t *symbols = second ? job_b.symbols : job_a.symbols;
+    int *balance = second ? job_b.balance : job_a.balance;
+    const uint64_t tile = tile_in_tape;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tot = (int64_t)total;
     // interior tiles: every word this block touches (its own and the one after its last) lies inside the tape; the others
@@ -1217,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(const uint8_t *data, u
             uint32_t sum = 0;
             for (int qq = 0; qq < kUtf8Passes; ++qq)
                 for (int w = 0; w < 4; ++w) sum += lds.wave_tot[qq][w];
-            __hip_atomic_store(status + tile, (tile == 0 ? 2ull << 62 : 1ull << 62) | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(status + tile, status_word(epoch, tile == 0 ? 2u : 1u, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // (writing every byte slot unconditionally -- lead bytes at their rank, the others into a dump word -- instead of a
         // store under a condition per slot: fewer SALU instructions, the same time)
@@ -1237,11 +1275,11 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(const uint8_t *data, u
         unsigned long long exclusive = 0;
         for (int64_t first = (int64_t)tile - 1; first >= 0; first -= 64) {
             const int64_t at = first - lane;
-            unsigned long long word = 2ull << 62;   // before the tape: "everything up to here" = 0
+            unsigned long long word = status_word(epoch, 2u, 0);   // before the tape: "everything up to here" = 0
             if (at >= 0) {
-                while (((word = __hip_atomic_load(status + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+                while (status_flag(word = __hip_atomic_load(status + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), epoch) == 0) __builtin_amdgcn_s_sleep(1);
             }
-            const unsigned long long closed = __ballot((word >> 62) == 2);
+            const unsigned long long closed = __ballot(status_flag(word, epoch) == 2u);
             const int stop = closed ? __builtin_ctzll(closed) : 64;   // the nearest tile that knows its inclusive prefix
             unsigned long long part = lane <= stop ? (word & kStatusCount) : 0ull;
 #pragma unroll
@@ -1250,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(const uint8_t *data, u
             if (closed) break;
         }
         if (lane == 0) {
-            if (tile) __hip_atomic_store(status + tile, (2ull << 62) | (exclusive + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile) __hip_atomic_store(status + tile, status_word(epoch, 2u, exclusive + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tile_base = exclusive;
             tile_prefix[tile] = exclusive;
             if (tile + 1 == tiles) tile_prefix[tiles] = exclusive + tile_total;
@@ -1281,6 +1319,7 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(const uint8_t *data, u
     if (bad) atomicCAS(invalid, 0u, (uint32_t)((tile * kUtf8Tile + bad_at) >> 2) + 1u);
     __syncthreads();
     if (threadIdx.x == 0) balance[tile] = lds.wave_bal[0] + lds.wave_bal[1] + lds.wave_bal[2] + lds.wave_bal[3];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_utf8_balance(const int *tile_balance, uint64_t tiles, int *balance) {
@@ -1296,12 +1335,9 @@ __global__ __launch_bounds__(256) void k_utf8_balance(const int *tile_balance, u
     if (threadIdx.x == 0 && red[0] != 0) atomicAdd(balance, red[0]);
 }
 
+// Code-point offset of string i of a tape (i == count: the tape's end) and the check that it starts on a sequence boundary.
 template <typename Off>
-__global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, const uint64_t *tile_prefix,
-                                                             const uint32_t *sub_prefix, const int *balance) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && *balance != 0) atomicCAS(args.invalid, 0u, 0x7FFFFFFFu);  // stray continuation bytes somewhere
-    if (i > args.in.count) return;
+__device__ __forceinline__ void utf8_string_offset(const Utf8Args &args, const uint64_t *tile_prefix, const uint32_t *sub_prefix, uint64_t i) {
     const Off *offs = (const Off *)args.in.offsets;
     const uint8_t *data = (const uint8_t *)args.in.data;
     const int64_t total = (int64_t)args.total_bytes;
@@ -1328,6 +1364,49 @@ __global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, cons
     // a non-empty string must start on a sequence boundary
     if (i < args.in.count && (int64_t)offs[i + 1] > off && (data[off] & 0xC0u) == 0x80u)
         atomicCAS(args.invalid, 0u, (uint32_t)i + 1u);
+}
+
+template <typename Off>
+__global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, const uint64_t *tile_prefix,
+                                                             const uint32_t *sub_prefix, const int *balance) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && *balance != 0) atomicCAS(args.invalid, 0u, 0x7FFFFFFFu);  // stray continuation bytes somewhere
+    if (i > args.in.count) return;
+    utf8_string_offset<Off>(args, tile_prefix, sub_prefix, i);
+}
+
+// The one-pass staging's second (and last) launch: the string offsets of BOTH tapes (blocks [0, a.blocks) are tape a's), and
+// in the first block of each tape's range the balance of its tiles (k_utf8_balance's sum: stray continuation bytes somewhere).
+struct Utf8FinishJob {
+    Utf8Args args;
+    const uint64_t *tile_prefix; const uint32_t *sub_prefix; const int *tile_balance;
+    uint64_t tiles; uint32_t blocks;
+};
+template <typename Off>
+__global__ __launch_bounds__(256) void k_utf8_finish(Utf8FinishJob job_a, Utf8FinishJob job_b) {
+    __shared__ int red[256];
+    const bool second = blockIdx.x >= job_a.blocks;   // (workgroup-uniform: the selections below stay in scalar registers)
+    const Utf8Args args = second ? job_b.args : job_a.args;
+    const uint64_t *tile_prefix = second ? job_b.tile_prefix : job_a.tile_prefix;
+    const uint32_t *sub_prefix = second ? job_b.sub_prefix : job_a.sub_prefix;
+    const int *tile_balance = second ? job_b.tile_balance : job_a.tile_balance;
+    const uint64_t tiles = second ? job_b.tiles : job_a.tiles;
+    const uint32_t block = second ? blockIdx.x - job_a.blocks : blockIdx.x;
+    if (block == 0) {
+        int sum = 0;
+        for (uint64_t t = threadIdx.x; t < tiles; t += 256) sum += tile_balance[t];
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && red[0] != 0) atomicCAS(args.invalid, 0u, 0x7FFFFFFFu);
+    }
+    const uint64_t i = (uint64_t)block * 256 + threadIdx.x;
+    if (i > args.in.count) return;
+    if (tiles == 0) { args.offsets[i] = 0; return; }   // an empty tape: every string is empty
+    utf8_string_offset<Off>(args, tile_prefix, sub_prefix, i);
 }
 
 // Exclusive scan of u32 counts into u64 offsets (count+1 entries). Three small kernels.
@@ -1417,7 +1496,78 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_one(const uint32_t *counts,
     }
 }
 
+// STRINGWARS_AMD_UTF8_SCAN=split forces the count / scan / write kernels with the three-kernel scan, =scan the same with
+// the one-launch scan (what round 2 ran; tests and comparisons use them). 0: the one-pass staging.
+static int utf8_scan_mode() {
+    static const int mode = [] {
+        const char *e = getenv("STRINGWARS_AMD_UTF8_SCAN");
+        return !e ? 0 : (!strcmp(e, "split") ? 2 : (!strcmp(e, "scan") ? 1 : 0));
+    }();
+    return mode;
+}
+bool utf8_one_pass() { return utf8_scan_mode() == 0; }
+
+// One-pass staging of one or two tapes (`b` may be null) in TWO launches: k_utf8_tile_decode over the tiles of both, then
+// k_utf8_finish over the strings of both. `a.invalid` (= `b->invalid`) points at four zeroed words: [0] the invalid-UTF-8 marker,
+// [32 (1 + a.slot)] the tile ticket (kUtf8FlagWords zeroed words in all). Large tapes are staged one launch pair per tape on two streams (api.hip: measured faster than
+// one launch over both, whatever the order of the tiles); the caller opens the epoch once (utf8_status_open) and the second launch passes the first's tile count as `first_word`. The look-back words live in a buffer of the scope that nothing else writes, tagged with a per-call
+// epoch: no clearing between calls (only when the 16-bit epoch wraps, or the buffer grows).
+// Room for `words` look-back words (what a call's tapes have tiles); growing the buffer waits for the device, so a call that
+// stages its tapes with two launches on two streams reserves for both before the first.
+static void utf8_status_reserve(Scope *scope, uint64_t words) {
+    if (words <= scope->utf8_status_cap) return;
+    if (scope->utf8_status) SWH_HIP_CHECK(hipFree(scope->utf8_status));   // (hipFree waits for the device)
+    scope->utf8_status = nullptr; scope->utf8_status_cap = 0;
+    const uint64_t want = words + words / 4 + 1024;
+    SWH_HIP_CHECK(hipMalloc((void **)&scope->utf8_status, want * sizeof(unsigned long long)));
+    scope->utf8_status_cap = want;
+    scope->utf8_epoch = 0xFFFFu;   // cleared by the next launch
+}
+
+// Opens a call's epoch of look-back words on scope->stream (room for `words`; every 65 535 calls, and after the buffer grew, the
+// words are cleared). A call that stages its tapes on two streams opens BEFORE it forks: the clearing must not race the fork.
+void utf8_status_open(Scope *scope, uint64_t words) {
+    utf8_status_reserve(scope, words);
+    if (++scope->utf8_epoch > 0xFFFFu) {
+        SWH_HIP_CHECK(hipMemsetAsync(scope->utf8_status, 0, scope->utf8_status_cap * sizeof(unsigned long long), scope->stream));
+        scope->utf8_epoch = 1;
+    }
+}
+
+void launch_utf8_decode_pair(Scope *scope, const Utf8Args &a, const Utf8Args *b, uint64_t first_word, bool opened) {
+    hipStream_t stream = scope->stream;
+    auto carve = [](const Utf8Args &args, Utf8TileJob &tj, Utf8FinishJob &fj) {
+        const uint64_t total = args.total_bytes, tiles = (total + kUtf8Tile - 1) / kUtf8Tile;
+        uint32_t *tile_counts = args.counts;   // (the carving of launch_utf8_decode: the count / scan kernels' areas stay unused)
+        uint32_t *sub_prefix = tile_counts + ((tiles + 2) & ~1ull);
+        uint64_t *tile_prefix = (uint64_t *)(sub_prefix + kUtf8Subs * tiles + 2 - ((kUtf8Subs * tiles) & 1));
+        unsigned long long *block_sums = (unsigned long long *)(tile_prefix + tiles + 2);
+        int *tile_balance = (int *)(block_sums + (tiles + 1023) / 1024 + 4);
+        tj = Utf8TileJob{(const uint8_t *)args.in.data, total, tiles, nullptr, tile_prefix, sub_prefix, args.symbols, tile_balance};
+        fj = Utf8FinishJob{args, tile_prefix, sub_prefix, tile_balance, tiles, (uint32_t)((args.in.count + 1 + 255) / 256)};
+    };
+    Utf8TileJob ta{}, tb{};
+    Utf8FinishJob fa{}, fb{};
+    carve(a, ta, fa);
+    if (b) carve(*b, tb, fb);
+    const uint64_t words = ta.tiles + tb.tiles;
+    if (!opened) utf8_status_open(scope, first_word + words);   // (`opened`: the caller did, for both of its launches)
+    ta.status = scope->utf8_status + first_word;
+    tb.status = ta.status + ta.tiles;
+    if (words) {
+        StampGuard guard(scope, "utf8_tile_decode");
+        hipLaunchKernelGGL(k_utf8_tile_decode, dim3((uint32_t)words), dim3(256), 0, stream, ta, tb, a.invalid + 32 * (1 + a.slot), a.invalid, scope->utf8_epoch);
+    }
+    {
+        StampGuard guard(scope, "utf8_offsets");
+        if (a.off64) hipLaunchKernelGGL(k_utf8_finish<uint64_t>, dim3(fa.blocks + fb.blocks), dim3(256), 0, stream, fa, fb);
+        else hipLaunchKernelGGL(k_utf8_finish<uint32_t>, dim3(fa.blocks + fb.blocks), dim3(256), 0, stream, fa, fb);
+    }
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
 void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
+    if (utf8_one_pass()) { launch_utf8_decode_pair(scope, args, nullptr, 0, false); return; }
     hipStream_t stream = scope->stream;
     const uint64_t n = args.in.count, total = args.total_bytes;
     const uint64_t tiles = (total + kUtf8Tile - 1) / kUtf8Tile;
@@ -1427,20 +1577,7 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
     uint64_t *tile_prefix = (uint64_t *)(sub_prefix + kUtf8Subs * tiles + 2 - ((kUtf8Subs * tiles) & 1));
     unsigned long long *block_sums = (unsigned long long *)(tile_prefix + tiles + 2);
     int *tile_balance = (int *)(block_sums + (tiles + 1023) / 1024 + 4);
-    unsigned long long *status = (unsigned long long *)(tile_balance + ((tiles + 4) & ~1ull));   // + the ticket behind its `tiles` words
-    // STRINGWARS_AMD_UTF8_SCAN=split forces the count / scan / write kernels with the three-kernel scan, =scan the same with
-    // the one-launch scan (what round 2 ran; tests and comparisons use them)
-    static const int scan_mode = [] {
-        const char *e = getenv("STRINGWARS_AMD_UTF8_SCAN");
-        return !e ? 0 : (!strcmp(e, "split") ? 2 : (!strcmp(e, "scan") ? 1 : 0));
-    }();
-    if (tiles && scan_mode == 0) {
-        SWH_HIP_CHECK(hipMemsetAsync(status, 0, (tiles + 1) * sizeof(unsigned long long), stream));
-        StampGuard guard(scope, "utf8_tile_decode");
-        hipLaunchKernelGGL(k_utf8_tile_decode, dim3((uint32_t)tiles), dim3(256), 0, stream, (const uint8_t *)args.in.data, total, tiles, status,
-                           (uint32_t *)(status + tiles), tile_prefix, sub_prefix, args.symbols, args.invalid, tile_balance);
-        hipLaunchKernelGGL(k_utf8_balance, dim3(64), dim3(256), 0, stream, tile_balance, tiles, (int *)(args.invalid + 1 + args.slot));
-    } else if (tiles) {
+    if (tiles) {
         {
             StampGuard guard(scope, "utf8_tile_count");
             hipLaunchKernelGGL(k_utf8_tile_count, dim3((uint32_t)tiles), dim3(256), 0, stream, (const uint8_t *)args.in.data,
@@ -1449,7 +1586,7 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
         uint32_t nblocks = (uint32_t)((tiles + kScanBlock - 1) / kScanBlock);
         {
             StampGuard guard(scope, "utf8_scan");
-            const bool split_scan = scan_mode == 2;   // (also what tapes beyond 0.5 GB take on this path)
+            const bool split_scan = utf8_scan_mode() == 2;   // (also what tapes beyond 0.5 GB take on this path)
             if (tiles <= kScanOneMax && !split_scan) {
                 hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(kScanBlock), 0, stream, tile_counts, tiles, tile_prefix);
             } else {

@@ -574,6 +574,29 @@ def test_gotoh_narrow_strips_follow_the_scores(sw, orc, scope):
     want = orc.nw_pairs(a, b, full, -11, -1)
     assert (got == want).all(), np.nonzero(got != want)[0][:8]
     assert (engine.pairs(b, a, scope) == want).all()
+    # at the edge of what the strips may hold: max |cost| + |open| + |extend| = 29, times the 1024 cells a wave spans = 29 696 of the
+    # 30 000 allowed; strings made of long runs, so that one half of a wave's columns climbs 17 a cell while the other half falls
+    steep = costs.copy()
+    steep[:21, :21] = -17
+    steep[np.arange(21), np.arange(21)] = 17
+    run_a, run_b = [], []
+    for n in (900, 1600, 3100, 4700):
+        for period in (64, 300, 768, n // 2):
+            x = bytes((np.arange(n) // period % 2).astype(np.uint8))                 # 000..111..000..
+            y = bytes(((np.arange(n + 11) // (period + 5)) % 3 == 0).astype(np.uint8))
+            run_a += [x, x, bytes(n), x[: n // 2] + bytes([2]) * (n // 2)]
+            run_b += [y, x[::-1], bytes([1]) * n, x]
+    ra, rb = sw.Strs(run_a), sw.Strs(run_b)
+    engine = sw.NeedlemanWunschScores(byte_to_class, steep, open=-11, extend=-1, capabilities=scope)
+    got = engine.pairs(ra, rb, scope)
+    assert "narrow" in scope.last_timing()["dominant_name"], scope.last_timing()
+    want = orc.nw_pairs(ra, rb, steep[byte_to_class][:, byte_to_class].astype(np.int8), -11, -1)
+    assert (got == want).all(), np.nonzero(got != want)[0][:8]
+    steep[0, 0] = 18                                                                   # one more: 30 x 1024 > 30 000
+    engine = sw.NeedlemanWunschScores(byte_to_class, steep, open=-11, extend=-1, capabilities=scope)
+    got = engine.pairs(ra, rb, scope)
+    assert "narrow" not in scope.last_timing()["dominant_name"], scope.last_timing()
+    assert (got == orc.nw_pairs(ra, rb, steep[byte_to_class][:, byte_to_class].astype(np.int8), -11, -1)).all()
     wide = costs.copy()
     wide[:21, :21] = -60
     wide[np.arange(21), np.arange(21)] = 60

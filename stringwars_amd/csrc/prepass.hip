@@ -1521,7 +1521,14 @@ static void utf8_status_reserve(Scope *scope, uint64_t words) {
     const uint64_t want = words + words / 4 + 1024;
     SWH_HIP_CHECK(hipMalloc((void **)&scope->utf8_status, want * sizeof(unsigned long long)));
     scope->utf8_status_cap = want;
-    scope->utf8_epoch = 0xFFFFu;   // cleared by the next launch
+    SWH_HIP_CHECK(hipMemsetAsync(scope->utf8_status, 0, want * sizeof(unsigned long long), scope->stream));
+    // test hook STRINGWARS_AMD_UTF8_EPOCH=n: the first epoch of a fresh buffer (default 1), to reach the wrap-around in a few calls
+    static const uint32_t first_epoch = [] {
+        const char *e = getenv("STRINGWARS_AMD_UTF8_EPOCH");
+        const long v = e ? atol(e) : 1;
+        return (uint32_t)(v >= 1 && v <= 0xFFFF ? v : 1);
+    }();
+    scope->utf8_epoch = first_epoch - 1;
 }
 
 // Opens a call's epoch of look-back words on scope->stream (room for `words`; every 65 535 calls, and after the buffer grew, the

@@ -1367,6 +1367,30 @@ def test_utf8_validation_fuzz(sw, orc, scope):
     assert rejected > 200 and accepted > 200, (rejected, accepted)
 
 
+def test_utf8_look_back_epoch_wraps(orc):
+    """The one-pass staging tags its look-back words with a 16-bit call epoch instead of clearing them; every 65 535 calls the
+    words ARE cleared and the epoch starts over. STRINGWARS_AMD_UTF8_EPOCH (a test hook, read once per process) starts a fresh
+    buffer near the end: calls across the wrap, small tapes (one launch pair for both) and large ones (a stream per tape),
+    growing and shrinking so that words of older epochs sit where the newer calls look."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, stringwars_amd as sw, oracle\n"
+        "scope = sw.DeviceScope(gpu_device=0)\n"
+        "engine = sw.LevenshteinDistancesUTF8(capabilities=scope)\n"
+        "big = sw.generate_pairs('utf8_lines', 9000, seed=5)       # ~9 MB a tape: a stream per tape\n"
+        "small = sw.generate_pairs('utf8_lines', 300, seed=6)\n"
+        "tiny = (sw.Strs(['h\u00e9llo', '\u4e2d\u6587', 'abc']), sw.Strs(['hello', '\u4e2d', 'abd']))\n"
+        "want = {id(t): oracle.levenshtein_pairs(t[0], t[1], utf8=True, bound=40) for t in (big, small, tiny)}\n"
+        "for round in range(12):\n"
+        "    for t in (small, tiny, big, tiny, small):\n"
+        "        assert (engine.pairs(t[0], t[1], scope, bound=40) == want[id(t)]).all(), round\n"
+        "print('epochs ok')\n")
+    env = dict(os.environ, STRINGWARS_AMD_UTF8_EPOCH="65520", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0 and "epochs ok" in done.stdout, done.stderr[-2000:]
+
+
 @pytest.mark.parametrize("mode", ["split", "scan"])
 def test_utf8_three_kernel_scan_path(orc, mode):
     """The decoder before the one-pass kernel (count, scan, write): STRINGWARS_AMD_UTF8_SCAN=scan runs it with the one-launch

@@ -1,3 +1,4 @@
+"""Prints config, GCUPS per call, GCUPS over the kernels, dominant kernel, kernel ms and the parity flag of `bench.py --only-config` lines read from stdin."""
 import sys, json
 for line in sys.stdin:
     line=line.strip()

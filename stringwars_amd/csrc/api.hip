@@ -167,7 +167,11 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
 }
 
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
-constexpr uint64_t kUtf8MergedBytes = 8ull << 20;   // both tapes of a call up to this size are staged by one launch pair
+// both tapes of a call up to this size (together) are staged by one launch pair; STRINGWARS_AMD_UTF8_MERGED_MB=n moves it
+static uint64_t utf8_merged_bytes() {
+    static const uint64_t bytes = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_MERGED_MB"); return (uint64_t)(e ? atol(e) : 48) << 20; }();
+    return bytes;
+}
 static size_t utf8_scratch_words(uint64_t bytes) {
     // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances | u64 look-back words + ticket
     uint64_t tiles = (bytes + kUtf8Tile - 1) / kUtf8Tile;
@@ -453,10 +457,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             if (same_tape) {
                 decode(ta, a_bytes, da, 0, false);
                 db = da;
-            } else if (utf8_one_pass() && a_bytes + b_bytes <= kUtf8MergedBytes) {
+            } else if (utf8_one_pass() && a_bytes + b_bytes <= utf8_merged_bytes()) {
                 // both tapes in the same two launches (tile decode, then string offsets + balance): what a small call costs is
-                // its launches (10 K word pairs: 135 -> 117 us per call). Large tapes keep a launch pair and a stream each
-                // below: 2 x 100 MB are staged in 0.28 ms that way, in 0.33 by one launch over both.
+                // its launches (10 K word pairs: 135 -> 107 us per call). Large tapes keep a launch pair and a stream each
+                // below: 2 x 100 MB are staged in 0.27 ms that way, in 0.33 by one launch over both. In between
+                // (tools/mid_utf8.py): 16 MB of tapes 280 -> 267 us per call merged, 31 MB 323 -> 311, 63 MB the same.
                 auto prepare = [&](const TapeRef &in, uint64_t bytes, Utf8Args &u) {
                     u.slot = decode_slot++;
                     u.in = in; u.off64 = off64; u.total_bytes = bytes;

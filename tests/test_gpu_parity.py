@@ -1386,7 +1386,9 @@ def test_utf8_look_back_epoch_wraps(orc):
         "    for t in (small, tiny, big, tiny, small):\n"
         "        assert (engine.pairs(t[0], t[1], scope, bound=40) == want[id(t)]).all(), round\n"
         "print('epochs ok')\n")
-    env = dict(os.environ, STRINGWARS_AMD_UTF8_EPOCH="65520", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    # (tapes of more than 4 MB together take the stream-per-tape path here; the default is 48 MB)
+    env = dict(os.environ, STRINGWARS_AMD_UTF8_EPOCH="65520", STRINGWARS_AMD_UTF8_MERGED_MB="4",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0 and "epochs ok" in done.stdout, done.stderr[-2000:]
 

@@ -166,12 +166,12 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
     cap = want;
 }
 
-// u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
 // both tapes of a call up to this size (together) are staged by one launch pair; STRINGWARS_AMD_UTF8_MERGED_MB=n moves it
 static uint64_t utf8_merged_bytes() {
     static const uint64_t bytes = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_MERGED_MB"); return (uint64_t)(e ? atol(e) : 48) << 20; }();
     return bytes;
 }
+// u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
 static size_t utf8_scratch_words(uint64_t bytes) {
     // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances | u64 look-back words + ticket
     uint64_t tiles = (bytes + kUtf8Tile - 1) / kUtf8Tile;

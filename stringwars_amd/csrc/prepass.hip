@@ -1186,7 +1186,9 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(Utf8TileJob job_a, Utf
 #ifdef SWH_UTF8_NO_TICKET
     // Diagnostic build only (make EXTRA=-DSWH_UTF8_NO_TICKET): tiles in blockIdx order. What the tickets cost: a 103 MB tape (12.5 K
     // tiles) is staged in 0.134 ms instead of 0.179 -- 3.6 ns per atomic on one address. Safe only if workgroups start in
-    // blockIdx order; nothing promises that. (Drawing one ticket per group of four tiles would get most of it back: not built.)
+    // blockIdx order; nothing promises that. (One ticket and one look-back per group of four tiles, the group's code points counted
+    // up front and its tiles decoded one after the other by the workgroup, was built: 0.216 ms -- the tiles' words are read twice,
+    // the kernel needs 92 registers and a workgroup lives four times as long. Taken out again.)
     const uint32_t drawn = blockIdx.x;
 #else
     if (threadIdx.x == 0) my_tile = atomicAdd(ticket, 1u);

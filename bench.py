@@ -35,6 +35,15 @@ the checks, the other configs, the CPU rows.
     python bench.py                       # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N              # the same N ranks: without WORLD_SIZE in the environment the script starts
+                                          # torch.distributed.run itself, as a child, before anything touches a GPU
+    python bench.py --gpus N --single-process   # one process, one scope over N devices: swh_scope_init_gpus +
+                                          # swh_levenshtein_pairs_sharded, the RCCL gather INSIDE the library
+
+At N > 1 the line's `value` is still config C2 (weak: N x 1 M pairs); `configs` then holds BASELINE configs[4] -- C5, the
+100 M short-word pairs split over the ranks (strong scaling), with `gather_ok`, the gather's cost per step and the ranks
+and devices that took part -- and `single_process` the in-library sharded call over the same N devices, run by rank 0 as
+a child process once the ranks are done. A world size that differs from --gpus is an error, never a smaller measurement.
     python bench.py --only-config c4_linear --calls 3     # exactly 3 engine calls of one config (PMC passes)
 """
 import argparse
@@ -119,6 +128,13 @@ def parse_args():
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo + --share-gpu exercises the multi-rank control flow on a one-GPU box (testing only)")
     p.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (testing only; never a result)")
+    p.add_argument("--single-process", action="store_true",
+                   help="one process, one scope over --gpus devices: swh_scope_init_gpus + swh_levenshtein_pairs_sharded (the RCCL gather inside the library)")
+    p.add_argument("--no-single-process", action="store_true", help="at N > 1: leave the single-process leg (a child of rank 0) out of the line")
+    p.add_argument("--single-process-timeout", type=float, default=300.0)
+    p.add_argument("--gather-transport", default="auto", choices=["auto", "u32", "u8"],
+                   help="strong configs: what travels to rank 0 -- the u32 distances as they are, or bytes when no distance can exceed 255 (auto)")
+    p.add_argument("--c5-pairs", type=int, default=0, help="at N > 1: total pairs of the C5 strong-scaling entry (default 100 M; testing)")
     return p.parse_args()
 
 
@@ -213,7 +229,9 @@ def cpu_rows(a, b, budget_s=6.0):
     one = min(pairs, 1_000_000)
     timed("cpu::hyyro<1cpu>", 1, lambda n: oracle.levenshtein_pairs(a, b, algo="hyyro", count=n), one,
           "oracle Hyyro/Myers 64-bit bit-parallel (the algorithm family of rapidfuzz), one pair per call")
-    cores = min(os.cpu_count() or 1, 64)
+    # "the host cores" of the north-star: every hardware thread the box has (not a cap), the physical core count stated
+    cores = os.cpu_count() or 1
+    physical = physical_cores()
     if cores > 1:
         pool = ThreadPoolExecutor(cores)
 
@@ -222,13 +240,30 @@ def cpu_rows(a, b, budget_s=6.0):
             jobs = [pool.submit(oracle.levenshtein_pairs, a, b, False, "hyyro", None, bounds[t], bounds[t + 1] - bounds[t]) for t in range(cores)]
             for job in jobs:
                 job.result()
-        timed(f"cpu::hyyro<{cores}cpu>", cores, sharded, one, f"the same over {cores} host threads (contiguous slices)")
+        timed(f"cpu::hyyro<{cores}cpu>", cores, sharded, one,
+              f"the same over {cores} host threads = every hardware thread of the box ({physical} physical cores), contiguous slices")
         pool.shutdown()
     timed("cpu::wagner_fischer<1cpu>", 1, lambda n: oracle.levenshtein_pairs(a, b, algo="wf", count=n), min(pairs, 100_000),
           "oracle two-row Wagner-Fischer (the algorithm of bio::levenshtein)")
+    # BASELINE configs[0] as it is worded: the per-pair CPU call on 10 K ASCII word pairs <= 16 B, one thread, in the harness
+    # loop (rapidfuzz::levenshtein::distance per pair inside measure_throughput, bench.rs:404-423, utils.rs:721-799): the
+    # oracle's bit-parallel routine called pair by pair over the `words16` tapes -- the plumbing row, no GPU
+    import stringwars_amd as sw
+    wa, wb = sw.generate_pairs("words16", 10_000, seed=42)
+    word_cells = int((wa.lengths.astype(np.int64) * wb.lengths.astype(np.int64)).sum())
+    repeats, start = 0, time.perf_counter()
+    while True:
+        oracle.levenshtein_pairs(wa, wb, algo="hyyro")
+        repeats += 1
+        spent = time.perf_counter() - start
+        if spent >= budget_s / 3:
+            break
+    rows.append({"name": "c1/cpu::hyyro<1cpu>", "value": round(word_cells * repeats / spent / 1e9, 3), "unit": "GCUPS", "cores": 1, "kind": "port",
+                 "config": "C1: 10 K ASCII word pairs <= 16 B (words16), one thread, one pair per call",
+                 "pairs_per_second": round(10_000 * repeats / spent, 1),
+                 "sample": f"all 10000 pairs x {repeats} repeats, oracle Hyyro/Myers bit-parallel called per pair (the shape of the rapidfuzz row, bench.rs:404-423)"})
     # cpu::gotoh<1cpu> (~ bio::pairwise::Aligner::global, bench.rs:746-765) has no pairs of this workload to run on: it is
     # timed on config C4's shape (4 KB amino-acid sequences, 256x256 i8 matrix, affine gaps), cells of that sample
-    import stringwars_amd as sw
     pa, pb = sw.generate_pairs("protein4k", 4, seed=42)
     matrix = sw.substitution_matrix(42)
     gotoh_cells = int((pa.lengths * pb.lengths).sum())
@@ -243,6 +278,20 @@ def cpu_rows(a, b, budget_s=6.0):
                  "sample": f"4 pairs of config C4 (protein4k, affine -11/-1) x {repeats} repeats, oracle Gotoh score-only DP "
                            "(bio::pairwise also keeps traceback matrices)"})
     return rows
+
+
+def physical_cores():
+    """Distinct (socket, core) pairs of /proc/cpuinfo; falls back to the logical count."""
+    seen, socket = set(), 0
+    try:
+        for row in open("/proc/cpuinfo"):
+            if row.startswith("physical id"):
+                socket = int(row.split(":")[1])
+            elif row.startswith("core id"):
+                seen.add((socket, int(row.split(":")[1])))
+    except (OSError, ValueError):
+        pass
+    return len(seen) or (os.cpu_count() or 1)
 
 
 def codepoint_lengths(strs):
@@ -354,48 +403,134 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
     return entry
 
 
-def main():
-    args = parse_args()
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def last_json_line(text):
+    for row in reversed(text.splitlines()):
+        if row.startswith("{"):
+            try:
+                return json.loads(row)
+            except ValueError:
+                continue
+    return None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE around: start the N ranks ourselves. This process has not imported
+    torch, loaded the library or made any HIP call -- the ranks are a CHILD process (torch.distributed.run), never an exec --
+    and it leaves with the child's exit code; rank 0's JSON line goes straight to our stdout."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    done = subprocess.run(cmd, env=env)
+    raise SystemExit(done.returncode)
+
+
+def visible_devices(torch):
+    return int(torch.cuda.device_count())     # counting devices does not initialise the GPU on this image
+
+
+def run_single_process(args):
+    """One process, ONE scope over N devices (`swh_scope_init_gpus`, include/stringwars_amd.h): the batch is cut into
+    cells-balanced shards, shard r prepared on device r (`swh_sharded_prepare_*`), and every step is one
+    `swh_levenshtein_pairs_sharded` call -- all shards scored side by side, pieces sent to the first device with
+    ncclSend / ncclRecv INSIDE the library (csrc/sharded.hip), self-checked on the scope's first call. The distances land in
+    memory of the first device. C2 weak (N x 1 M pairs) by default, `--config c5` for the 100 M strong config."""
     import torch
-    import torch.distributed as dist
 
     import stringwars_amd as sw
-    from stringwars_amd import sharding
 
     cfg = CONFIGS[args.config]
     workload = args.workload or cfg["workload"]
     strong = cfg["scaling"] == "strong"
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    # a stream of our own: on the legacy default stream the library's side stream (wavefront class kernels run on two streams)
-    # would serialise with it instead of overlapping
-    torch.cuda.set_stream(torch.cuda.Stream(device))
+    n = args.gpus
+    have = visible_devices(torch)
+    if not args.share_gpu and have < n:
+        raise SystemExit(f"--gpus {n} --single-process but only {have} device(s) are visible")
+    devices = [0] * n if args.share_gpu else list(range(n))
+    per_gpu = args.pairs or cfg["pairs"]
+    total_pairs = per_gpu if strong else per_gpu * n
+    started = time.perf_counter()
+    a, b = sw.generate_pairs(workload, total_pairs, seed=args.seed)
+    cells = int((a.lengths.astype(np.int64) * b.lengths.astype(np.int64)).sum())
+    os.environ.setdefault("STRINGWARS_AMD_SHARD_CHECK", "1")   # every call checks its gather (sum + keyed xor per shard)
+    scope = sw.DeviceScope(gpu_devices=devices)
+    engine = sw.LevenshteinDistances(capabilities=scope, algorithm=args.algorithm)
+    batch = sw.ShardedPairs(scope, a, b)
+    setup_s = time.perf_counter() - started
+    torch.cuda.set_device(devices[0])
+    out = torch.zeros(total_pairs + 4, dtype=torch.int32, device=torch.device("cuda", devices[0]))
 
-    if args.only_config:
-        scope = sw.DeviceScope(gpu_device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        entry = run_leg(args.only_config, sw, scope, torch, device, args.seed, load_pmc_constants(), calls=args.calls,
-                        pairs_override=args.leg_pairs, check=not args.no_cpu_baseline, algorithm=args.algorithm)
-        print(json.dumps(entry), flush=True)
-        return
+    def step():
+        engine.pairs_sharded(batch, scope, out=out)       # synchronous: results visible on return
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
-    comm_device = device if args.backend == "nccl" else torch.device("cpu")
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
 
+    step()
+    if args.prewarm_seconds > 0:
+        until = time.perf_counter() + args.prewarm_seconds
+        while time.perf_counter() < until:
+            step()
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - start
+    shard = scope.shard_timing()
+    got = out[:total_pairs].cpu().numpy().astype(np.uint32)
+    parity = None
+    if not args.no_cpu_baseline:
+        import oracle  # the checker; never on the timed path
+        cuts = batch.cuts
+        ok = True
+        for r in range(n):                                  # the head of EVERY shard: each device's results reached their place
+            count = min(cuts[r + 1] - cuts[r], 4000)
+            want = oracle.levenshtein_pairs(a, b, algo="hyyro", first=cuts[r], count=count)
+            ok = ok and bool((want == got[cuts[r]:cuts[r] + count]).all())
+        parity = ok
+    line = {
+        "metric": "GCUPS (DP cell updates/s) batched Levenshtein", "value": round(cells * args.steps / elapsed / 1e9, 2), "unit": "GCUPS",
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "mode": "single-process",
+        "config": {"workload": cfg["text"].format(pairs=total_pairs if strong else per_gpu) + ", shards prepared and resident in HBM",
+                   "value_is": "rate of K synchronous swh_levenshtein_pairs_sharded calls on ONE scope over all devices (one process); "
+                               "the gather to the first device is part of every call",
+                   "devices": devices, "device_count": scope.device_count, "shard_cuts": batch.cuts, "pairs_total": total_pairs, "cells_total": cells,
+                   "collective": "ncclSend/ncclRecv groups inside the library (RCCL bound with dlopen), four pieces per shard" if len(set(devices)) > 1
+                                 else "members share a device: copies in RCCL's place (testing only)",
+                   "self_check": "STRINGWARS_AMD_SHARD_CHECK=" + os.environ["STRINGWARS_AMD_SHARD_CHECK"] + ": a checksum mismatch after the gather fails the call",
+                   "setup_s": round(setup_s, 2), "seed": args.seed},
+        "shard_timing_last_call": shard, "parity_vs_oracle": parity, "gather_ok": True,   # a failed self-check raises
+    }
+    print(json.dumps(line), flush=True)
+
+
+def measure(cfg_name, args, env, steps, warmup, prewarm_seconds, steady_seconds, with_pipelined, pairs_arg=None, gather_cost=False):
+    """The measurement of one bench config on this rank's GPU (+ the collective at N > 1): returns what the line needs.
+    Every rank makes the same calls in the same order (a step contains the collective)."""
+    torch, dist, sw, sharding = env["torch"], env["dist"], env["sw"], env["sharding"]
+    world, rank, device, comm_device, scope = env["world"], env["rank"], env["device"], env["comm_device"], env["scope"]
+    cfg = CONFIGS[cfg_name]
+    workload = (args.workload if cfg_name == args.config else None) or cfg["workload"]
+    strong = cfg["scaling"] == "strong"
+    chunks = args.chunks
     # ---- this rank's shard of the seeded stream -------------------------------------------------------------------
     if strong:
-        total_pairs = args.pairs or cfg["pairs"]
+        total_pairs = pairs_arg or cfg["pairs"]
         lo, hi = sharding.shard_range(total_pairs, rank, world)
         if world > 1:
             # cells-balanced cuts without any rank holding all the lengths: per-block cell sums of the count-balanced
@@ -417,7 +552,7 @@ def main():
             a, b = sw.generate_pairs(workload, total_pairs, seed=args.seed)
         pairs = hi - lo
     else:
-        pairs = args.pairs or cfg["pairs"]
+        pairs = pairs_arg or cfg["pairs"]
         total_pairs = pairs * world
         ranges = [(r * pairs, (r + 1) * pairs) for r in range(world)]
         a, b = sw.generate_pairs(workload, pairs, seed=args.seed, first=sharding.weak_shard_first(rank, pairs))
@@ -431,7 +566,6 @@ def main():
     da = sw.DeviceTape(tensors[0].data_ptr(), tensors[1].data_ptr(), a.count, offsets_dtype, keepalive=tensors[:2])
     db = sw.DeviceTape(tensors[2].data_ptr(), tensors[3].data_ptr(), b.count, offsets_dtype, keepalive=tensors[2:])
 
-    scope = sw.DeviceScope(gpu_device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     engine = sw.LevenshteinDistances(capabilities=scope, algorithm=args.algorithm)
     # prepared once, outside every timed region: resident, measured (the engine then needs no planning pre-pass)
     pa, pb = sw.PreparedTape(scope, da), sw.PreparedTape(scope, db)
@@ -443,11 +577,24 @@ def main():
     outs = [torch.zeros(max(pairs, 1), dtype=torch.int32, device=device) for _ in range(2)]
     counter = [0]
     pipelined = [False]
+    collective = [True]            # switched off for the compute-only steps that price the gather
     if strong:
-        if args.chunks <= 0:
-            args.chunks = 4 if world > 1 else 1
-        pieces = sharding.chunk_ranges(pairs, args.chunks)
+        if chunks <= 0:
+            chunks = 4 if world > 1 else 1
+        pieces = sharding.chunk_ranges(pairs, chunks)
         gathers = [None, None]
+        # The root's vector: one per slot, reused from step to step. Transport: u8 when no distance of any shard can exceed
+        # 255 (the longest strings are that short: every rank knows its own from the prepared tapes, one all-reduce agrees),
+        # a quarter of the bytes over the root's inbound xGMI links; --gather-transport u32 sends the distances as they are.
+        fulls = [torch.zeros(total_pairs, dtype=torch.int32, device=comm_device) if rank == 0 and world > 1 else None for _ in range(2)]
+        transport = None
+        if world > 1:
+            longest = torch.tensor([int(max(a.lengths.max(initial=0), b.lengths.max(initial=0)))], dtype=torch.int64, device=comm_device)
+            dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+            if args.gather_transport == "u8" and int(longest.item()) > 255:
+                raise SystemExit("--gather-transport u8 needs every string <= 255 bytes")
+            if args.gather_transport != "u32" and int(longest.item()) <= 255:
+                transport = torch.uint8
         # one pre-bound call per (buffer, piece): sub-views of the prepared tapes, the piece's slice of the result buffer
         piece_calls = [[engine.bind_pairs(pa[p_lo:p_hi], pb[p_lo:p_hi], scope, outs[slot][p_lo:p_hi]) if p_hi > p_lo else None
                         for p_lo, p_hi in pieces] for slot in range(2)]
@@ -457,7 +604,7 @@ def main():
             counter[0] += 1
             if gathers[slot] is not None:
                 gathers[slot].wait()            # this buffer's previous gather has left it
-            gather = sharding.ChunkedGather(ranges, args.chunks, torch.int32, device) if world > 1 else None
+            gather = sharding.ChunkedGather(ranges, chunks, torch.int32, device, full=fulls[slot], transport=transport) if world > 1 and collective[0] else None
             for j, (p_lo, p_hi) in enumerate(pieces):
                 if p_hi > p_lo:
                     piece_calls[slot][j]()
@@ -467,6 +614,8 @@ def main():
                     gather.send_chunk(outs[slot], j)
             gathers[slot] = gather              # (waited for when this buffer comes round again, and by the final fence)
     else:
+        pieces = [(0, pairs)]
+        transport = None
         gathered = [[torch.zeros(pairs, dtype=torch.int32, device=comm_device) for _ in range(world)] for _ in range(2)] \
             if rank == 0 and world > 1 else [None, None]
         works = [None, None]
@@ -480,7 +629,7 @@ def main():
                 works[slot].wait()
                 works[slot] = None
             calls[slot]()               # engine.pairs(pa, pb, scope, out=outs[slot]) with its arguments bound once
-            if world > 1:
+            if world > 1 and collective[0]:
                 if pipelined[0]:
                     scope.join()        # the gather is ordered on torch's stream: make that stream wait for this call
                 if args.backend == "nccl":
@@ -499,10 +648,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region(steps):
+    def timed_region(count):
         fence()
         start = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(count):
             step()
         fence()
         return time.perf_counter() - start
@@ -517,14 +666,14 @@ def main():
     # An idle MI355X takes a few hundred milliseconds of work to reach its clocks (profiles/r2: the same 20 steps measure
     # 8 % apart right after start-up and after a second of calls). The device is brought there first -- every rank runs the same
     # number of untimed steps, the collective included --, then come the W warm-up steps and the K timed ones.
-    if args.prewarm_seconds > 0:
+    if prewarm_seconds > 0:
         fence()
         start = time.perf_counter()
         for _ in range(8):                      # what a step costs here
             step()
         fence()
         per_step = (time.perf_counter() - start) / 8
-        extra = int(min(max(args.prewarm_seconds / max(per_step, 1e-6) - 8, 0), 100000))
+        extra = int(min(max(prewarm_seconds / max(per_step, 1e-6) - 8, 0), 100000))
         if world > 1:                           # the same count on every rank: a step contains the collective
             agreed = torch.tensor([extra], dtype=torch.int64, device=comm_device)
             dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
@@ -534,9 +683,9 @@ def main():
             if i % 64 == 63:
                 fence()
     # ---- `value`: K synchronous steps -----------------------------------------------------------------------------------
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    elapsed = max_over_ranks(timed_region(args.steps))
+    elapsed = max_over_ranks(timed_region(steps))
     if world > 1:
         c = torch.tensor([cells], dtype=torch.int64, device=comm_device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
@@ -563,19 +712,48 @@ def main():
                             (int(np.bitwise_xor.reduce(s)) if s.size else 0) == int(sums[r][1]) for r, s in enumerate(slices))
             gather_ok = bool(gather_ok and (slices[0] == sync_result).all())
 
+    # ---- what the gather costs a step: the same K steps with the collective switched off -------------------------------
+    gather = None
+    if world > 1 and gather_cost:
+        collective[0] = False
+        fence()
+        compute_only = max_over_ranks(timed_region(steps))
+        collective[0] = True
+        # and one step's gather by itself: results already there, every piece sent, waited for (enqueue -> complete on this rank)
+        fence()
+        start = time.perf_counter()
+        slot = counter[0] & 1
+        if strong:
+            alone = sharding.ChunkedGather(ranges, chunks, torch.int32, device, full=fulls[slot], transport=transport)
+            for j in range(len(pieces)):
+                alone.send_chunk(outs[slot], j)
+            alone.wait()
+        elif args.backend == "nccl":
+            dist.gather(outs[slot], gathered[slot], dst=0)
+        else:
+            dist.gather(outs[slot].cpu(), gathered[slot], dst=0)
+        torch.cuda.synchronize()
+        alone_s = max_over_ranks(time.perf_counter() - start)
+        gather = {"exposed_ms_per_step": round((elapsed - compute_only) / steps * 1e3, 4),
+                  "exposed_is": "ms per step of the K timed steps minus the same K steps without the collective (max over ranks both)",
+                  "alone_ms": round(alone_s * 1e3, 4), "alone_is": "one step's gather by itself, enqueue to completion, max over ranks",
+                  "transport": "u8 over the links, widened to u32 on the root" if transport is not None else "u32",
+                  "bytes_to_root_per_step": int((1 if transport is not None else 4) * (total_pairs - (ranges[0][1] - ranges[0][0]))),
+                  "compute_only_ms_per_step": round(compute_only / steps * 1e3, 4)}
+
     # ---- the same steps with the library's hipEvent pairs on (kernel durations on the kernels' own streams) ----------
     # They cost a few microseconds per call, so `value` above comes from the run without them; same calls, same conditions
     # -- what `rocprofv3 --kernel-trace --stats` of `bench.py --no-pipelined --no-configs --no-cpu-baseline` averages over.
     scope.set_profiling(True)
-    timed_region(args.steps)
+    timed_region(steps)
     totals = scope.timing_totals()
     sync_timing = scope.last_timing()
     scope.set_profiling(False)
 
     # ---- steady state: the same synchronous steps for at least --steady-seconds ---------------------------------------
     steady = None
-    if args.steady_seconds > 0:
-        steps_for = max(int(args.steady_seconds / max(elapsed / args.steps, 1e-6) * 1.05) + 1, args.steps)
+    if steady_seconds > 0:
+        steps_for = max(int(steady_seconds / max(elapsed / steps, 1e-6) * 1.05) + 1, steps)
         if world > 1:
             agreed = torch.tensor([steps_for], dtype=torch.int64, device=comm_device)
             dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
@@ -585,27 +763,116 @@ def main():
 
     # ---- pipelined: K steps enqueued asynchronously on two internal lanes (host work of step i+1 overlaps step i) ----
     pipelined_rate, pipelined_result, pipelined_ms = None, None, None
-    if not args.no_pipelined:
+    if with_pipelined:
         scope.set_async(True)
         scope.set_pipelined(True)
         pipelined[0] = True
-        for _ in range(max(args.warmup, 4)):
+        for _ in range(max(warmup, 4)):
             step()
-        pipelined_elapsed = max_over_ranks(timed_region(args.steps))
-        pipelined_ms = pipelined_elapsed / args.steps * 1e3
-        pipelined_rate = round(total_cells * args.steps / pipelined_elapsed / 1e9, 2)
+        pipelined_elapsed = max_over_ranks(timed_region(steps))
+        pipelined_ms = pipelined_elapsed / steps * 1e3
+        pipelined_rate = round(total_cells * steps / pipelined_elapsed / 1e9, 2)
         pipelined_result = outs[(counter[0] - 1) & 1][:pairs].cpu().numpy().astype(np.uint32)
         pipelined[0] = False
         scope.set_pipelined(False)
         scope.set_async(False)
+    fence()
+    return dict(cfg=cfg, workload=workload, strong=strong, a=a, b=b, pairs=pairs, total_pairs=total_pairs, cells=cells, total_cells=total_cells,
+                offsets_dtype=offsets_dtype, n_pieces=len(pieces), elapsed=elapsed, steps=steps, sync_result=sync_result, gather_ok=gather_ok,
+                gather=gather, totals=totals, sync_timing=sync_timing, steady=steady, pipelined_rate=pipelined_rate,
+                pipelined_result=pipelined_result, pipelined_ms=pipelined_ms, ranges=ranges)
+
+
+def collective_text(strong, world):
+    if world == 1:
+        return "none"
+    return ("ncclSend/ncclRecv group per piece to rank 0 (variable-size gather of u32 distances)" if strong
+            else "RCCL gather of u32 distances to rank 0")
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.single_process:
+        if world_env is not None and int(world_env) > 1:
+            raise SystemExit(f"--single-process is ONE process over {args.gpus} devices, but WORLD_SIZE={world_env}")
+        return run_single_process(args)
+    if args.gpus > 1 and world_env is None:
+        return self_launch(args)               # before torch, the library or any HIP call
+    world = int(world_env or "1")
+    if world != args.gpus:                     # never a silent measurement of fewer GPUs than asked for
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different number of GPUs")
+
+    import torch
+    import torch.distributed as dist
+
+    import stringwars_amd as sw
+    from stringwars_amd import sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not args.share_gpu and visible_devices(torch) < (local_rank + 1 if world > 1 else 1):
+        raise SystemExit(f"rank {rank}: device {local_rank} is not there ({visible_devices(torch)} visible)")
+    if args.share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    # a stream of our own: on the legacy default stream the library's side stream (wavefront class kernels run on two streams)
+    # would serialise with it instead of overlapping
+    torch.cuda.set_stream(torch.cuda.Stream(device))
+
+    if args.only_config:
+        scope = sw.DeviceScope(gpu_device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        entry = run_leg(args.only_config, sw, scope, torch, device, args.seed, load_pmc_constants(), calls=args.calls,
+                        pairs_override=args.leg_pairs, check=not args.no_cpu_baseline, algorithm=args.algorithm)
+        print(json.dumps(entry), flush=True)
+        return
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+    comm_device = device if args.backend == "nccl" else torch.device("cpu")
+    scope = sw.DeviceScope(gpu_device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    env = dict(torch=torch, dist=dist, sw=sw, sharding=sharding, world=world, rank=rank, device=device, comm_device=comm_device, scope=scope)
+
+    # ---- who is here: ranks, devices, the collective library ------------------------------------------------------------
+    ranks_seen = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(device)
+        me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "device": props.name,
+              "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": int(getattr(props, "pci_bus_id", -1))}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        version = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": args.backend, "rccl_version": version,
+                      "distinct_devices": len({(e["uuid"], e["pci_bus_id"]) for e in everyone}), "ranks": everyone}
+
+    head = measure(args.config, args, env, args.steps, args.warmup, args.prewarm_seconds, args.steady_seconds, not args.no_pipelined,
+                   pairs_arg=args.pairs, gather_cost=world > 1)
+
+    # ---- N > 1: BASELINE configs[4] beside the headline -- the 100 M short-word pairs, strong scaling -------------------
+    c5 = None
+    if world > 1 and args.config == "c2" and not args.no_configs:
+        c5_pairs = args.c5_pairs or CONFIGS["c5"]["pairs"]
+        try:
+            c5 = measure("c5", args, env, args.steps, min(args.warmup, 2), min(args.prewarm_seconds, 0.25), 0.0, False, pairs_arg=c5_pairs, gather_cost=True)
+        except Exception as error:   # must not cost the line its headline; every rank raises or none (same calls everywhere)
+            c5 = {"error": f"{type(error).__name__}: {error}"}
 
     line = None
     if rank == 0:
         constants = load_pmc_constants()
-        n_pieces = len(pieces) if strong else 1
+        cfg, strong, pairs, cells = head["cfg"], head["strong"], head["pairs"], head["cells"]
+        n_pieces = head["n_pieces"]
+        totals, sync_timing = head["totals"], head["sync_timing"]
         calls_timed = max(totals["calls"], 1)
         kernel_ms = totals["compute_ms"] / calls_timed
-        roofline = roofline_of(sync_timing["dominant_name"], kernel_ms, int(cells / n_pieces), int(sync_timing["bytes"]), workload,
+        roofline = roofline_of(sync_timing["dominant_name"], kernel_ms, int(cells / n_pieces), int(sync_timing["bytes"]), head["workload"],
                                pairs // n_pieces, constants,
                                extra={"all_kernels_ms": round(totals["total_ms"] / calls_timed, 4), "launches_timed": totals["calls"],
                                       "measured": "hipEvents inside the library over a repeat of the K timed synchronous steps (average per call)"})
@@ -615,11 +882,11 @@ def main():
         if not args.no_cpu_baseline:
             import oracle  # checker + reported baseline only; never on the timed GPU path
             check = min(pairs, 20_000)   # (rank 0's shard; the other ranks' slices are covered by `gather_ok`)
-            want = oracle.levenshtein_pairs(a, b, algo="hyyro", count=check)
-            parity = bool((want == sync_result[:check]).all() and (pipelined_result is None or (pipelined_result == sync_result).all()))
+            want = oracle.levenshtein_pairs(head["a"], head["b"], algo="hyyro", count=check)
+            parity = bool((want == head["sync_result"][:check]).all() and
+                          (head["pipelined_result"] is None or (head["pipelined_result"] == head["sync_result"]).all()))
         leg_entries = None
         if world == 1 and not args.no_configs:
-            # release the headline's device memory before the larger configs come
             leg_entries = []
             for leg_name in [n for n in args.legs.split(",") if n]:
                 try:
@@ -628,32 +895,76 @@ def main():
                 except Exception as error:   # one config failing must not cost the line its headline
                     leg_entries.append({"config": leg_name, "error": f"{type(error).__name__}: {error}"})
                 torch.cuda.empty_cache()
+        elif c5 is not None:
+            if "error" in c5:
+                leg_entries = [{"config": "c5_strong", **c5}]
+            else:
+                c5_parity = None
+                if not args.no_cpu_baseline:
+                    check = min(c5["pairs"], 200_000)
+                    want = oracle.levenshtein_pairs(c5["a"], c5["b"], algo="hyyro", count=check)
+                    c5_parity = bool((want == c5["sync_result"][:check]).all())
+                c5_calls = max(c5["totals"]["calls"], 1)
+                leg_entries = [{
+                    "config": "c5_strong", "workload": CONFIGS["c5"]["text"].format(pairs=c5["total_pairs"]) + ", tapes prepared and resident in HBM",
+                    "scaling": "strong", "n_gpus": world, "pairs_total": c5["total_pairs"], "pairs_rank0": c5["pairs"], "cells_total": c5["total_cells"],
+                    "shard_ranges": [list(r) for r in c5["ranges"]], "pieces_per_step": c5["n_pieces"],
+                    "value": round(c5["total_cells"] * c5["steps"] / c5["elapsed"] / 1e9, 2), "unit": "GCUPS", "steps": c5["steps"],
+                    "ms_per_step": round(c5["elapsed"] / c5["steps"] * 1e3, 4),
+                    "value_is": "K synchronous steps, barrier + synchronize on both sides, max over ranks: every rank scores its cells-balanced "
+                                "shard in pieces and sends each piece to its place in rank 0's vector while the next is scored",
+                    "collective": collective_text(True, world), "gather_ok": c5["gather_ok"], "gather": c5["gather"], "ranks_seen": ranks_seen,
+                    "kernel_ms_rank0_per_step": round(c5["totals"]["compute_ms"] / c5_calls * c5["n_pieces"], 4),
+                    "dominant_kernel": kernel_family(c5["sync_timing"]["dominant_name"]), "parity_vs_oracle": c5_parity,
+                    "parity_sample": "first 200000 pairs of rank 0's shard against oracle/; every other rank's slice by checksum (gather_ok)"}]
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N = 1 only
-            cpu_baselines = cpu_rows(a, b, budget_s=args.cpu_seconds)
+            cpu_baselines = cpu_rows(head["a"], head["b"], budget_s=args.cpu_seconds)
             cpu_baseline = {k: v for k, v in cpu_baselines[0].items() if k != "name"}
+        elapsed, steady = head["elapsed"], head["steady"]
         ms_per_step = elapsed / args.steps * 1e3
         line = {
-            "metric": "GCUPS (DP cell updates/s) batched Levenshtein", "value": round(total_cells * args.steps / elapsed / 1e9, 2),
+            "metric": "GCUPS (DP cell updates/s) batched Levenshtein", "value": round(head["total_cells"] * args.steps / elapsed / 1e9, 2),
             "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "value_steady": steady["value"] if steady else None, "value_pipelined": pipelined_rate,
-            "config": {"workload": cfg["text"].format(pairs=total_pairs if strong else pairs) + ", tapes prepared and resident in HBM",
+            "value_steady": steady["value"] if steady else None, "value_pipelined": head["pipelined_rate"],
+            "config": {"workload": cfg["text"].format(pairs=head["total_pairs"] if strong else pairs) + ", tapes prepared and resident in HBM",
                        "value_is": "rate of the K timed steps; a step is one synchronous call (results visible on return; the reference's "
                                    "compute_into metric, utils.rs:721-799)" + (" followed by the gather of the distances to rank 0, which overlaps the next step's call" if world > 1 else ""),
                        "value_steady_is": f"the same steps over >= {args.steady_seconds} s: {steady}" if steady else None,
-                       "value_pipelined_is": "K steps enqueued asynchronously on two internal lanes" + (f", {round(pipelined_ms, 4)} ms per step" if pipelined_ms else ""),
-                       "pairs_per_gpu": pairs, "pairs_total": total_pairs, "cells_per_gpu": cells, "algorithm": args.algorithm,
-                       "offsets": str(offsets_dtype), "pieces_per_step": n_pieces, "device_prewarm_s": args.prewarm_seconds,
-                       "collective": ("ncclSend/ncclRecv group per piece to rank 0 (variable-size gather of u32 distances)" if strong
-                                      else "RCCL gather of u32 distances to rank 0") if world > 1 else "none",
-                       "seed": args.seed},
+                       "value_pipelined_is": "K steps enqueued asynchronously on two internal lanes" + (f", {round(head['pipelined_ms'], 4)} ms per step" if head["pipelined_ms"] else ""),
+                       "pairs_per_gpu": pairs, "pairs_total": head["total_pairs"], "cells_per_gpu": cells, "algorithm": args.algorithm,
+                       "offsets": str(head["offsets_dtype"]), "pieces_per_step": n_pieces, "device_prewarm_s": args.prewarm_seconds,
+                       "collective": collective_text(strong, world), "seed": args.seed},
             "roofline": roofline, "configs": leg_entries, "cpu_baseline": cpu_baseline, "cpu_baselines": cpu_baselines,
-            "parity_vs_oracle": parity, "gather_ok": gather_ok,
+            "parity_vs_oracle": parity, "gather_ok": head["gather_ok"], "gather": head["gather"], "ranks_seen": ranks_seen,
         }
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None and world > 1 and not args.no_single_process:
+        # The in-library multi-device path (one scope over all N devices, ncclSend / ncclRecv inside csrc/sharded.hip) on the same
+        # devices, once the ranks are done with them: a CHILD process of rank 0 (never an exec), bounded by a timeout so that a
+        # hang there cannot cost the line. The other ranks have nothing left to do and exit.
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", str(args.steps), "--warmup",
+               str(args.warmup), "--config", args.config, "--seed", str(args.seed), "--prewarm-seconds", str(min(args.prewarm_seconds, 0.25))]
+        if args.pairs:
+            cmd += ["--pairs", str(args.pairs)]
+        if args.share_gpu:
+            cmd.append("--share-gpu")
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        child_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                        "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        try:
+            done = subprocess.run(cmd, env=child_env, capture_output=True, text=True, timeout=args.single_process_timeout)
+            child = last_json_line(done.stdout)
+            if done.returncode != 0 or child is None:
+                child = {"error": f"exit code {done.returncode}", "stderr_tail": done.stderr[-600:]}
+        except subprocess.TimeoutExpired:
+            child = {"error": f"no line within {args.single_process_timeout} s"}
+        line["single_process"] = child
     if line is not None:
         print(json.dumps(line), flush=True)
 

@@ -30,13 +30,21 @@ def main(argv=None) -> int:
     parser.add_argument("--tokens", choices=["lines", "words", "file"], default=None)
     parser.add_argument("-k", "--filter", metavar="REGEX")
     parser.add_argument("--time-limit", type=float, default=10.0)
+    parser.add_argument("--dataset-limit", type=str, default="128mb",
+                        help="Maximum dataset size (default: 128mb). Supports formats like '1gb', '500mb', '10kb'")     # utils.py:489-494
+    parser.add_argument("--bio", action="store_true",
+                        help="accepted so that the reference's command lines work (similarities/bench.py:824-828 gates its NW / SW groups on it); "
+                             "this backend's linear / affine rows are always measured")
     parser.add_argument("--batch-size", type=int, default=None, help="pairs per core (overrides STRINGWARS_BATCH_PER_CORE)")
     args = parser.parse_args(argv)
     pattern = re.compile(args.filter) if args.filter else None
     time_limit = H.get_env_parsed("STRINGWARS_TIME", args.time_limit, parser=float)
     warmup = H.get_env_parsed("STRINGWARS_WARMUP", 0.0, parser=float)
 
-    tokens = H.load_tokens(args.dataset, tokens_mode=args.tokens or "words")
+    try:
+        tokens = H.load_tokens(args.dataset, tokens_mode=args.tokens or "words", size_limit=args.dataset_limit)
+    except ValueError as problem:
+        parser.error(str(problem))
     if len(tokens) < 2:
         parser.error("Dataset must contain at least two tokens for the cross-product")
     codepoints = np.fromiter((len(t) for t in tokens), dtype=np.int64, count=len(tokens))

@@ -120,7 +120,7 @@ static void harvest_timing(Scope *scope, bool complete) {
     }
     // a plan-free call reports its work units through host-mapped memory
     if (scope->summary_pending && complete) {
-        const CallSummary sm = *scope->summary_host;
+        const CallSummary sm = scope->summary_host[scope->summary_slot];
         scope->last_timing.cells = sm.cells;
         scope->last_timing.bytes = (scope->summary_extra_bytes ? scope->summary_extra_bytes : sm.symbols * scope->summary_sym_bytes) +
                                    scope->summary_pairs * (2 * scope->summary_ow + scope->summary_elem);
@@ -555,6 +555,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         if (route != kRoutePlanned) {
             // ---- no pre-pass: one DP launch; its summary (work units, longest strings, "a pair did not fit") arrives in
             // host-mapped memory with the kernel's completion ------------------------------------------------------------
+            // (an asynchronous call reports into slot 1, whose `sticky` word outlives the summary: see CallSummary)
+            scope->summary_slot = (scope->async && dev_out) ? 1u : 0u;
             if (route == kRouteDirectShort) launch_direct_short_alone(scope, pre);
             else if (route == kRouteShortTiled) {
                 // mean string length, for the chunk size: exact for prepared tapes (their totals), else what the last call saw
@@ -578,7 +580,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             if (!scope->async || !dev_out) {
                 SWH_HIP_CHECK(hipStreamSynchronize(stream));
                 if (*invalid_host) return invalid_utf8();
-                if (scope->summary_host->violation) {
+                if (scope->summary_host[0].violation) {
                     // the belief about the lengths was wrong (it came from an earlier batch): redo on the planned path
                     scope->hint_lengths = false;
                     scope->summary_pending = false;
@@ -830,6 +832,9 @@ swh_status_t swh_scope_synchronize(swh_scope_t handle, const char **error) {
     if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipStreamSynchronize"});
     harvest_timing(scope, true);
     violated |= scope->violation_seen; scope->violation_seen = false;
+    // every asynchronous plan-free call since the last synchronisation, not only the one whose summary was still there to read
+    for (Scope *each : {scope, scope->lanes[0], scope->lanes[1]})
+        if (each && each->summary_host && each->summary_host[1].sticky) { violated = true; each->summary_host[1].sticky = 0; }
     if (scope->pipelined && scope->last_lane) scope->last_timing = scope->last_lane->last_timing;
     if (violated)
         return fail(error, swh_invalid_argument_k, "an asynchronous call met strings longer than its prepared tapes were measured with (was a tape's memory "

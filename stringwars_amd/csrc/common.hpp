@@ -160,7 +160,13 @@ static_assert(sizeof(PlanPartial) == 32, "report_call_summary reads a partial as
 struct CallSummary {
     unsigned long long cells, symbols;
     uint32_t max_la, max_lb, short_pairs, violation;
+    // Set with `violation` and cleared only by the host: a summary is overwritten by the next call's, and an asynchronous call's
+    // summary is only READ when the host happens to synchronise right behind it (pipelined lanes carry two calls between
+    // synchronisations, a sharded call four pieces). Asynchronous calls report into slot 1 of the scope's summary block and
+    // swh_scope_synchronize looks at slot 1's `sticky`; synchronous calls (slot 0) handle `violation` on the spot.
+    uint32_t sticky, pad;
 };
+static_assert(sizeof(CallSummary) == 40, "two summary slots share the scope's 256-byte host-mapped block");
 // Tail of the kernels that run without the planning pre-pass, called by every thread of the workgroup; thread 0 passes the
 // workgroup's sums (`pad` != 0: it met a pair it could not score). The last workgroup to get here folds all partials and
 // writes the call's summary into host-mapped memory; the counter resets itself for the next launch.
@@ -235,6 +241,7 @@ __device__ __forceinline__ void report_call_summary(const PlanPartial &mine, Pla
         __hip_atomic_store(&summary->max_lb, maxb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&summary->short_pairs, shorts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&summary->violation, viol ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (viol) __hip_atomic_store(&summary->sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -330,6 +337,8 @@ struct Scope {
     uint32_t hint_mean_x16 = 0;   // mean string length of the previous call, x16 (both tapes together)
     CallSummary *summary_host = nullptr;   // pinned, mapped: written by kernels, read by the host after a synchronisation
     CallSummary *summary_dev = nullptr;    // the same memory as the device sees it
+    uint32_t summary_slot = 0;             // which of the block's two summaries the call in flight reports into (1: asynchronous)
+    CallSummary *summary_target() const { return summary_dev + summary_slot; }
     uint32_t *done_counter = nullptr;      // device: workgroups finished (self-resetting), for "last one reports"
     bool summary_pending = false;          // a plan-free call's summary has not been read yet (harvest_timing)
     bool violation_seen = false;           // an asynchronous plan-free call reported a pair that did not fit: swh_scope_synchronize fails

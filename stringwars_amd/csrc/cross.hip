@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kCrossWaves * 64) void k_cross_short(CrossArgs args
 void launch_cross_short(Scope *scope, const Job &job, uint32_t off64) {
     CrossArgs args{};
     args.job = job; args.off64 = off64;
-    args.partials = scope->plan_partials; args.done_counter = scope->done_counter; args.summary = scope->summary_dev;
+    args.partials = scope->plan_partials; args.done_counter = scope->done_counter; args.summary = scope->summary_target();
     const uint64_t items = ((job.b.count + 63) / 64) * ((job.a.count + kCrossQueries - 1) / kCrossQueries);
     uint64_t blocks64 = (items + kCrossWaves - 1) / kCrossWaves;
     uint32_t max_blocks = (uint32_t)scope->compute_units * 8;

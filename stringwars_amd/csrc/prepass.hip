@@ -755,7 +755,7 @@ void launch_direct_short_alone(Scope *scope, const PrepassArgs &args_in) {
     PrepassArgs args = args_in;
     args.direct_short = 1;
     args.partials = scope->plan_partials;
-    args.summary = scope->summary_dev;
+    args.summary = scope->summary_target();
     args.done_counter = scope->done_counter;
     const int dblocks = direct_short_blocks(scope, args.job.pairs);
     StampGuard guard(scope, "direct_short");

@@ -616,7 +616,7 @@ void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64, uint32_t m
     args.tiles = (uint32_t)((job.pairs + tile - 1) / tile);
     args.partials = scope->plan_partials;
     args.done_counter = scope->done_counter;
-    args.summary = scope->summary_dev;
+    args.summary = scope->summary_target();
     const uint32_t blocks = args.tiles < slots ? args.tiles : slots;
     StampGuard guard(scope, "short_tiled");
     if (off64) hipLaunchKernelGGL(k_short_tiled<uint64_t>, dim3(blocks), dim3(kShortThreads), 0, scope->stream, args);

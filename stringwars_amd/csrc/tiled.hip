@@ -429,7 +429,7 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
     t.cut_affixes = sizeof(Sym) == 1 && !no_affix ? 1u : 0u;
     t.partials = scope->plan_partials;
     t.done_counter = scope->done_counter;
-    t.summary = scope->summary_dev;
+    t.summary = scope->summary_target();
     opt_in_dynamic_lds(scope, (const void *)k_bitparallel_tiled<Sym, kWaves>, lds);
     static const bool debug = getenv("STRINGWARS_AMD_DEBUG") != nullptr;
     if (debug) {

@@ -123,13 +123,28 @@ def tokenize(haystack, tokens_mode: Optional[str] = None, unique: Optional[bool]
     return tokens
 
 
-def load_tokens(path: Optional[str] = None, tokens_mode: str = "words", shuffle: bool = True) -> List[str]:
-    """Dataset -> shuffled token list exactly as similarities/bench.py:857-867 prepares it."""
+_SIZE_UNITS = {"": 1, "b": 1, "kb": 1 << 10, "mb": 1 << 20, "gb": 1 << 30}
+
+
+def size_in_bytes(text: str) -> int:
+    """`--dataset-limit` values: a number with an optional b / kb / mb / gb suffix, powers of 1024, any case
+    (utils.py:340-367: '128mb', '1gb', '500kb', '1.5 mb')."""
+    spelled = (text or "").strip().lower()
+    digits = spelled.rstrip("kmgb").strip()
+    unit = spelled[len(spelled.rstrip("kmgb")):]
+    if not digits or unit not in _SIZE_UNITS or not re.fullmatch(r"\d+(\.\d+)?", digits):
+        raise ValueError(f"Invalid size format: {text}. Use formats like '128mb', '1gb', '500kb'")
+    return int(float(digits) * _SIZE_UNITS[unit])
+
+
+def load_tokens(path: Optional[str] = None, tokens_mode: str = "words", shuffle: bool = True, size_limit: Optional[str] = None) -> List[str]:
+    """Dataset -> shuffled token list exactly as similarities/bench.py:857-867 prepares it; `size_limit` reads at most that
+    much of the file (`--dataset-limit`, utils.py:489-494; counted in characters of the decoded text, as `f.read(n)` does)."""
     path = path or get_env("STRINGWARS_DATASET")
     if path is None:
         raise ValueError("No dataset path provided and STRINGWARS_DATASET not set")
     with open(path, encoding="utf-8", errors="ignore") as handle:
-        text = handle.read()
+        text = handle.read(size_in_bytes(size_limit)) if size_limit else handle.read()
     tokens = tokenize(text, os.environ.get("STRINGWARS_TOKENS", tokens_mode))
     max_tokens = get_env_parsed("STRINGWARS_MAX_TOKENS", None)
     if max_tokens is not None and max_tokens > 0:

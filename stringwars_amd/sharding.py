@@ -66,9 +66,15 @@ class ChunkedGather:
     rank cuts its shard with `chunk_ranges`, so the root knows from the shard sizes alone where piece j of rank r
     lands and posts a receive straight into `full[...]` for it; the others send their piece (`batch_isend_irecv` =
     one ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd per call on RCCL). Piece j travels while piece j + 1 is
-    still being scored."""
+    still being scored.
 
-    def __init__(self, ranges: Sequence[Tuple[int, int]], chunks: int, dtype, device, dst: int = 0):
+    `full` may be handed in (a buffer per pipeline slot, reused from step to step: allocating and zeroing 4 B per pair
+    on the root every step is a memset the size of the whole result). `transport` narrower than the result type
+    (`torch.uint8` when no distance can exceed 255: both strings of every pair are that short) sends a quarter of the
+    bytes over xGMI -- the root's inbound links are what bounds a gather of word-sized pairs -- and widens the pieces
+    into `full` on arrival; the vector the root ends up with is the same u32 vector either way."""
+
+    def __init__(self, ranges: Sequence[Tuple[int, int]], chunks: int, dtype, device, dst: int = 0, full=None, transport=None):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
@@ -76,9 +82,16 @@ class ChunkedGather:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.pieces = [chunk_ranges(hi - lo, chunks) for lo, hi in self.ranges]
         self.staged = dist.get_backend() == "gloo" and torch.device(device).type != "cpu"   # gloo moves host memory
-        self.full = (torch.zeros(self.ranges[-1][1], dtype=dtype, device="cpu" if self.staged else device)
-                     if self.rank == dst else None)
+        self.transport = transport if transport is not None and transport != dtype else None
+        where = "cpu" if self.staged else device
+        if self.rank == dst:
+            self.full = full if full is not None else torch.zeros(self.ranges[-1][1], dtype=dtype, device=where)
+            # narrow transport: the pieces arrive in a staging vector of the transport type, laid out like `full`
+            self.landing = torch.empty(self.ranges[-1][1], dtype=self.transport, device=where) if self.transport is not None else self.full
+        else:
+            self.full = self.landing = None
         self.pending = []
+        self.arrived = []          # (lo, hi) ranges of `landing` to widen into `full` once their receive has completed
 
     def piece(self, rank: int, j: int) -> Tuple[int, int]:
         """Piece j of rank `rank`, as indices into that rank's own shard."""
@@ -98,9 +111,12 @@ class ChunkedGather:
                 r_lo, r_hi = self.piece(r, j)
                 if r != self.dst and r_hi > r_lo:
                     base = self.ranges[r][0]
-                    ops.append(dist.P2POp(dist.irecv, self.full[base + r_lo:base + r_hi], r))
+                    ops.append(dist.P2POp(dist.irecv, self.landing[base + r_lo:base + r_hi], r))
+                    if self.transport is not None:
+                        self.arrived.append((base + r_lo, base + r_hi))
         elif hi > lo:
-            ops.append(dist.P2POp(dist.isend, local[lo:hi].cpu() if self.staged else local[lo:hi], self.dst))
+            piece = local[lo:hi] if self.transport is None else local[lo:hi].to(self.transport)
+            ops.append(dist.P2POp(dist.isend, piece.cpu() if self.staged else piece, self.dst))
         if ops:
             self.pending.extend(dist.batch_isend_irecv(ops))
 
@@ -108,6 +124,9 @@ class ChunkedGather:
         for work in self.pending:
             work.wait()
         self.pending = []
+        for lo, hi in self.arrived:
+            self.full[lo:hi].copy_(self.landing[lo:hi])      # widening copy, ordered behind the receive it follows
+        self.arrived = []
         return self.full
 
 

@@ -100,3 +100,45 @@ def test_pmc_constants_folds_counter_passes(tmp_path):
                     "--calls", "1", "--variant", "k8", "--out", str(out)], check=True, capture_output=True)
     book = json.load(open(out))["kernels"]
     assert set(book) == {"bitparallel_tiled|tokens64", "bitparallel_tiled|tokens64|k8"} and abs(book["bitparallel_tiled|tokens64|k8"]["valu_insts"] - 246e6) < 1
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """`--gpus N` is a promise: a process group of another size is an error before anything touches a GPU, never a quiet
+    measurement of fewer devices (the driver computes scaling efficiency from `n_gpus`)."""
+    bench = os.path.join(ROOT, "bench.py")
+    for gpus, world in (("2", "3"), ("8", "1"), ("1", "2")):
+        env = dict(os.environ, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0")
+        done = subprocess.run([sys.executable, bench, "--gpus", gpus, "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
+        assert done.returncode != 0 and f"--gpus {gpus} but WORLD_SIZE={world}" in done.stderr, (gpus, world, done.stderr[-400:])
+        assert not [row for row in done.stdout.splitlines() if row.startswith("{")]          # and no line
+
+
+def test_bench_starts_its_own_ranks_when_there_is_no_world(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE: the N ranks are started as a CHILD (`python -m torch.distributed.run
+    --nproc-per-node N ... bench.py <same arguments>`) by a process that has imported neither torch nor the library, and the
+    child's exit code is handed on."""
+    bench = load(os.path.join(ROOT, "bench.py"), "bench_module_launch")
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kwargs):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    try:
+        bench.main()
+        raise AssertionError("main() must leave with the child's exit code")
+    except SystemExit as leave:
+        assert leave.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[-7]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    source = open(os.path.join(ROOT, "bench.py")).read()
+    # nothing at module level pulls torch or the library in: both are imported inside the functions that need a GPU
+    assert not [row for row in source.splitlines() if row.startswith(("import torch", "import stringwars_amd", "from stringwars_amd"))]

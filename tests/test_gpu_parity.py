@@ -1132,7 +1132,31 @@ def test_prepared_tapes_in_asynchronous_and_pipelined_scopes(sw, orc):
         scope.synchronize()
     assert info.value.status == "invalid_argument" and "not scored" in str(info.value)
     scope.synchronize()                                           # reported once
+    # ... and it is reported whichever call it happened in: the summary of an asynchronous call is overwritten by the next call's
+    # and is only read when the host synchronises right behind it, so the faulty call is followed here by calls on INTACT tapes
+    # (their summaries are clean) -- plain asynchronous, then on the two pipeline lanes, where a lane carries two calls per sync.
+    ga, gb = sw.generate_pairs("tokens64", 30_000, seed=10)
+    good_a, good_b = sw.PreparedTape(scope, ga.to_device(scope)), sw.PreparedTape(scope, gb.to_device(scope))
+    good_out = torch.zeros(30_000, dtype=torch.int32, device="cuda")
+    want_good = orc.levenshtein_pairs(ga, gb, algo="hyyro")
+    for pipelined, calls_after in ((False, 1), (False, 3), (True, 2), (True, 5)):
+        scope.set_pipelined(pipelined)
+        engine.pairs(pa, pb, scope, out=out)                     # the call that cannot score its first pair
+        for _ in range(calls_after):
+            engine.pairs(good_a, good_b, scope, out=good_out)
+        with pytest.raises(sw.StringWarsError) as info:
+            scope.synchronize()
+        assert info.value.status == "invalid_argument" and "not scored" in str(info.value), (pipelined, calls_after)
+        assert (good_out.cpu().numpy().astype(np.uint32) == want_good).all()
+        for _ in range(3):                                       # nothing left over: clean calls synchronise cleanly afterwards
+            engine.pairs(good_a, good_b, scope, out=good_out)
+        scope.synchronize()
+    scope.set_pipelined(False)
     scope.set_async(False)
+    # a SYNCHRONOUS call on the damaged tapes is redone on the planned path on the spot (and must leave nothing behind for a later synchronize)
+    got = engine.pairs(pa, pb, scope, out=out).cpu().numpy().astype(np.uint32)
+    scope.synchronize()
+    assert (got[61:] == orc.levenshtein_pairs(a, b, algo="hyyro")[61:]).all()
 
 
 def test_multi_device_scope_on_one_gpu(sw, orc):
@@ -1697,7 +1721,11 @@ def test_bench_line_carries_every_config():
         assert "error" not in entry, entry
         assert entry["value"] > 0 and entry["parity_vs_oracle"] is True and entry["roofline"]["kernel_ms"] > 0 and entry["pairs"] == 600, entry
         assert "cells_mismatch" not in entry, entry
-    assert line["cpu_baseline"]["kind"] == "port" and len(line["cpu_baselines"]) == 4
+    assert line["cpu_baseline"]["kind"] == "port" and len(line["cpu_baselines"]) == 5
+    c1_cpu = [row for row in line["cpu_baselines"] if row["name"] == "c1/cpu::hyyro<1cpu>"]
+    assert len(c1_cpu) == 1 and c1_cpu[0]["cores"] == 1 and c1_cpu[0]["value"] > 0           # BASELINE configs[0]: the per-pair CPU row on 10 K words
+    many = [row for row in line["cpu_baselines"] if row["cores"] > 1]
+    assert len(many) == 1 and many[0]["cores"] == os.cpu_count()                                 # every hardware thread of the box
 
 
 @pytest.mark.parametrize("config,pairs", [("c2", 60_000), ("c5", 600_000)])
@@ -1718,3 +1746,46 @@ def test_bench_two_ranks_share_the_gpu(config, pairs):
     line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["gather_ok"] is True and line["parity_vs_oracle"] is True
     assert line["scaling"] == ("weak" if config == "c2" else "strong") and line["value"] > 0
+
+
+def test_bench_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with NO torchrun prefix and no WORLD_SIZE (the shape of the driver's N = 1 command): the script
+    starts its ranks as a child process before touching the GPU and rank 0's line says `n_gpus: 2`. At N > 1 the line also carries
+    BASELINE configs[4] -- C5, strong scaling -- with its checked gather (bytes on the wire, widened on the root), the gather's price and
+    the ranks that took part, and the in-library sharded call (one scope over both member devices) as `single_process`."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", "60000", "--c5-pairs", "700000", "--steps", "3", "--warmup", "1",
+           "--prewarm-seconds", "0.05", "--steady-seconds", "0.05", "--backend", "gloo", "--share-gpu"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-3000:])
+    line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["gather_ok"] is True and line["parity_vs_oracle"] is True and line["value"] > 0
+    assert line["ranks_seen"]["world_size"] == 2 and [r["rank"] for r in line["ranks_seen"]["ranks"]] == [0, 1]
+    assert line["gather"]["alone_ms"] > 0 and line["gather"]["bytes_to_root_per_step"] == 4 * 60000
+    (c5,) = line["configs"]
+    assert c5["config"] == "c5_strong" and c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["pairs_total"] == 700000, c5
+    assert c5["gather_ok"] is True and c5["parity_vs_oracle"] is True and c5["value"] > 0 and c5["ranks_seen"]["world_size"] == 2
+    assert c5["shard_ranges"][0][0] == 0 and c5["shard_ranges"][0][1] == c5["shard_ranges"][1][0] and c5["shard_ranges"][1][1] == 700000
+    assert c5["gather"]["transport"].startswith("u8") and c5["gather"]["bytes_to_root_per_step"] == 700000 - c5["shard_ranges"][0][1]
+    single = line["single_process"]
+    assert "error" not in single, single
+    assert single["mode"] == "single-process" and single["n_gpus"] == 2 and single["parity_vs_oracle"] is True and single["value"] > 0
+    assert single["config"]["device_count"] == 2 and single["config"]["shard_cuts"][-1] == 2 * 60000
+
+
+def test_bench_single_process_mode():
+    """`bench.py --gpus 3 --single-process --config c5`: one process, one scope over three member devices (all of them device 0 on
+    this box), `swh_sharded_prepare_*` + `swh_levenshtein_pairs_sharded` per step with the self-check on every call."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--single-process", "--share-gpu", "--config", "c5", "--pairs", "900000",
+           "--steps", "3", "--warmup", "1", "--prewarm-seconds", "0.05"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-3000:])
+    line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["mode"] == "single-process" and line["scaling"] == "strong" and line["parity_vs_oracle"] is True
+    assert line["config"]["shard_cuts"][0] == 0 and line["config"]["shard_cuts"][-1] == 900000 and line["value"] > 0

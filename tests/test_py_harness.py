@@ -50,6 +50,20 @@ def test_tokenisation_and_shuffle(tmp_path, monkeypatch):
     assert not H.should_run("linear/stringwars_amd.NeedlemanWunschScores<1gpu>", pattern)
 
 
+def test_dataset_limit_sizes_and_truncation(tmp_path):
+    """`--dataset-limit` (utils.py:340-367, :489-494): 1024-based b / kb / mb / gb suffixes; the loader reads at most that much."""
+    from stringwars_amd import harness as H
+    for text, want in (("128mb", 128 << 20), ("1gb", 1 << 30), ("500kb", 500 << 10), ("10", 10), ("1.5 MB", int(1.5 * (1 << 20))), ("7b", 7)):
+        assert H.size_in_bytes(text) == want, text
+    for bad in ("", "mb", "12tb", "-3kb", "1e3"):
+        with pytest.raises(ValueError):
+            H.size_in_bytes(bad)
+    path = tmp_path / "words.txt"
+    path.write_text(" ".join(f"w{i:04d}" for i in range(1000)))
+    assert len(H.load_tokens(str(path), shuffle=False)) == 1000
+    assert H.load_tokens(str(path), shuffle=False, size_limit="60b") == [f"w{i:04d}" for i in range(10)]
+
+
 def run_script(extra):
     env = dict(os.environ, PYTHONPATH=ROOT)
     return subprocess.run([sys.executable, "-m", "stringwars_amd.bench_similarities", "--dataset", os.path.join(ROOT, "README.md"),

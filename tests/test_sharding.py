@@ -69,7 +69,21 @@ def _worker(rank, world, port, queue):
     full = gather.wait()
     sums = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(sums, local.to(torch.int64).sum().reshape(1))
+    # the same gather twice more into ONE root buffer handed in (bench.py keeps one per pipeline slot), the second time with
+    # bytes on the wire (no distance of word-sized pairs exceeds 255) widened on arrival
+    reused = torch.full((total,), -1, dtype=torch.int32) if rank == 0 else None
+    narrow_ok = True
+    for transport in (None, torch.uint8):
+        if rank == 0:
+            reused.fill_(-1)
+        gather = sharding.ChunkedGather(ranges, 3, torch.int32, "cpu", full=reused, transport=transport)
+        for j in range(3):
+            gather.send_chunk(local, j)
+        again = gather.wait()
+        if rank == 0:
+            narrow_ok = narrow_ok and again is reused and bool((again == full).all())
     if rank == 0:
+        out["c5_reused_and_narrow_ok"] = narrow_ok
         out["c5"] = full.numpy()
         out["c5_ranges"] = ranges
         out["c5_sums_ok"] = all(int(full[l:h].to(torch.int64).sum()) == int(sums[r]) for r, (l, h) in enumerate(ranges))
@@ -102,6 +116,7 @@ def test_two_rank_gloo_gather_matches_single_process(sw, orc):
     assert abs(int(cells[lo0:hi0].sum()) - int(cells[lo1:hi1].sum())) <= int(cells.max())
     ga, gb = sw.generate_pairs("short_words", 7003, seed=42)
     assert (out["c5"] == orc.levenshtein_pairs(ga, gb, algo="hyyro").astype(np.int32)).all() and out["c5_sums_ok"]
+    assert out["c5_reused_and_narrow_ok"]
     (lo0, hi0), (lo1, hi1) = out["c5_ranges"]
     cells = (ga.lengths * gb.lengths).astype(np.int64)
     assert lo0 == 0 and hi0 == lo1 and hi1 == 7003

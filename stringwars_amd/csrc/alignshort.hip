@@ -1,0 +1,402 @@
+// alignshort.hip -- Needleman-Wunsch / Smith-Waterman SCORES for word-sized strings (both sides <= 32 bytes), one pair per lane.
+//
+// The reference's default token mode is `words` (similarities/bench.rs:271): its NW / SW rows (`perform_linear_benchmarks`,
+// `perform_affine_benchmarks`, bench.rs:641-699, :967-1026; README.md:70, the words column) score strings of ~5 bytes. The
+// wavefront kernels give such a pair a group of sixteen lanes and a four-step refill cadence: 2048 x 2048 words ran at
+// 0.05 TCUPS, thirty times below the Levenshtein rows on the same tapes. Here a LANE owns a pair:
+//
+//   * the DP row lives in W registers (W = 16 or 32 columns: the b string), the a string supplies the rows; a row is
+//     W cells updated in place, its left-to-right dependency is a chain of `v_max3` inside one lane -- no DPP, no LDS;
+//   * substitution scores come from the engine's 32 x 32 class table exactly as in the wavefront class models
+//     (wavefront.hip): per row ONE 32-byte cost row is read from LDS (the row symbol's class; two `ds_read_b128`, a
+//     broadcast when the whole wave scores the same query) and every group of four columns picks its four bytes with one
+//     `v_perm_b32` per eight classes in use (PQ) through selectors prepared once per b string; the cell is then
+//     `v_add_u32_sdwa (sext byte)` + `v_max3_i32` (Gotoh: two maxima more), with the same baseline-relative forms and the same
+//     biased table (global: sub - ext - open, local: sub - open) as the wavefront kernels, so the tables are shared;
+//   * pairwise batches run in tape order, 64 consecutive pairs per wave item; the reference's own call shape,
+//     `compute_into(queries, candidates, &mut matrix)` (bench.rs:478-486), keeps 64 CANDIDATES in the lanes of a wave (classes
+//     and selectors prepared once) and walks a block of queries over them, like k_cross_short.
+//
+// Exact for strings of up to W symbols; a longer string raises the call summary's `violation` flag and the host redoes the
+// call on the planned path (api.hip), as for the other plan-free kernels.
+#include "common.hpp"
+#include "bp_window.hpp"
+
+namespace swh {
+
+constexpr int kAlignQueries = 16;           // queries per cross-product work item
+constexpr int kAlignWaves = 4;
+constexpr int kAlignNegInf = -0x20000000;
+constexpr size_t kClassLdsBytes = 32 * 32 + 256;   // 32 x 32 i8 class costs, then the byte -> class map (wavefront.hip: kClassLds)
+
+struct AlignShortArgs {
+    Job job;
+    uint32_t off64;
+    int open, extend;
+    const uint8_t *class_table;   // 32 x 32 biased class costs, then the byte -> class map (wavefront.hip: kClassLds)
+    PlanPartial *partials;
+    uint32_t *done_counter;
+    CallSummary *summary;
+};
+
+__device__ __forceinline__ void align_extent(const void *offsets, uint32_t off64, uint64_t i, uint64_t &start, uint32_t &len) {
+    if (off64) { const uint64_t *o = (const uint64_t *)offsets; const uint64_t x0 = o[i], x1 = o[i + 1]; start = x0; len = (uint32_t)(x1 - x0); }
+    else { const uint32_t *o = (const uint32_t *)offsets; const uint32_t x0 = o[i], x1 = o[i + 1]; start = x0; len = (uint32_t)(x1 - x0); }
+}
+
+// bytes [start, start + 4 * WORDS) of a tape as dwords; what lies past the string is whatever the tape holds there (or a clamped
+// window's garbage): the callers never let it decide anything
+template <int WORDS>
+__device__ __forceinline__ void align_fetch(const uint8_t *data, uint64_t start, uint64_t total, uint32_t (&w)[WORDS]) {
+    ByteWindow win;
+    win.init(data, start, total);
+    if (total >= 16) {
+#pragma unroll
+        for (int h = 0; h < WORDS / 4; ++h) {
+            uint32_t half[4];
+            const int moved = win.fetch16_raw(16 * h, half);
+            win.fix16(16 * h, moved, half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[4 * h + q] = half[q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < WORDS; ++q) w[q] = win.fetch4(q * 4);
+    }
+}
+
+// bytes -> classes, four per dword, through the byte -> class map in LDS; only the first `upto` (wave-uniform) symbols matter
+template <int WORDS>
+__device__ __forceinline__ void align_classes(const uint8_t *lclass_of, const uint32_t (&w)[WORDS], uint32_t upto, uint32_t (&cls)[WORDS]) {
+#pragma unroll
+    for (int q = 0; q < WORDS; ++q) {
+        cls[q] = 0;
+        if ((uint32_t)(4 * q) < upto) {
+            const uint32_t c0 = lclass_of[w[q] & 0xffu], c1 = lclass_of[(w[q] >> 8) & 0xffu];
+            const uint32_t c2 = lclass_of[(w[q] >> 16) & 0xffu], c3 = lclass_of[w[q] >> 24];
+            cls[q] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        }
+    }
+}
+
+// v_perm selectors of a b string: per group of four columns and per pair of cost-row dwords pq, byte i is (class & 7) when
+// the class lives in dwords 2 pq .. 2 pq + 1 of the row, else 0x0C (a zero byte). Packed arithmetic, four columns at a time:
+// m = classes ^ (pq << 3) has members in 0..7 and everything else in 8..31; (m + 0x78) sets bit 7 exactly for the others.
+// Local alignment: columns right of the string select zero everywhere = a substitution score of `open` <= 0, so a phantom
+// cell never exceeds the real cell it descends from and the running maximum needs no column test (wavefront.hip).
+template <int W, int PQ, bool kLocal>
+__device__ __forceinline__ void align_selectors(const uint32_t (&cls)[W / 4], uint32_t n, uint32_t (&sel)[(W / 4) * PQ]) {
+#pragma unroll
+    for (int g = 0; g < W / 4; ++g) {
+        uint32_t beyond = 0;
+        if constexpr (kLocal) beyond = n >= (uint32_t)(4 * g + 4) ? 0u : (n <= (uint32_t)(4 * g) ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (n - 4 * g)));
+#pragma unroll
+        for (int pq = 0; pq < PQ; ++pq) {
+            const uint32_t m = cls[g] ^ (0x08080808u * (uint32_t)pq);
+            const uint32_t t = (m + 0x78787878u) & 0x80808080u;
+            const uint32_t others = ((t - (t >> 7)) | t) | beyond;           // 0xFF in the bytes that select nothing
+            sel[g * PQ + pq] = (m & ~others) | (0x0C0C0C0Cu & others);
+        }
+    }
+}
+
+// The rows of one pair (lane): `acls` the a string's classes, m rows of it, n columns prepared in `sel`; m_max / n_max are the
+// wave's maxima (uniform loop bounds). Returns the score of the global alignment or the best local one; pairs with an empty
+// side are the caller's.
+template <int W, int PQ, bool kAffine, bool kLocal>
+__device__ __forceinline__ int align_rows(const uint32_t (&acls)[W / 4], uint32_t m, uint32_t m_max, const uint32_t (&sel)[(W / 4) * PQ],
+                                          uint32_t n, uint32_t n_max, const char *ltable, int open, int ext) {
+    constexpr bool kSkew = !kAffine && !kLocal;          // U = H - (r + k) g:  U = max3(U_diag + (s - 2g), U_up, U_left), boundaries 0
+    constexpr bool kSkewAffine = kAffine && !kLocal;     // strips hold H^ + (open - ext): see wavefront.hip
+    const int open_minus_ext = open - ext;
+    int H[W];
+    [[maybe_unused]] int F[kAffine ? W : 1];
+    const int row0 = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        H[k] = row0;
+        if constexpr (kAffine) F[k] = kAlignNegInf;
+    }
+    uint32_t rowq[W / 4];
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) rowq[q] = acls[q];
+    int best = 0;
+    uint4 lo_next = *(const uint4 *)(ltable + (rowq[0] & 0xffu) * 32);
+    uint4 hi_next{0, 0, 0, 0};
+    if constexpr (PQ > 2) hi_next = *(const uint4 *)(ltable + (rowq[0] & 0xffu) * 32 + 16);
+    for (uint32_t i = 0; i < m_max; ++i) {
+        const uint4 r_lo = lo_next, r_hi = hi_next;
+        // the next row's class moves down to byte 0; its cost row is requested before this row's cells
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) rowq[q] = q + 1 < W / 4 ? __builtin_amdgcn_alignbyte(rowq[q + 1 < W / 4 ? q + 1 : q], rowq[q], 1) : rowq[q] >> 8;
+        lo_next = *(const uint4 *)(ltable + (rowq[0] & 0xffu) * 32);
+        if constexpr (PQ > 2) hi_next = *(const uint4 *)(ltable + (rowq[0] & 0xffu) * 32 + 16);
+        if (i < m) {
+            // boundary column: H of (row i + 1, column 0) on the left, of (row i, column 0) on the diagonal
+            int left = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);
+            int diag = kLocal ? open : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext));
+            [[maybe_unused]] int e = kAlignNegInf;
+#pragma unroll
+            for (int g4 = 0; g4 < W; g4 += 4) {
+                if ((uint32_t)g4 < n_max) {
+                    const uint32_t *sg = sel + (g4 >> 2) * PQ;
+                    uint32_t c4 = __builtin_amdgcn_perm(r_lo.y, r_lo.x, sg[0]);
+                    if constexpr (PQ > 1) c4 |= __builtin_amdgcn_perm(r_lo.w, r_lo.z, sg[PQ > 1 ? 1 : 0]);
+                    if constexpr (PQ > 2) c4 |= __builtin_amdgcn_perm(r_hi.y, r_hi.x, sg[PQ > 2 ? 2 : 0]);
+                    if constexpr (PQ > 3) c4 |= __builtin_amdgcn_perm(r_hi.w, r_hi.z, sg[PQ > 3 ? 3 : 0]);
+                    // the four diagonal sums read the OLD row before any cell of the group is overwritten
+                    int t[4];
+                    t[0] = diag + (int)(int8_t)c4;
+                    t[1] = H[g4] + (int)(int8_t)(c4 >> 8);
+                    t[2] = H[g4 + 1] + (int)(int8_t)(c4 >> 16);
+                    t[3] = H[g4 + 2] + (int)(int8_t)(c4 >> 24);
+                    diag = H[g4 + 3];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = g4 + u;
+                        if constexpr (kSkew) {
+                            asm("v_max3_i32 %0, %1, %0, %2" : "+v"(H[k]) : "v"(t[u]), "v"(left));
+                        } else if constexpr (kSkewAffine) {
+                            const int f = max(H[k], F[k]);
+                            F[k] = f;
+                            e = max(left, e);
+                            const int h3 = max(max(t[u], e), f);
+                            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open_minus_ext));
+                        } else if constexpr (kAffine) {   // local, Gotoh: strips hold H + open
+                            const int f = max(H[k], F[k] + ext);
+                            F[k] = f;
+                            e = max(left, e + ext);
+                            const int h3 = max(max(max(t[u], e), f), 0);
+                            best = max(best, h3);
+                            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open));
+                        } else {                          // local, linear
+                            const int h3 = max(max(max(t[u], H[k]), left), 0);
+                            best = max(best, h3);
+                            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open));
+                        }
+                        left = H[k];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (kLocal) return best;
+    int result = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+        if ((uint32_t)k + 1 == n) result = H[k];
+    if constexpr (kSkew) result += (int)(m + n) * ext;
+    else result += (int)(m + n) * ext - open_minus_ext;
+    return result;
+}
+
+__device__ __forceinline__ int align_trivial(uint32_t la, uint32_t lb, bool local, int open, int ext) {
+    const uint32_t len = la + lb;
+    return (len && !local) ? open + (int)(len - 1) * ext : 0;   // gap(k) = open + (k - 1) extend; two empty strings score 0
+}
+
+struct AlignWaveLds {
+    uint32_t qlen[kAlignQueries];
+    uint32_t qcls[kAlignQueries][8];     // the item's queries as class bytes (<= 32 per query)
+};
+
+template <int W, int PQ, bool kAffine, bool kLocal>
+__global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs args) {
+    __shared__ __attribute__((aligned(16))) char ltable[kClassLdsBytes];
+    __shared__ AlignWaveLds wave_lds[kAlignWaves];
+    __shared__ SummaryLds summary_lds;
+    __shared__ unsigned long long lcells, lsyms;
+    __shared__ uint32_t lmaxa, lmaxb, lshorts, lmisfit;
+    {
+        const uint32_t *src = (const uint32_t *)args.class_table;
+        for (int i = threadIdx.x; i < (int)kClassLdsBytes / 4; i += blockDim.x) ((uint32_t *)ltable)[i] = src[i];
+    }
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; lmisfit = 0; }
+    __syncthreads();
+    const uint8_t *lclass_of = (const uint8_t *)ltable + 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Job &job = args.job;
+    const uint8_t *a_data = (const uint8_t *)job.a.data, *b_data = (const uint8_t *)job.b.data;
+    const uint64_t na = job.a.count, nb = job.b.count;
+    uint64_t a_total, b_total;
+    { uint32_t unused; align_extent(job.a.offsets, args.off64, na, a_total, unused); align_extent(job.b.offsets, args.off64, nb, b_total, unused); }
+    const uint64_t waves_total = (uint64_t)gridDim.x * kAlignWaves, wave_id = (uint64_t)blockIdx.x * kAlignWaves + wave;
+    const int open = args.open, ext = args.extend;
+    const size_t elem = job.out_elem64 ? 8 : 4;
+    unsigned long long cells = 0, syms = 0;
+    uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
+
+    if (!job.cross) {
+        // ---- pairwise: 64 consecutive pairs per item, tape order -------------------------------------------------------------------
+        const uint64_t items = (job.pairs + 63) / 64;
+        for (uint64_t item = wave_id; item < items; item += waves_total) {
+            const uint64_t p = item * 64 + (uint64_t)lane;
+            const bool have = p < job.pairs;
+            uint64_t a0 = 0, b0 = 0;
+            uint32_t la = 0, lb = 0;
+            if (have) { align_extent(job.a.offsets, args.off64, p, a0, la); align_extent(job.b.offsets, args.off64, p, b0, lb); }
+            uint32_t aw[W / 4], bw[W / 4];
+            align_fetch<W / 4>(a_data, a0, a_total, aw);
+            align_fetch<W / 4>(b_data, b0, b_total, bw);
+            const bool fits = have && la <= (uint32_t)W && lb <= (uint32_t)W;
+            if (have && !fits) misfit = 1;
+            const bool runs = fits && la && lb;
+            const uint32_t m = runs ? la : 0u, n = runs ? lb : 0u;
+            const uint32_t m_max = wave_max_u32(m), n_max = wave_max_u32(n);
+            uint32_t acls[W / 4], bcls[W / 4], sel[(W / 4) * PQ];
+            align_classes<W / 4>(lclass_of, aw, m_max, acls);
+            align_classes<W / 4>(lclass_of, bw, n_max, bcls);
+            align_selectors<W, PQ, kLocal>(bcls, n, sel);
+            int score = align_rows<W, PQ, kAffine, kLocal>(acls, m, m_max, sel, n, n_max, ltable, open, ext);
+            if (fits) {
+                if (!runs) score = align_trivial(la, lb, kLocal, open, ext);
+                char *dst = job.out + p * job.out_stride;
+                if (job.out_elem64) *(int64_t *)dst = (int64_t)score;
+                else *(int32_t *)dst = score;
+                shorts += 1;
+            }
+            if (have) {
+                cells += (unsigned long long)la * lb;
+                syms += (unsigned long long)la + lb;
+                maxa = la > maxa ? la : maxa;
+                maxb = lb > maxb ? lb : maxb;
+            }
+        }
+    } else {
+        // ---- queries x candidates: a wave keeps 64 candidates (columns) and walks a block of queries (rows) over them --------------
+        AlignWaveLds &wl = wave_lds[wave];
+        const uint64_t chunks = (nb + 63) / 64, qblocks = (na + kAlignQueries - 1) / kAlignQueries;
+        const uint64_t items = chunks * qblocks;
+        for (uint64_t item = wave_id; item < items; item += waves_total) {
+            const uint64_t chunk = item / qblocks, qb = item - chunk * qblocks;
+            const uint64_t q_first = qb * kAlignQueries, q_last = q_first + kAlignQueries < na ? q_first + kAlignQueries : na;
+            const uint32_t q_count = (uint32_t)(q_last - q_first);
+            const uint64_t cand = chunk * 64 + (uint64_t)lane;
+            const bool have = cand < nb;
+            uint64_t b0 = 0;
+            uint32_t lb = 0;
+            if (have) align_extent(job.b.offsets, args.off64, cand, b0, lb);
+            // queries: lane l stages bytes 8 (l % 4) .. + 7 of query l / 4 as classes (16 queries x 32 bytes = 64 lanes x 8 bytes)
+            const uint32_t ql = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
+            uint64_t qa0 = 0;
+            uint32_t qm = 0;
+            if (ql < q_count) align_extent(job.a.offsets, args.off64, q_first + ql, qa0, qm);
+            uint32_t staged[2] = {0, 0};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t at = part * 8 + (uint32_t)t;
+                const uint32_t byte = (at < qm && qm <= (uint32_t)W) ? a_data[qa0 + at] : 0u;
+                staged[t >> 2] |= byte << (8 * (t & 3));
+            }
+            uint32_t bw[W / 4];
+            align_fetch<W / 4>(b_data, b0, b_total, bw);
+            const bool fits = have && lb <= (uint32_t)W;
+            if (have && !fits) misfit = 1;
+            const uint32_t n = fits ? lb : 0u;
+            const uint32_t n_max = wave_max_u32(n);
+            uint32_t bcls[W / 4], sel[(W / 4) * PQ];
+            align_classes<W / 4>(lclass_of, bw, n_max, bcls);
+            align_selectors<W, PQ, kLocal>(bcls, n, sel);
+            {
+                uint32_t scls[2];
+                align_classes<2>(lclass_of, staged, 8, scls);
+                wave_lds_fence();                              // the previous item's readers are done with the staging area
+                wl.qcls[ql][part * 2] = scls[0];
+                wl.qcls[ql][part * 2 + 1] = scls[1];
+                if (part == 0) wl.qlen[ql] = ql < q_count ? qm : 0u;
+                wave_lds_fence();
+            }
+            unsigned long long sum_m = 0;
+            uint32_t item_maxa = 0;
+            for (uint32_t q = 0; q < q_count; ++q) {
+                const uint32_t qlen = wl.qlen[q];
+                sum_m += qlen;
+                item_maxa = qlen > item_maxa ? qlen : item_maxa;
+                if (qlen > (uint32_t)W) { misfit = 1; continue; }
+                uint32_t acls[W / 4];
+#pragma unroll
+                for (int w4 = 0; w4 < W / 4; ++w4) acls[w4] = wl.qcls[q][w4];
+                const uint32_t m = (n && qlen) ? qlen : 0u;
+                int score = align_rows<W, PQ, kAffine, kLocal>(acls, m, qlen, sel, n, n_max, ltable, open, ext);
+                if (fits) {
+                    if (!m) score = align_trivial(qlen, lb, kLocal, open, ext);
+                    char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
+                    if (job.out_elem64) *(int64_t *)dst = (int64_t)score;
+                    else *(int32_t *)dst = score;
+                }
+            }
+            if (have) {
+                cells += sum_m * (unsigned long long)lb;
+                maxb = lb > maxb ? lb : maxb;
+                if (qb == 0) syms += lb;                                  // every candidate once ...
+                if (fits) shorts += q_count;
+            }
+            if (lane == 0) {
+                maxa = item_maxa > maxa ? item_maxa : maxa;
+                if (chunk == 0) syms += sum_m;                            // ... and every query once (bench.rs:216-224)
+            }
+        }
+    }
+    // ---- summary ---------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cells += __shfl_xor(cells, off);
+        syms += __shfl_xor(syms, off);
+        shorts += __shfl_xor(shorts, off);
+        misfit |= __shfl_xor(misfit, off);
+        const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+        maxa = oa > maxa ? oa : maxa;
+        maxb = ob > maxb ? ob : maxb;
+    }
+    if (lane == 0) {
+        atomicAdd(&lcells, cells);
+        atomicAdd(&lsyms, syms);
+        atomicAdd(&lshorts, shorts);
+        atomicMax(&lmaxa, maxa);
+        atomicMax(&lmaxb, maxb);
+        atomicOr(&lmisfit, misfit);
+    }
+    __syncthreads();
+    report_call_summary(PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, lmisfit}, args.partials, args.done_counter, args.summary, summary_lds);
+}
+
+template <int W, int PQ>
+static void launch_align_short_model(Scope *scope, const AlignShortArgs &args, bool affine, bool local, uint32_t blocks, const char *&name) {
+    const dim3 grid(blocks), block(kAlignWaves * 64);
+    if (!affine && !local) { name = W == 16 ? "align_short_w16" : "align_short_w32"; }
+    else if (affine && !local) { name = W == 16 ? "align_short_affine_w16" : "align_short_affine_w32"; }
+    else if (!affine) { name = W == 16 ? "align_short_local_w16" : "align_short_local_w32"; }
+    else { name = W == 16 ? "align_short_affine_local_w16" : "align_short_affine_local_w32"; }
+    StampGuard guard(scope, name);
+    if (!affine && !local) hipLaunchKernelGGL((k_align_short<W, PQ, false, false>), grid, block, 0, scope->stream, args);
+    else if (affine && !local) hipLaunchKernelGGL((k_align_short<W, PQ, true, false>), grid, block, 0, scope->stream, args);
+    else if (!affine) hipLaunchKernelGGL((k_align_short<W, PQ, false, true>), grid, block, 0, scope->stream, args);
+    else hipLaunchKernelGGL((k_align_short<W, PQ, true, true>), grid, block, 0, scope->stream, args);
+    SWH_HIP_CHECK(hipGetLastError());
+}
+
+void launch_align_short(Scope *scope, const KernelArgs &k, uint32_t longest) {
+    AlignShortArgs args{};
+    args.job = k.job; args.off64 = k.off64;
+    args.open = k.scoring.open; args.extend = k.scoring.extend;
+    args.class_table = k.scoring.class_table;
+    args.partials = scope->plan_partials; args.done_counter = scope->done_counter; args.summary = scope->summary_target();
+    const Job &job = k.job;
+    const uint64_t items = job.cross ? ((job.b.count + 63) / 64) * ((job.a.count + kAlignQueries - 1) / kAlignQueries) : (job.pairs + 63) / 64;
+    const uint64_t blocks64 = (items + kAlignWaves - 1) / kAlignWaves;
+    uint32_t max_blocks = (uint32_t)scope->compute_units * 8;
+    if (max_blocks > (uint32_t)kMaxPartials) max_blocks = kMaxPartials;
+    const uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)(blocks64 ? blocks64 : 1);
+    const bool affine = k.affine != 0, local = k.local != 0;
+    const bool few = k.scoring.classes && k.scoring.classes <= 8;   // every class in the first two dwords of a cost row
+    const char *name = nullptr;
+    if (longest <= 16) {
+        if (few) launch_align_short_model<16, 1>(scope, args, affine, local, blocks, name);
+        else launch_align_short_model<16, 4>(scope, args, affine, local, blocks, name);
+    } else {
+        if (few) launch_align_short_model<32, 1>(scope, args, affine, local, blocks, name);
+        else launch_align_short_model<32, 4>(scope, args, affine, local, blocks, name);
+    }
+}
+
+}  // namespace swh

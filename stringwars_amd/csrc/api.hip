@@ -248,7 +248,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
 }
 
 // Which kernels a unit-cost Levenshtein call runs on.
-enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort, kRouteShortTiled, kRouteCrossShort };
+enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort, kRouteShortTiled, kRouteCrossShort, kRouteAlignShort };
 
 // Strings up to this many symbols (G <= 8 blocks) are scored by the tiled kernel when their lengths are known; beyond it
 // a tile holds too few pairs per block count and the global sort of the planned path packs the waves better.
@@ -405,6 +405,21 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                     route = (longest <= 32 && !utf8 && short_route_choice() != 2)
                                 ? (spec.cross ? kRouteCrossShort : (longest <= 16 && pairs >= short_tiled_min_pairs() && short_route_choice() == 0 ? kRouteShortTiled : kRouteDirectShort))
                                 : kRouteTiled;
+            }
+        }
+
+        // Alignment scores on a class table when both tapes hold word-sized strings only (the reference's default `words` token mode,
+        // bench.rs:271): one pair per lane, no pre-pass (alignshort.hip). STRINGWARS_AMD_ALIGN_SHORT=0 keeps them on the planned path.
+        static const bool align_short_on = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_SHORT"); return !e || atoi(e) != 0; }();
+        if (engine->kind != 0 && engine->scoring.class_table && !utf8 && !spec.force_planned && align_short_on) {
+            bool known = false;
+            uint32_t la_max = 0, lb_max = 0;
+            if (prepared) { known = guaranteed = true; la_max = spec.pa->longest_bytes; lb_max = spec.pb->longest_bytes; }
+            else if (scope->hint_lengths) { known = true; la_max = scope->hint_max_la; lb_max = scope->hint_max_lb; }
+            const bool can_verify = !scope->async || !dev_out;
+            if (known && (guaranteed || can_verify) && la_max <= 32 && lb_max <= 32) {
+                route = kRouteAlignShort;
+                longest = la_max > lb_max ? la_max : lb_max;
             }
         }
 
@@ -569,6 +584,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 launch_short_tiled(scope, job, off64, mean_x16);
             }
             else if (route == kRouteCrossShort) launch_cross_short(scope, job, off64);
+            else if (route == kRouteAlignShort) launch_align_short(scope, k, longest);
             else launch_bitparallel_tiled(scope, k, pairs, longest);
             if (invalid_dev) SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));
             copy_results_back();

@@ -456,6 +456,8 @@ constexpr int kNwProfileFirstWide = 3;
 uint32_t nwprofile_waves(const Scope *scope, uint32_t classes);   // waves of a launch = boundary areas it needs
 void launch_nwprofile(Scope *scope, KernelArgs args, uint32_t first, uint32_t count);
 int wavefront_strip_cap();
+// alignshort.hip: NW / SW scores on a class table, both strings <= 32 bytes (`longest`: of both tapes), one pair per lane; plan-free
+void launch_align_short(Scope *scope, const KernelArgs &args, uint32_t longest);
 
 // UTF-8 staging: decodes a byte tape into u32 code points + u64 code-point offsets.
 constexpr int kUtf8Pass = 1024, kUtf8Passes = 8;     // a block walks its tile in passes of 256 threads x one dword

@@ -1789,3 +1789,96 @@ def test_bench_single_process_mode():
     line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 3 and line["mode"] == "single-process" and line["scaling"] == "strong" and line["parity_vs_oracle"] is True
     assert line["config"]["shard_cuts"][0] == 0 and line["config"]["shard_cuts"][-1] == 900000 and line["value"] > 0
+
+
+@pytest.mark.parametrize("local", [False, True])
+@pytest.mark.parametrize("gaps", [(-2, -2), (-5, -1), (-4, -4), (-11, -1)])
+@pytest.mark.parametrize("classes", [4, 8, 21, 32])
+def test_word_sized_alignment_kernel(sw, orc, scope, local, gaps, classes):
+    """alignshort.hip: NW / SW scores of strings of at most 32 bytes on a class table, one pair per lane -- the reference's
+    default `words` token mode (bench.rs:271; its rows: perform_linear_benchmarks / perform_affine_benchmarks, bench.rs:641-699,
+    :967-1026). Every length 0..32 on both sides (16- and 32-column variants), <= 8 classes (one v_perm per four columns) and up to
+    32 (four), asymmetric class costs, linear and affine gaps, global and local, pairwise (prepared tapes, u32 and u64 offsets; raw
+    tapes once the scope has seen their lengths) and the cross-product entry point, against the oracle's Gotoh; then a batch with one
+    string of 33 bytes: the kernel refuses it, the call is redone on the planned path."""
+    rng = np.random.default_rng(classes * 131 + gaps[0] * 7 + local)
+    byte_to_class = rng.integers(0, classes, 256).astype(np.uint8)
+    costs = np.zeros((32, 32), dtype=np.int8)
+    costs[:classes, :classes] = rng.integers(-9, 12, (classes, classes))            # asymmetric on purpose
+    full = costs[byte_to_class][:, byte_to_class].astype(np.int8)
+    Engine = sw.SmithWatermanScores if local else sw.NeedlemanWunschScores
+    engine = Engine(byte_to_class, costs, open=gaps[0], extend=gaps[1], capabilities=scope)
+
+    def want_pairs(xs, ys):
+        return np.array([orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for x, y in zip(xs, ys)], dtype=np.int64)
+
+    for longest in (16, 32):
+        lengths = list(range(0, longest + 1))
+        items_a, items_b = random_pairs(rng, 700, lengths, 256, related=0.4)
+        items_a = [x[:longest] for x in items_a]
+        items_b = [x[:longest] for x in items_b]
+        items_a += [b"", b"", bytes(range(longest)), bytes(longest)]
+        items_b += [b"", bytes(range(3)), bytes(range(longest)), bytes(range(longest))]
+        a, b = sw.Strs(items_a), sw.Strs(items_b)
+        want = want_pairs(items_a, items_b)
+        for offsets in (np.uint32, np.uint64):
+            pa, pb = sw.PreparedTape(scope, a.with_offsets(offsets)), sw.PreparedTape(scope, b.with_offsets(offsets))
+            scope.set_profiling(True)
+            got = engine.pairs(pa, pb, scope)
+            timing = scope.last_timing()
+            scope.set_profiling(False)
+            assert timing["dominant_name"].startswith("align_short") and timing["dominant_name"].endswith(f"w{longest}"), timing
+            assert timing["cells"] == int((a.lengths.astype(np.int64) * b.lengths.astype(np.int64)).sum())
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (longest, offsets, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+            # sub-views of the prepared tapes (items that start in the middle of a wave's 64 pairs)
+            assert (engine.pairs(pa[37:500], pb[37:500], scope) == want[37:500]).all()
+        # raw tapes: the first call plans (and learns the lengths), the second takes the lane-per-pair kernel; same scores
+        fresh = sw.DeviceScope(gpu_device=0)
+        first = engine.pairs(a, b, fresh)
+        fresh.set_profiling(True)
+        second = engine.pairs(a, b, fresh)
+        assert fresh.last_timing()["dominant_name"].startswith("align_short"), fresh.last_timing()
+        fresh.set_profiling(False)
+        assert (first == want).all() and (second == want).all()
+        # queries x candidates (compute_into, bench.rs:478-486): more queries than one item holds, candidates beyond one chunk of 64
+        q, c = sw.Strs(items_a[:41]), sw.Strs(items_b[100:231])
+        pq, pc = sw.PreparedTape(scope, q), sw.PreparedTape(scope, c)
+        scope.set_profiling(True)
+        matrix = engine(pq, pc, scope)
+        assert scope.last_timing()["dominant_name"].startswith("align_short"), scope.last_timing()
+        scope.set_profiling(False)
+        want_matrix = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in items_b[100:231]] for x in items_a[:41]])
+        assert matrix.shape == (41, 131) and (matrix == want_matrix).all()
+    # one string too long for the kernel among word-sized ones, on a scope that believes in word-sized strings: refused, redone
+    fresh = sw.DeviceScope(gpu_device=0)
+    items_a, items_b = random_pairs(rng, 300, list(range(0, 17)), 256)
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    assert (engine.pairs(a, b, fresh) == want_pairs(items_a, items_b)).all()
+    items_a[150] = bytes(rng.integers(0, 256, 33, dtype=np.uint8))
+    a = sw.Strs(items_a)
+    assert (engine.pairs(a, b, fresh) == want_pairs(items_a, items_b)).all()
+    items_b[7] = bytes(rng.integers(0, 256, 90, dtype=np.uint8))
+    q, c = sw.Strs(items_a[:20]), sw.Strs(items_b[:70])
+    want_matrix = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in items_b[:70]] for x in items_a[:20]])
+    assert (engine(q, c, fresh) == want_matrix).all()
+
+
+def test_word_sized_alignment_reference_rows(sw, orc, scope):
+    """The reference's own alignment rows on word-sized tokens: `unary_class_costs(2, -1)` (bench.rs:98-108: class = byte % 32, so
+    all 32 classes are in play), linear (-2, -2) and affine (-5, -1) gaps (bench.rs:640, :966), NW and SW, a 300 x 300 cross-product of
+    the synthetic words -- every score against the oracle."""
+    a, b = sw.generate_pairs("words16", 600, seed=5)
+    queries, candidates = a.subview(0, 300), b.subview(300, 600)
+    byte_to_class, costs = sw.unary_class_costs(2, -1)
+    full = np.array([[costs[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+    for Engine, local in ((sw.NeedlemanWunschScores, False), (sw.SmithWatermanScores, True)):
+        for gaps in ((-2, -2), (-5, -1)):
+            engine = Engine(byte_to_class, costs, open=gaps[0], extend=gaps[1], capabilities=scope)
+            first = engine(queries, candidates, scope)           # raw host tapes: plans, learns the lengths
+            scope.set_profiling(True)
+            again = engine(queries, candidates, scope)
+            assert scope.last_timing()["dominant_name"].startswith("align_short"), scope.last_timing()
+            scope.set_profiling(False)
+            want = np.array([[orc.nw_score(queries[i], candidates[j], full, gaps[0], gaps[1], local=local) for j in range(300)] for i in range(300)])
+            assert (first == want).all() and (again == want).all(), (local, gaps)

@@ -100,6 +100,57 @@ __device__ __forceinline__ void align_selectors(const uint32_t (&cls)[W / 4], ui
     }
 }
 
+// One group of four cells of one DP row, updated in place: `H` holds the row above on entry (the previous row's values) and this
+// row's on exit. `c4` = the four substitution scores (biased as the table is), `diag` / `left` / `e` travel along the row. The four
+// diagonal sums read the OLD row before any cell of the group is overwritten; the last instruction of a cell has H[k] as a tied
+// operand so that the row never moves to other registers (wavefront.hip: in-place strips).
+template <int W, bool kAffine, bool kLocal>
+__device__ __forceinline__ void align_group(int (&H)[W], int (&F)[kAffine ? W : 1], int g4, uint32_t c4, int &diag, int &left, int &e, int &best,
+                                            int open, int ext, int open_minus_ext) {
+    constexpr bool kSkew = !kAffine && !kLocal;          // U = H - (r + k) g:  U = max3(U_diag + (s - 2g), U_up, U_left), boundaries 0
+    constexpr bool kSkewAffine = kAffine && !kLocal;     // strips hold H^ + (open - ext): see wavefront.hip
+    int t[4];
+    t[0] = diag + (int)(int8_t)c4;
+    t[1] = H[g4] + (int)(int8_t)(c4 >> 8);
+    t[2] = H[g4 + 1] + (int)(int8_t)(c4 >> 16);
+    t[3] = H[g4 + 2] + (int)(int8_t)(c4 >> 24);
+    diag = H[g4 + 3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = g4 + u;
+        if constexpr (kSkew) {
+            asm("v_max3_i32 %0, %1, %0, %2" : "+v"(H[k]) : "v"(t[u]), "v"(left));
+        } else if constexpr (kSkewAffine) {
+            const int f = max(H[k], F[k]);
+            F[k] = f;
+            e = max(left, e);
+            const int h3 = max(max(t[u], e), f);
+            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open_minus_ext));
+        } else if constexpr (kAffine) {   // local, Gotoh: strips hold H + open
+            const int f = max(H[k], F[k] + ext);
+            F[k] = f;
+            e = max(left, e + ext);
+            const int h3 = max(max(max(t[u], e), f), 0);
+            best = max(best, h3);
+            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open));
+        } else {                          // local, linear
+            const int h3 = max(max(max(t[u], H[k]), left), 0);
+            best = max(best, h3);
+            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open));
+        }
+        left = H[k];
+    }
+}
+
+template <int PQ>
+__device__ __forceinline__ uint32_t align_costs4(const uint4 &r_lo, const uint4 &r_hi, const uint32_t *sg) {
+    uint32_t c4 = __builtin_amdgcn_perm(r_lo.y, r_lo.x, sg[0]);
+    if constexpr (PQ > 1) c4 |= __builtin_amdgcn_perm(r_lo.w, r_lo.z, sg[PQ > 1 ? 1 : 0]);
+    if constexpr (PQ > 2) c4 |= __builtin_amdgcn_perm(r_hi.y, r_hi.x, sg[PQ > 2 ? 2 : 0]);
+    if constexpr (PQ > 3) c4 |= __builtin_amdgcn_perm(r_hi.w, r_hi.z, sg[PQ > 3 ? 3 : 0]);
+    return c4;
+}
+
 // The rows of one pair (lane): `acls` the a string's classes, m rows of it, n columns prepared in `sel`; m_max / n_max are the
 // wave's maxima (uniform loop bounds). Returns the score of the global alignment or the best local one; pairs with an empty
 // side are the caller's.
@@ -179,6 +230,73 @@ __device__ __forceinline__ int align_rows(const uint32_t (&acls)[W / 4], uint32_
                 }
             }
         }
+    }
+    if constexpr (kLocal) return best;
+    int result = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+        if ((uint32_t)k + 1 == n) result = H[k];
+    if constexpr (kSkew) result += (int)(m + n) * ext;
+    else result += (int)(m + n) * ext - open_minus_ext;
+    return result;
+}
+
+// The same when the WHOLE WAVE walks the same rows (queries x candidates: one query against 64 candidates): `rowcls` points at
+// the query's class bytes in LDS, every lane runs all `m` rows (lanes without a candidate compute something nobody looks at), and
+// rows are processed TWO AT A TIME, the second one group of four columns behind the first. A row is a chain of W dependent
+// maxima inside one lane, and a wave issues a dependent instruction only every ~8 cycles (tools/valu_chain.hip): with two or
+// three waves per SIMD (a 128-column row and its selectors fill the register file) the chain, not the issue rate, set the pace.
+// Row i + 1's group g - 1 needs row i's values of columns 4g - 5 .. 4g - 1: what row i wrote one step earlier, still in place --
+// the pair shares ONE register row, its two chains are independent, and the instruction count is unchanged.
+template <int W, int PQ, bool kAffine, bool kLocal>
+__device__ __forceinline__ int align_rows_uniform(const uint8_t *rowcls, uint32_t m, const uint32_t (&sel)[(W / 4) * PQ], uint32_t n, uint32_t n_max,
+                                                  const char *ltable, uint32_t row_bytes, int open, int ext) {
+    constexpr bool kSkew = !kAffine && !kLocal;
+    const int open_minus_ext = open - ext;
+    int H[W];
+    int F[kAffine ? W : 1];
+    const int row0 = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        H[k] = row0;
+        if constexpr (kAffine) F[k] = kAlignNegInf;
+    }
+    int best = 0;
+    // a row's costs: `row_bytes` = 32 (the class table itself) or 8 (a table compacted to the classes in use: PQ == 1, r_lo.x / .y)
+    auto fetch = [&](uint32_t row, uint4 &lo, uint4 &hi) {
+        const uint32_t rc = row < m ? rowcls[row] : 0u;
+        if (row_bytes == 8) { const uint2 v = *(const uint2 *)(ltable + rc * 8); lo = make_uint4(v.x, v.y, 0, 0); }
+        else {
+            lo = *(const uint4 *)(ltable + rc * 32);
+            if constexpr (PQ > 2) hi = *(const uint4 *)(ltable + rc * 32 + 16);
+        }
+    };
+    uint4 a_lo{0, 0, 0, 0}, a_hi{0, 0, 0, 0}, b_lo{0, 0, 0, 0}, b_hi{0, 0, 0, 0};
+    fetch(0, a_lo, a_hi);
+    fetch(1, b_lo, b_hi);
+    const int edge = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);
+    uint32_t i = 0;
+    for (; i + 1 < m; i += 2) {
+        const uint4 ra_lo = a_lo, ra_hi = a_hi, rb_lo = b_lo, rb_hi = b_hi;
+        fetch(i + 2, a_lo, a_hi);      // the next pair's costs are requested before this pair's cells
+        fetch(i + 3, b_lo, b_hi);
+        int left_a = edge, left_b = edge, e_a = kAlignNegInf, e_b = kAlignNegInf;
+        int diag_a = kLocal ? open : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext)), diag_b = edge;
+#pragma unroll
+        for (int g4 = 0; g4 <= W; g4 += 4) {
+            if (g4 < W && (uint32_t)g4 < n_max)
+                align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<PQ>(ra_lo, ra_hi, sel + (g4 >> 2) * PQ), diag_a, left_a, e_a, best, open, ext, open_minus_ext);
+            if (g4 >= 4 && (uint32_t)(g4 - 4) < n_max)
+                align_group<W, kAffine, kLocal>(H, F, g4 - 4, align_costs4<PQ>(rb_lo, rb_hi, sel + ((g4 - 4) >> 2) * PQ), diag_b, left_b, e_b, best, open, ext, open_minus_ext);
+        }
+    }
+    if (i < m) {   // an odd row count: the last row on its own
+        int left = edge, e = kAlignNegInf;
+        int diag = kLocal ? open : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext));
+#pragma unroll
+        for (int g4 = 0; g4 < W; g4 += 4)
+            if ((uint32_t)g4 < n_max)
+                align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<PQ>(a_lo, a_hi, sel + (g4 >> 2) * PQ), diag, left, e, best, open, ext, open_minus_ext);
     }
     if constexpr (kLocal) return best;
     int result = 0;
@@ -313,6 +431,8 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
                 sum_m += qlen;
                 item_maxa = qlen > item_maxa ? qlen : item_maxa;
                 if (qlen > (uint32_t)W) { misfit = 1; continue; }
+                // (rows two at a time -- align_rows_uniform -- pay for strings of ~100 symbols; on words of ~5 the pair's extra step
+                // and registers cost more than the second chain returns: 2048 x 2048 words 1.40 -> 1.00 TCUPS, measured)
                 uint32_t acls[W / 4];
 #pragma unroll
                 for (int w4 = 0; w4 < W / 4; ++w4) acls[w4] = wl.qcls[q][w4];
@@ -338,6 +458,181 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
         }
     }
     // ---- summary ---------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cells += __shfl_xor(cells, off);
+        syms += __shfl_xor(syms, off);
+        shorts += __shfl_xor(shorts, off);
+        misfit |= __shfl_xor(misfit, off);
+        const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+        maxa = oa > maxa ? oa : maxa;
+        maxb = ob > maxb ? ob : maxb;
+    }
+    if (lane == 0) {
+        atomicAdd(&lcells, cells);
+        atomicAdd(&lsyms, syms);
+        atomicAdd(&lshorts, shorts);
+        atomicMax(&lmaxa, maxa);
+        atomicMax(&lmaxb, maxb);
+        atomicOr(&lmisfit, misfit);
+    }
+    __syncthreads();
+    report_call_summary(PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, lmisfit}, args.partials, args.done_counter, args.summary, summary_lds);
+}
+
+// ---- queries x candidates on strings of up to 128 symbols over a SMALL alphabet (DNA: the reference's ACGT datasets, README.md:38) ---
+// A row of 128 cells still fits a lane's registers when nothing else has to: the v_perm selectors of a 32-class table are four
+// registers per four columns, as many as the cells themselves. So the classes are COMPACTED per work item: the (at most eight)
+// classes that occur in the item's 64 candidates get the ids 0..7, a 32 x 8 byte cost table for them is built in LDS (256 bytes per
+// wave), every row fetches its eight costs with one broadcast `ds_read_b64`, and a group of four columns needs ONE selector and
+// ONE v_perm: 2.5 instructions per cell (perm / 4 + sdwa add + max3 + a quarter move), 160 registers for the row and its
+// selectors. An item whose candidates use more than eight classes raises `violation` (the call is redone on the planned path and
+// the scope stops trying). Linear gaps only (Gotoh's second row would not fit), global and local.
+struct AlignWideLds {
+    uint32_t qlen[kAlignQueries];
+    uint8_t qcls[kAlignQueries][128];    // the item's queries as class bytes
+    uint8_t ctab[32][8];                 // cost of (row class, compact column class)
+    uint8_t cid[32];                     // class -> compact id
+};
+
+template <int W, bool kLocal>
+__global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShortArgs args) {
+    __shared__ __attribute__((aligned(16))) char ltable[kClassLdsBytes];
+    __shared__ __attribute__((aligned(16))) AlignWideLds wave_lds[kAlignWaves];
+    __shared__ SummaryLds summary_lds;
+    __shared__ unsigned long long lcells, lsyms;
+    __shared__ uint32_t lmaxa, lmaxb, lshorts, lmisfit;
+    {
+        const uint32_t *src = (const uint32_t *)args.class_table;
+        for (int i = threadIdx.x; i < (int)kClassLdsBytes / 4; i += blockDim.x) ((uint32_t *)ltable)[i] = src[i];
+    }
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; lmisfit = 0; }
+    __syncthreads();
+    const uint8_t *lclass_of = (const uint8_t *)ltable + 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    AlignWideLds &wl = wave_lds[wave];
+    const Job &job = args.job;
+    const uint8_t *a_data = (const uint8_t *)job.a.data, *b_data = (const uint8_t *)job.b.data;
+    const uint64_t na = job.a.count, nb = job.b.count;
+    uint64_t a_total, b_total;
+    { uint32_t unused; align_extent(job.a.offsets, args.off64, na, a_total, unused); align_extent(job.b.offsets, args.off64, nb, b_total, unused); }
+    const uint64_t waves_total = (uint64_t)gridDim.x * kAlignWaves, wave_id = (uint64_t)blockIdx.x * kAlignWaves + wave;
+    const int open = args.open, ext = args.extend;
+    const size_t elem = job.out_elem64 ? 8 : 4;
+    unsigned long long cells = 0, syms = 0;
+    uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
+    const uint64_t chunks = (nb + 63) / 64, qblocks = (na + kAlignQueries - 1) / kAlignQueries;
+    const uint64_t items = chunks * qblocks;
+    for (uint64_t item = wave_id; item < items; item += waves_total) {
+        const uint64_t chunk = item / qblocks, qb = item - chunk * qblocks;
+        const uint64_t q_first = qb * kAlignQueries, q_last = q_first + kAlignQueries < na ? q_first + kAlignQueries : na;
+        const uint32_t q_count = (uint32_t)(q_last - q_first);
+        const uint64_t cand = chunk * 64 + (uint64_t)lane;
+        const bool have = cand < nb;
+        uint64_t b0 = 0;
+        uint32_t lb = 0;
+        if (have) align_extent(job.b.offsets, args.off64, cand, b0, lb);
+        const bool fits = have && lb <= (uint32_t)W;
+        if (have && !fits) misfit = 1;
+        const uint32_t n = fits ? lb : 0u;
+        const uint32_t n_max = wave_max_u32(n);
+        // -- my candidate: bytes -> classes (packed four to a dword), and the set of classes it uses
+        uint32_t bcls[W / 4];
+        uint32_t used = 0;
+        {
+            uint32_t bw[W / 4];
+            align_fetch<W / 4>(b_data, b0, b_total, bw);
+            align_classes<W / 4>(lclass_of, bw, n_max, bcls);
+#pragma unroll
+            for (int g = 0; g < W / 4; ++g) {
+                if ((uint32_t)(4 * g) < n_max) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if ((uint32_t)(4 * g + u) < n) used |= 1u << ((bcls[g] >> (8 * u)) & 31u);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) used |= (uint32_t)__shfl_xor((int)used, off);
+        const bool compact = __popc(used) <= 8;
+        if (!compact) misfit = 1;
+        // -- the item's queries into LDS as class bytes: lane l stages bytes 16 (l % 8) .. + 15 of query l / 8, two rounds of eight queries
+        wave_lds_fence();                                  // the previous item's readers are done with the staging area
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            const uint32_t ql = (uint32_t)round * 8 + ((uint32_t)lane >> 3), part = (uint32_t)lane & 7u;
+            uint64_t qa0 = 0;
+            uint32_t qm = 0;
+            if (ql < q_count) align_extent(job.a.offsets, args.off64, q_first + ql, qa0, qm);
+            uint32_t staged[4] = {0, 0, 0, 0};
+            if (16 * part < qm && qm <= (uint32_t)W) {
+                ByteWindow win;
+                win.init(a_data, qa0 + 16 * part, a_total);
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) staged[w4] = win.fetch4(4 * w4);
+            }
+            uint32_t scls[4];
+            align_classes<4>(lclass_of, staged, 16, scls);
+            if (16 * part < (uint32_t)W) *(uint4 *)(wl.qcls[ql] + 16 * part) = make_uint4(scls[0], scls[1], scls[2], scls[3]);
+            if (part == 0) wl.qlen[ql] = ql < q_count ? qm : 0u;
+        }
+        // -- compaction: class -> id for the classes in use, and the 32 x 8 cost table of (row class, id)
+        if (lane < 32) {
+            wl.cid[lane] = (uint8_t)__popc(used & ((1u << lane) - 1u));
+            uint32_t rest = used, lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t cls = rest ? (uint32_t)__builtin_ctz(rest) : 0u;
+                const uint32_t cost = rest ? (uint32_t)(uint8_t)ltable[lane * 32 + cls] : 0u;
+                rest &= rest - 1u;
+                if (j < 4) lo |= cost << (8 * j); else hi |= cost << (8 * (j - 4));
+            }
+            *(uint2 *)wl.ctab[lane] = make_uint2(lo, hi);
+        }
+        wave_lds_fence();
+        // -- selectors: the compact ids of my candidate's symbols; local alignment: nothing right of the string
+        uint32_t sel[W / 4];
+#pragma unroll
+        for (int g = 0; g < W / 4; ++g) {
+            sel[g] = 0x0C0C0C0Cu;
+            if ((uint32_t)(4 * g) < n_max) {
+                const uint32_t c = bcls[g];
+                uint32_t ids = (uint32_t)wl.cid[c & 31u] | ((uint32_t)wl.cid[(c >> 8) & 31u] << 8) | ((uint32_t)wl.cid[(c >> 16) & 31u] << 16) | ((uint32_t)wl.cid[(c >> 24) & 31u] << 24);
+                ids &= 0x07070707u;
+                if constexpr (kLocal) {
+                    const uint32_t beyond = n >= (uint32_t)(4 * g + 4) ? 0u : (n <= (uint32_t)(4 * g) ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (n - 4 * g)));
+                    ids = (ids & ~beyond) | (0x0C0C0C0Cu & beyond);
+                }
+                sel[g] = ids;
+            }
+        }
+        unsigned long long sum_m = 0;
+        uint32_t item_maxa = 0;
+        for (uint32_t q = 0; q < q_count; ++q) {
+            const uint32_t qlen = wl.qlen[q];
+            sum_m += qlen;
+            item_maxa = qlen > item_maxa ? qlen : item_maxa;
+            if (qlen > (uint32_t)W) { misfit = 1; continue; }
+            if (!compact) continue;
+            int score = align_rows_uniform<W, 1, false, kLocal>(wl.qcls[q], qlen, sel, n, n_max, (const char *)&wl.ctab[0][0], 8u, open, ext);
+            if (fits) {
+                if (!n || !qlen) score = align_trivial(qlen, lb, kLocal, open, ext);
+                char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
+                if (job.out_elem64) *(int64_t *)dst = (int64_t)score;
+                else *(int32_t *)dst = score;
+            }
+        }
+        if (have) {
+            cells += sum_m * (unsigned long long)lb;
+            maxb = lb > maxb ? lb : maxb;
+            if (qb == 0) syms += lb;
+            if (fits) shorts += q_count;
+        }
+        if (lane == 0) {
+            maxa = item_maxa > maxa ? item_maxa : maxa;
+            if (chunk == 0) syms += sum_m;
+        }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         cells += __shfl_xor(cells, off);
@@ -390,6 +685,20 @@ void launch_align_short(Scope *scope, const KernelArgs &k, uint32_t longest) {
     const bool affine = k.affine != 0, local = k.local != 0;
     const bool few = k.scoring.classes && k.scoring.classes <= 8;   // every class in the first two dwords of a cost row
     const char *name = nullptr;
+    if (longest > 32) {   // (api.hip picks this only for cross-products with linear gaps)
+        const dim3 grid(blocks), block(kAlignWaves * 64);
+        name = longest <= 64 ? (local ? "align_wide_local_w64" : "align_wide_w64") : (local ? "align_wide_local_w128" : "align_wide_w128");
+        StampGuard guard(scope, name);
+        if (longest <= 64) {
+            if (local) hipLaunchKernelGGL((k_align_cross_wide<64, true>), grid, block, 0, scope->stream, args);
+            else hipLaunchKernelGGL((k_align_cross_wide<64, false>), grid, block, 0, scope->stream, args);
+        } else {
+            if (local) hipLaunchKernelGGL((k_align_cross_wide<128, true>), grid, block, 0, scope->stream, args);
+            else hipLaunchKernelGGL((k_align_cross_wide<128, false>), grid, block, 0, scope->stream, args);
+        }
+        SWH_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (longest <= 16) {
         if (few) launch_align_short_model<16, 1>(scope, args, affine, local, blocks, name);
         else launch_align_short_model<16, 4>(scope, args, affine, local, blocks, name);

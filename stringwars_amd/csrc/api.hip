@@ -417,9 +417,13 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             if (prepared) { known = guaranteed = true; la_max = spec.pa->longest_bytes; lb_max = spec.pb->longest_bytes; }
             else if (scope->hint_lengths) { known = true; la_max = scope->hint_max_la; lb_max = scope->hint_max_lb; }
             const bool can_verify = !scope->async || !dev_out;
-            if (known && (guaranteed || can_verify) && la_max <= 32 && lb_max <= 32) {
+            const uint32_t both = la_max > lb_max ? la_max : lb_max;
+            // up to 128 symbols for cross-products with linear gaps, as long as the candidates of a work item use at most eight symbol
+            // classes (DNA; the kernel checks per item, a scope that met richer text stops trying -- `align_wide_off`)
+            const bool wide = spec.cross && both <= 128 && engine->scoring.open == engine->scoring.extend && !scope->align_wide_off && can_verify;
+            if (known && (guaranteed || can_verify) && (both <= 32 || wide)) {
                 route = kRouteAlignShort;
-                longest = la_max > lb_max ? la_max : lb_max;
+                longest = both;
             }
         }
 
@@ -599,6 +603,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 if (scope->summary_host[0].violation) {
                     // the belief about the lengths was wrong (it came from an earlier batch): redo on the planned path
                     scope->hint_lengths = false;
+                    if (route == kRouteAlignShort && longest > 32) scope->align_wide_off = true;   // (or: more than eight classes in an item)
                     scope->summary_pending = false;
                     scope->stamps_pending = false;
                     CallSpec again = spec;

@@ -333,6 +333,7 @@ struct Scope {
     // Longest strings of the previous call on this scope (symbols), the basis for running the NEXT call on raw tapes
     // without a planning pre-pass; the kernels verify it per pair and raise CallSummary::violation if it no longer holds.
     bool hint_lengths = false;
+    bool align_wide_off = false;   // k_align_cross_wide met candidates with more than eight symbol classes (or longer strings): not tried again
     uint32_t hint_max_la = 0, hint_max_lb = 0;
     uint32_t hint_mean_x16 = 0;   // mean string length of the previous call, x16 (both tapes together)
     CallSummary *summary_host = nullptr;   // pinned, mapped: written by kernels, read by the host after a synchronisation

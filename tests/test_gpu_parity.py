@@ -1882,3 +1882,47 @@ def test_word_sized_alignment_reference_rows(sw, orc, scope):
             scope.set_profiling(False)
             want = np.array([[orc.nw_score(queries[i], candidates[j], full, gaps[0], gaps[1], local=local) for j in range(300)] for i in range(300)])
             assert (first == want).all() and (again == want).all(), (local, gaps)
+
+
+@pytest.mark.parametrize("local", [False, True])
+def test_small_alphabet_cross_product_up_to_128_symbols(sw, orc, scope, local):
+    """k_align_cross_wide (alignshort.hip): queries x candidates with linear gaps on strings of 33..128 symbols whose candidates use at
+    most eight symbol classes per work item (DNA under the reference's `unary_class_costs`: A, C, G, T are classes 1, 3, 7, 20) -- the
+    classes are compacted per item so that one v_perm serves four columns. Every length 0..128 on both sides, the 64- and the
+    128-column variant, a random asymmetric class table, global and local; then candidates over 26 letters: the kernel refuses
+    them, the call is redone on the planned path and the scope stops trying."""
+    rng = np.random.default_rng(77 + local)
+    Engine = sw.SmithWatermanScores if local else sw.NeedlemanWunschScores
+    byte_to_class, costs = sw.unary_class_costs(2, -1)
+    random_costs = rng.integers(-9, 12, (32, 32)).astype(np.int8)
+    for table, gaps in ((costs, (-2, -2)), (random_costs, (-3, -3))):
+        full = np.array([[table[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+        engine = Engine(byte_to_class, table, open=gaps[0], extend=gaps[1], capabilities=scope)
+        for longest in (64, 128):
+            def dna(n):
+                return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(n)))
+            queries = [dna(n) for n in list(range(0, longest + 1, 7)) + [longest, longest - 1, 1, 0, 33]]
+            candidates = [dna(n) for n in rng.integers(0, longest + 1, 150)] + [dna(longest), b"", dna(1)]
+            candidates[5] = queries[3][:longest]                                 # related strings, too
+            q, c = sw.PreparedTape(scope, sw.Strs(queries)), sw.PreparedTape(scope, sw.Strs(candidates))
+            scope.set_profiling(True)
+            got = engine(q, c, scope)
+            name = scope.last_timing()["dominant_name"]
+            scope.set_profiling(False)
+            assert name.startswith("align_wide") and name.endswith(f"w{longest}"), name
+            want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
+            bad = np.argwhere(got != want)
+            assert bad.size == 0, (longest, bad[:5], [(len(queries[i]), len(candidates[j]), got[i, j], want[i, j]) for i, j in bad[:5]])
+    # text over 26 letters: more than eight classes among a wave's candidates
+    fresh = sw.DeviceScope(gpu_device=0)
+    engine = Engine(byte_to_class, costs, open=-2, extend=-2, capabilities=fresh)
+    full = np.array([[costs[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+    words = [bytes(rng.integers(97, 123, int(n), dtype=np.uint8)) for n in rng.integers(20, 100, 90)]
+    q, c = sw.PreparedTape(fresh, sw.Strs(words[:20])), sw.PreparedTape(fresh, sw.Strs(words[20:]))
+    want = np.array([[orc.nw_score(x, y, full, -2, -2, local=local) for y in words[20:]] for x in words[:20]])
+    for _ in range(2):
+        fresh.set_profiling(True)
+        got = engine(q, c, fresh)
+        name = fresh.last_timing()["dominant_name"]
+        fresh.set_profiling(False)
+        assert (got == want).all() and not name.startswith("align_wide"), name

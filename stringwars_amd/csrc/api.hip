@@ -173,9 +173,10 @@ static uint64_t utf8_merged_bytes() {
 }
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
 static size_t utf8_scratch_words(uint64_t bytes) {
-    // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances | u64 look-back words + ticket
+    // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances
+    // (the look-back words and tickets of the one-pass kernel live in scope->utf8_status / the call's flag words)
     uint64_t tiles = (bytes + kUtf8Tile - 1) / kUtf8Tile;
-    return (size_t)((tiles + 4) + (kUtf8Subs * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4) + (tiles + 6) + 2 * (tiles + 2));
+    return (size_t)((tiles + 4) + (kUtf8Subs * tiles + 4) + 2 * (tiles + 4) + 2 * ((tiles + 1023) / 1024 + 4) + (tiles + 6));
 }
 
 static bool is_device_pointer(const void *p) {
@@ -694,7 +695,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             // alternate between two streams and run side by side (launch_wavefront), one for the profile kernel's waves
             const uint64_t stride = (uint64_t)(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb) + 64 + 16;
             const uint64_t groups = multi ? (uint64_t)scope->compute_units * 8 * 4 : 0;  // max blocks * waves (G = 64)
-            const uint64_t profile_waves = profile_count ? nwprofile_waves(scope, engine->scoring.classes ? engine->scoring.classes : 32) : 0;
+            // (one area per wave the profile launch can have: launch_nwprofile never starts more workgroups than it has pairs)
+            const uint64_t profile_waves = profile_count ? std::min<uint64_t>(nwprofile_waves(scope, engine->scoring.classes ? engine->scoring.classes : 32), profile_count) : 0;
             if (multi || profile_count) ensure(scope->boundary, scope->boundary_bytes, (2 * groups + profile_waves) * stride * 2 * sizeof(int32_t));
             if (profile_count) {
                 KernelArgs kp = k;
@@ -1087,6 +1089,7 @@ swh_status_t swh_levenshtein_init(swh_scope_t handle, int match, int mismatch, i
 swh_status_t swh_levenshtein_free(swh_levenshtein_t handle) {
     Engine *engine = (Engine *)handle;
     if (!engine) return swh_success_k;
+    if (engine->kind != 0 && engine->uid) drop_engine_clones(engine->uid);   // the per-device clones multi-device scopes made of it (sharded.hip)
     if (engine->matrix_dev) { (void)hipSetDevice(engine->device); (void)hipFree(engine->matrix_dev); }
     if (engine->class_dev) { (void)hipSetDevice(engine->device); (void)hipFree(engine->class_dev); }
     delete[] engine->matrix_host;
@@ -1124,7 +1127,7 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
     engine->uid = next_engine_uid();
     (void)hipSetDevice(scope->device);
     swh_status_t st = upload_matrix(engine, matrix, error);
-    if (st != swh_success_k) { delete engine; return st; }
+    if (st != swh_success_k) { swh_levenshtein_free((swh_levenshtein_t)engine); return st; }   // (releases matrix_host, too)
     // Symbol classes: bytes whose matrix rows AND columns coincide are interchangeable. With <= 32 classes (the
     // reference's own byte_to_class + 32x32 model, bench.rs:95-108; also 20 amino acids + "other") the kernels keep a
     // 32-byte cost row in registers per step instead of one LDS lookup per cell.

@@ -367,6 +367,7 @@ struct Scope {
 };
 
 void free_multi_scope(void *multi);   // sharded.hip
+void drop_engine_clones(uint64_t engine_uid);   // sharded.hip: an alignment engine is being freed -- its per-device clones go with it
 
 struct Engine {
     int kind;  // 0 = levenshtein, 1 = needleman-wunsch (global), 2 = smith-waterman (local)
@@ -477,7 +478,9 @@ struct Utf8Args {
     uint64_t total_bytes;
 };
 void launch_utf8_decode(Scope *scope, const Utf8Args &args);
-// the one-pass staging (default; prepass.hip) takes both tapes of a call in one go -- `invalid` must point at four zeroed words
+// the one-pass staging (default; prepass.hip) takes both tapes of a call in one go -- `invalid` must point at kUtf8FlagWords ZEROED
+// words: [0] the invalid-UTF-8 marker, [32 (1 + slot)] the launch's tile ticket (the kernel takes tickets from there: anything
+// but zero at launch is a hang or a tile never decoded)
 bool utf8_one_pass();
 void launch_utf8_decode_pair(Scope *scope, const Utf8Args &a, const Utf8Args *b, uint64_t first_word, bool opened);
 void utf8_status_open(Scope *scope, uint64_t words);

@@ -20,6 +20,8 @@
 #include <new>
 #include <unordered_map>
 
+#include <mutex>
+
 #include "common.hpp"
 #include "../../include/stringwars_amd_harness.h"
 
@@ -79,6 +81,11 @@ struct MultiScope {
     std::unordered_map<uint64_t, std::vector<void *>> engine_clones;
     swh_shard_timing_t timing{};
 };
+
+// every live multi-device scope, so that freeing an alignment engine can take its per-device clones along (a harness that builds an
+// engine per row on a long-lived scope would otherwise pile up a 64 KB matrix + a class table per device and engine)
+static std::mutex g_multi_mutex;
+static std::vector<MultiScope *> g_multi_scopes;
 
 // (sum, xor) of n distances: what the self-check of the sharded call compares between a shard's device and the gathered vector
 __global__ __launch_bounds__(256) void k_shard_checksum(const uint32_t *values, uint64_t n, unsigned long long *out) {
@@ -214,6 +221,20 @@ swh_status_t swh_scope_init_gpus(const int *devices, int count, swh_scope_t *out
         // (peers exchange results only through RCCL, which sets up its own peer mappings: no hipDeviceEnablePeerAccess here)
         if (hipSetDevice(devices[0]) != hipSuccess) return cleanup(sharded_fail(error, swh_device_error_k, "hipSetDevice failed"));
     }
+    // rows of a sharded cross-product go straight from device r into a matrix that may live on the first device: peers are mapped
+    // where the hardware allows (best effort: without it the runtime stages such copies itself)
+    if (distinct && count > 1) {
+        for (int r = 1; r < count; ++r) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[r], devices[0]) == hipSuccess && can && hipSetDevice(devices[r]) == hipSuccess) (void)hipDeviceEnablePeerAccess(devices[0], 0);
+            (void)hipGetLastError();   // (already enabled: fine)
+        }
+        (void)hipSetDevice(devices[0]);
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_multi_mutex);
+        g_multi_scopes.push_back(multi.get());
+    }
     ((Scope *)parent)->multi = multi.release();
     *out = parent;
     return swh_success_k;
@@ -236,9 +257,27 @@ swh_status_t swh_scope_shard_timing(swh_scope_t handle, swh_shard_timing_t *timi
 }  // extern "C"
 
 namespace swh {
+void drop_engine_clones(uint64_t engine_uid) {
+    std::vector<void *> clones;
+    {
+        std::lock_guard<std::mutex> lock(g_multi_mutex);
+        for (MultiScope *multi : g_multi_scopes) {
+            auto it = multi->engine_clones.find(engine_uid);
+            if (it == multi->engine_clones.end()) continue;
+            clones.insert(clones.end(), it->second.begin(), it->second.end());
+            multi->engine_clones.erase(it);
+        }
+    }
+    for (void *clone : clones) if (clone) swh_nw_free((swh_nw_t)clone);   // (a clone has a uid of its own and no clones: no recursion)
+}
 void free_multi_scope(void *handle) {
     MultiScope *multi = (MultiScope *)handle;
     if (!multi) return;
+    {
+        std::lock_guard<std::mutex> lock(g_multi_mutex);
+        for (size_t i = 0; i < g_multi_scopes.size(); ++i)
+            if (g_multi_scopes[i] == multi) { g_multi_scopes.erase(g_multi_scopes.begin() + i); break; }
+    }
     RcclApi &api = rccl();
     for (ncclComm_t comm : multi->comms)
         if (comm && api.CommDestroy) api.CommDestroy(comm);

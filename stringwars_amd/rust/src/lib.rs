@@ -367,7 +367,6 @@ impl LevenshteinDistances {
         let mut message = ptr::null();
         check(unsafe { swh_levenshtein_pairs_sharded(self.handle, scope.handle, batch.handle, bound.unwrap_or(UNBOUNDED), out.as_mut_ptr(), &mut message) }, message)
     }
-    /// One-shot form: shard, upload, score, gather, free.
     /// The dense matrix of a sharded product: every device fills its rows and copies them into `matrix`.
     pub fn compute_into_sharded(&self, scope: &DeviceScope, product: &ShardedCross, matrix: &mut [usize]) -> Result<(), Error> {
         let (rows, columns) = product.shape();
@@ -375,6 +374,7 @@ impl LevenshteinDistances {
         let mut message = ptr::null();
         check(unsafe { swh_levenshtein_cross_sharded(self.handle, scope.handle, product.handle, matrix.as_mut_ptr(), columns * 8, &mut message) }, message)
     }
+    /// One-shot form: shard, upload, score, gather, free.
     pub fn pairs_into_sharded(&self, scope: &DeviceScope, a: &BytesTapeView<u64>, b: &BytesTapeView<u64>, bound: Option<u32>, out: &mut [u32]) -> Result<(), Error> {
         let (ta, tb) = (bytes_tape(a), bytes_tape(b));
         let mut message = ptr::null();

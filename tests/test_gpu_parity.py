@@ -1926,3 +1926,28 @@ def test_small_alphabet_cross_product_up_to_128_symbols(sw, orc, scope, local):
         name = fresh.last_timing()["dominant_name"]
         fresh.set_profiling(False)
         assert (got == want).all() and not name.startswith("align_wide"), name
+
+
+def test_engine_clones_go_with_their_engine(sw, orc):
+    """A multi-device scope clones an alignment engine per member on first use (its matrix lives on ONE device); freeing the engine
+    frees the clones -- a harness that builds an engine per row on a long-lived scope must not pile up matrices on every device."""
+    import torch
+    scope = sw.DeviceScope(gpu_devices=[0, 0, 0])
+    a, b = sw.generate_pairs("words16", 3000, seed=3)
+    batch = sw.ShardedPairs(scope, a, b)
+    matrix = sw.substitution_matrix(5)
+    want = orc.nw_pairs(a, b, matrix, -3, -3)
+
+    def one_engine():
+        engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=-3, extend=-3, capabilities=scope)
+        assert (engine.pairs_sharded(batch, scope) == want).all()
+        del engine
+
+    for _ in range(8):
+        one_engine()                                   # scratch of the member scopes reaches its size
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(96):
+        one_engine()                                   # 96 engines x 3 members x (64 KB matrix + class table) = 19 MB if the clones stayed
+    torch.cuda.synchronize()
+    assert free_before - torch.cuda.mem_get_info()[0] < 6 << 20

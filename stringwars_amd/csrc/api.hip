@@ -265,6 +265,11 @@ static uint64_t short_tiled_min_pairs() {
     const char *e = getenv("STRINGWARS_AMD_SHORT_MIN_PAIRS");
     return e ? (uint64_t)atoll(e) : (uint64_t)1 << 16;
 }
+// Bounds up to here may take the banded kernel (STRINGWARS_AMD_BAND_MAX=63: the one-word windows only, the comparison knob).
+static uint32_t band_max_bound() {
+    static const uint32_t most = [] { const char *e = getenv("STRINGWARS_AMD_BAND_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : kBandMaxBound; return v > kBandMaxBound ? kBandMaxBound : v; }();
+    return most;
+}
 static int short_route_choice() {
     static const int choice = [] {
         const char *e = getenv("STRINGWARS_AMD_SHORT");
@@ -400,7 +405,9 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             if (known && (guaranteed || can_verify)) {
                 longest = la_max > lb_max ? la_max : lb_max;
                 const uint32_t shorter_side = la_max < lb_max ? la_max : lb_max;
-                const bool band_pays = spec.bound <= 63 && longest > 32;   // plan_key(): the banded kernel wins from ~6 blocks at k = 32
+                // plan_key(): the banded kernel wins from ~6 blocks at k = 32 (bounds of 64 .. 255: where band_cost() says so)
+                const bool band_pays = spec.bound <= 63 ? longest > 32
+                                                        : spec.bound <= band_max_bound() && band_cost(spec.bound) < (utf8 ? 40u : 28u) * ((longest + 31) >> 5);
                 if (forced) route = (!guaranteed || shorter_side <= 2048) ? kRouteTiled : kRoutePlanned;
                 else if (!band_pays && longest <= tiled_longest_limit())
                     route = (longest <= 32 && !utf8 && short_route_choice() != 2)
@@ -541,7 +548,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         pre.unit_costs = engine->kind == 0 && engine->unit_costs ? 1 : 0;
         pre.local = engine->kind == 2 ? 1 : 0;
         pre.direct_short = bitpar_ok && sym_bytes == 1 && engine->algorithm == swh_algorithm_auto_k && scope->hint_short ? 1 : 0;
-        pre.banded = pre.unit_costs && spec.bound <= 63 && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
+        pre.banded = pre.unit_costs && spec.bound <= band_max_bound() && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
         pre.perm = perm; pre.keys = plan_keys; pre.hist = scope->plan_hist; pre.cursor = scope->plan_cursor;
         pre.partials = scope->plan_partials; pre.leftover = scope->plan_leftover; pre.plan = plan_dev;
 

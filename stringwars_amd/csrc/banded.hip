@@ -1,4 +1,4 @@
-// banded.hip -- bounded unit-cost Levenshtein (out = min(d, k+1), k <= 63) as a sliding 64-bit band.
+// banded.hip -- bounded unit-cost Levenshtein (out = min(d, k+1), k <= 127) as a sliding band of one or two 64-bit words.
 //
 // Ukkonen: an alignment with at most k edits between strings whose lengths differ by delta stays on
 // the diagonals [-(k+delta)/2, (k-delta)/2] -- at most k+1 of them. The band is kept as ONE 64-bit
@@ -10,6 +10,10 @@
 // inside the matrix and along the last row afterwards. Rows above the matrix behave like row 0 on their
 // own (VP = VN = Eq = 0 gives HP = 1), rows entering at the bottom start as "+1", which over-estimates
 // cells outside the band only -- exact whenever d <= k. Prototype + proof-by-test: DESIGN.md section 4.4.
+// Bounds of 64 .. 127 (STRINGWARS_ERROR_BOUND is free-form, README.md:311) run the same scheme on a window of NW = 2 words: bit
+// 64 NW - 1 on the bottom diagonal, the addition's carry and the one-bit shift run through the words. (The code is written for
+// any NW; three and four words were built and measured on config C3's lines -- k = 128: 1.30 ms against 1.05 for the unbounded
+// code-point kernel + the clamp, whose 16 blocks of 32 rows ARE half this matrix's band by then -- and are not instantiated.)
 //
 // Mapping to a wave64 (no tables, any symbol width -- bytes or decoded code points):
 //   phase 1  "match masks": for a chunk of 32 text symbols, lanes = (pair parity, column). Each lane
@@ -27,15 +31,17 @@ constexpr int kBandChunk = 32;                      // text symbols per chunk
 constexpr int kBandPitch = kBandChunk + 1;          // u64 per pair row in LDS
 constexpr int kBandWaves = 4;
 constexpr int kBandParamWords = 8;
-constexpr int kBandStage = 96;                      // u32 window symbols staged per half-wave (32 + WBITS max)
-// P = pairs per wave item (64, or 32 when the batch is too small to give every SIMD a few waves at 64)
-constexpr size_t band_lds_per_wave(int P) { return (size_t)P * kBandPitch * 8 + (size_t)P * kBandParamWords * 4 + 2 * kBandStage * 4; }
+constexpr int band_stage(int wbits) { return wbits <= 64 ? 96 : 32 + wbits; }   // u32 window symbols staged per half-wave
+// P = pairs per wave item (64, or 32 when the batch is too small to give every SIMD a few waves at 64; 16 for windows of three and four words)
+constexpr size_t band_lds_per_wave(int P, int wbits = 64) {
+    return (size_t)((wbits + 63) / 64) * P * kBandPitch * 8 + (size_t)P * kBandParamWords * 4 + 2 * (size_t)band_stage(wbits) * 4;
+}
 
 struct BandPair {            // per-pair parameters parked in LDS for phase 1 (uniform reads)
     uint32_t pat_lo, pat_hi; // pattern pointer
     uint32_t txt_lo, txt_hi; // text pointer
     uint32_t len1, len2;     // pattern / text length in symbols
-    int32_t start0;          // pattern index of window bit 0 at text index 0 (= dhi - 63)
+    int32_t start0;          // pattern index of window bit 0 at text index 0 (= dhi - (64 NW - 1))
     uint32_t pad;
 };
 static_assert(sizeof(BandPair) == kBandParamWords * 4, "BandPair layout");
@@ -46,7 +52,7 @@ __device__ __forceinline__ uint32_t band_load_sym(const Sym *base, int idx, int 
     return (uint32_t)base[c];
 }
 
-// WBITS = number of live window bits (a multiple of 4, >= k + 1): bits [64 - WBITS, 63].
+// WBITS = number of live window bits (a multiple of 4 up to 64, of 32 beyond; >= k + 1): bits [64 NW - WBITS, 64 NW - 1], NW = ceil(WBITS / 64).
 // P = the most pairs an item can hold (LDS layout). The recurrence is a serial chain per pair and one wave issues a dependent
 // instruction only every ~8.5 cycles, so a batch of 100 K pairs (1564 items of 64 = 1.5 waves per SIMD) ran at 11 SIMD-cycles
 // per instruction. Items of 32 pairs leave half of phase 2's lanes idle (+30 % instructions) but double the resident waves.
@@ -55,14 +61,15 @@ __device__ __forceinline__ uint32_t band_load_sym(const Sym *base, int idx, int 
 // where items of 32 left some SIMDs with four waves and some with three.
 template <typename Sym, int WBITS, int P>
 __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
-    constexpr size_t kBandLdsPerWave = band_lds_per_wave(P);
+    constexpr int NW = (WBITS + 63) / 64, kTop = 64 * NW - 1, kBandStage = band_stage(WBITS);
+    constexpr size_t kBandLdsPerWave = band_lds_per_wave(P, WBITS);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     char *wave_lds = smem + (size_t)wave_in_block * kBandLdsPerWave;
-    unsigned long long *eqbuf = (unsigned long long *)wave_lds;                   // [P][kBandPitch]
-    BandPair *params = (BandPair *)(wave_lds + (size_t)P * kBandPitch * 8);       // [P]
-    uint32_t *stage = (uint32_t *)(wave_lds + (size_t)P * kBandPitch * 8 + (size_t)P * kBandParamWords * 4);  // [2][kBandStage]
+    unsigned long long *eqbuf = (unsigned long long *)wave_lds;                   // [NW][P][kBandPitch]
+    BandPair *params = (BandPair *)(wave_lds + (size_t)NW * P * kBandPitch * 8);       // [P]
+    uint32_t *stage = (uint32_t *)(wave_lds + (size_t)NW * P * kBandPitch * 8 + (size_t)P * kBandParamWords * 4);  // [2][kBandStage]
 
     const uint32_t cstart = args.plan->class_start[cls], ccount = args.plan->class_count[cls];
     const uint32_t waves_total = gridDim.x * kBandWaves;
@@ -94,8 +101,8 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
         const Sym *txt = (const Sym *)(a_is_text ? args.job.a.data : args.job.b.data) + (a_is_text ? a0 : b0);
         const Sym *pat = (const Sym *)(a_is_text ? args.job.b.data : args.job.a.data) + (a_is_text ? b0 : a0);
         const int delta = (int)len2 - (int)len1;              // <= 0, |delta| <= k (pre-pass guarantees it)
-        const int dhi = ((int)k - delta) / 2;                 // bottom diagonal of the band, 0 <= dhi <= 63
-        const int start0 = dhi - 63;
+        const int dhi = ((int)k - delta) / 2;                 // bottom diagonal of the band, 0 <= dhi <= k <= 64 NW - 1
+        const int start0 = dhi - kTop;
         {
             BandPair bp;
             bp.pat_lo = (uint32_t)(uintptr_t)pat; bp.pat_hi = (uint32_t)((uintptr_t)pat >> 32);
@@ -106,12 +113,16 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
         wave_lds_fence();  // params are read by other lanes in phase 1
         const uint32_t n_max = wave_max_u32(have ? len2 : 0);
         // recurrence state of my pair (phase 2): rows 0..dhi of column 0 carry vertical +1
-        uint32_t vp_lo, vp_hi, vn_lo = 0, vn_hi = 0;
+        unsigned long long vp[NW], vn[NW];
         {
-            // bits b with start0 + b >= 0  <=>  b >= 63 - dhi
-            int first = 63 - dhi;
-            unsigned long long vp = first <= 0 ? ~0ull : (~0ull << first);
-            vp_lo = (uint32_t)vp; vp_hi = (uint32_t)(vp >> 32);
+            // bits b with start0 + b >= 0  <=>  b >= kTop - dhi
+            const int first = kTop - dhi;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int from = first - 64 * w;     // first set bit inside word w
+                vp[w] = from <= 0 ? ~0ull : (from >= 64 ? 0ull : (~0ull << from));
+                vn[w] = 0;
+            }
         }
         int cur = (int)len1 < dhi ? (int)len1 : dhi;
         const int diag_cols = (int)len1 - dhi;  // text indices i < diag_cols follow the bottom diagonal
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
                 const Sym *tp = (const Sym *)(((uintptr_t)bp.txt_hi << 32) | bp.txt_lo);
                 const Sym *pw = (const Sym *)(((uintptr_t)bp.pat_hi << 32) | bp.pat_lo);
                 nxt_tsym = i < bp.len2 ? (uint32_t)tp[i] : 0xFFFFFFFEu;   // past the text: matches nothing
-                const int base0 = bp.start0 + (int)i0 + (64 - WBITS);     // pattern index of window symbol 0, column 0
+                const int base0 = bp.start0 + (int)i0 + (64 * NW - WBITS);   // pattern index of window symbol 0, column 0
 #pragma unroll
                 for (int r = 0; r < kStageLoads; ++r) {
                     const int idx = base0 + col + 32 * r;
@@ -181,10 +192,19 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
                             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(tsym));
                     }
                 }
-                unsigned long long hits = 0;
+                // segment sgm holds window symbols [sgm kSegLen, (sgm + 1) kSegLen) = band bits from 64 NW - WBITS + sgm kSegLen on
+                unsigned long long hits[NW];
 #pragma unroll
-                for (int sgm = 0; sgm < kSegs; ++sgm) hits |= (unsigned long long)seg[sgm] << (sgm * kSegLen);
-                eqbuf[q * kBandPitch + col] = WBITS == 64 ? hits : (hits << (64 - WBITS));
+                for (int w = 0; w < NW; ++w) hits[w] = 0;
+#pragma unroll
+                for (int sgm = 0; sgm < kSegs; ++sgm) {
+                    constexpr int kOff = 64 * NW - WBITS;
+                    const int pos = kOff + sgm * kSegLen, word = pos >> 6, shift = pos & 63;
+                    hits[word] |= (unsigned long long)seg[sgm] << shift;
+                    if (shift + kSegLen > 64 && word + 1 < NW) hits[word + 1] |= (unsigned long long)seg[sgm] >> (64 - shift);
+                }
+#pragma unroll
+                for (int w = 0; w < NW; ++w) eqbuf[((size_t)w * P + q) * kBandPitch + col] = hits[w];
                 wave_lds_fence();  // the window buffer is rewritten by the next pair
             }
             wave_lds_fence();  // Eq masks cross from (pair parity, column) lanes to pair lanes
@@ -193,27 +213,37 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
             for (int c = 0; c < kBandChunk; ++c) {
                 const uint32_t i = i0 + (uint32_t)c;
                 if (have && i < len2) {
-                    const unsigned long long eq = eqbuf[(lane < P ? lane : 0) * kBandPitch + c];
-                    const uint32_t eq_lo = (uint32_t)eq, eq_hi = (uint32_t)(eq >> 32);
-                    // D0 = (((Eq & VP) + VP) ^ VP) | Eq | VN   (64-bit add with carry)
-                    uint32_t x_lo = eq_lo & vp_lo, x_hi = eq_hi & vp_hi;
-                    uint32_t s_lo = x_lo + vp_lo;
-                    uint32_t carry = s_lo < x_lo ? 1u : 0u;
-                    uint32_t s_hi = x_hi + vp_hi + carry;
-                    uint32_t d0_lo = (s_lo ^ vp_lo) | eq_lo | vn_lo;
-                    uint32_t d0_hi = (s_hi ^ vp_hi) | eq_hi | vn_hi;
-                    uint32_t hp_lo = vn_lo | ~(d0_lo | vp_lo), hp_hi = vn_hi | ~(d0_hi | vp_hi);
-                    uint32_t hn_lo = d0_lo & vp_lo, hn_hi = d0_hi & vp_hi;
+                    unsigned long long eq[NW], d0[NW], hp[NW], hn[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) eq[w] = eqbuf[((size_t)w * P + (lane < P ? lane : 0)) * kBandPitch + c];
+                    // D0 = (((Eq & VP) + VP) ^ VP) | Eq | VN   (one addition through all the words)
+                    unsigned long long carry = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const unsigned long long x = eq[w] & vp[w];
+                        unsigned long long out = 0;
+                        const unsigned long long sum = __builtin_addcll(x, vp[w], carry, &out);
+                        carry = out;
+                        d0[w] = (sum ^ vp[w]) | eq[w] | vn[w];
+                        hp[w] = vn[w] | ~(d0[w] | vp[w]);
+                        hn[w] = d0[w] & vp[w];
+                    }
                     if ((int)i < diag_cols) {
-                        cur += (d0_hi >> 31) ? 0 : 1;                 // one step down the bottom diagonal
+                        cur += (d0[NW - 1] >> 63) ? 0 : 1;                // one step down the bottom diagonal
                     } else {
                         const int b = (int)len1 - 1 - (start0 + (int)i);  // last pattern row inside the window
-                        const uint32_t hp_w = b >= 32 ? hp_hi : hp_lo, hn_w = b >= 32 ? hn_hi : hn_lo;
-                        cur += (int)((hp_w >> (b & 31)) & 1u) - (int)((hn_w >> (b & 31)) & 1u);
+                        unsigned long long hp_w = hp[0], hn_w = hn[0];
+#pragma unroll
+                        for (int w = 1; w < NW; ++w)
+                            if ((b >> 6) == w) { hp_w = hp[w]; hn_w = hn[w]; }
+                        cur += (int)((hp_w >> (b & 63)) & 1ull) - (int)((hn_w >> (b & 63)) & 1ull);
                     }
-                    const uint32_t d1_lo = __builtin_amdgcn_alignbit(d0_hi, d0_lo, 1), d1_hi = d0_hi >> 1;  // D0 >> 1
-                    vp_lo = hn_lo | ~(d1_lo | hp_lo); vp_hi = hn_hi | ~(d1_hi | hp_hi);
-                    vn_lo = d1_lo & hp_lo; vn_hi = d1_hi & hp_hi;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const unsigned long long d1 = (d0[w] >> 1) | (w + 1 < NW ? d0[w + 1 < NW ? w + 1 : w] << 63 : 0ull);   // D0 >> 1
+                        vp[w] = hn[w] | ~(d1 | hp[w]);
+                        vn[w] = d1 & hp[w];
+                    }
                 }
             }
             wave_lds_fence();  // the next chunk's phase 1 overwrites the Eq buffer
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
 
 template <typename Sym, int WBITS, int P>
 static void launch_banded_items(Scope *scope, const KernelArgs &args, uint64_t pairs) {
-    const size_t lds = kBandWaves * band_lds_per_wave(P);
+    const size_t lds = kBandWaves * band_lds_per_wave(P, WBITS);
     // the kernel sizes its items from the class's real size (known on the device only); the grid is the whole device
     // unless the batch is too small to give every wave two pairs
     uint64_t items = args.band_fixed_items ? (pairs + P - 1) / P : (pairs + 1) / 2;
@@ -248,7 +278,10 @@ static void launch_banded_one(Scope *scope, const KernelArgs &args, uint64_t pai
     // per CU): 0.356 / 0.344 / 0.331 / 0.351 / 0.450 ms; at 150 K - 800 K pairs 32 beats 64 by 13-17 % as well.
     // STRINGWARS_AMD_BAND_CAP=64: the large items (comparison knob).
     static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_BAND_CAP"); return e ? atoi(e) : 0; }();
-    if (forced == 64) launch_banded_items<Sym, WBITS, 64>(scope, args, pairs);
+    // Two-word windows: items of 16 pairs keep the workgroup at 35 KB of LDS = four per CU (items of 32: 69 KB, two per CU, and
+    // the serial recurrence at two waves per SIMD: C3's lines at k = 64 / 100 / 127 take 0.81 / 0.99 / 1.05 ms instead of 0.73 / 0.84 / 0.91).
+    if constexpr (WBITS > 64) launch_banded_items<Sym, WBITS, 16>(scope, args, pairs);
+    else if (forced == 64) launch_banded_items<Sym, WBITS, 64>(scope, args, pairs);
     else launch_banded_items<Sym, WBITS, 32>(scope, args, pairs);
 }
 
@@ -262,7 +295,9 @@ void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     if (k + 1 <= 8) launch_banded_one<SYM, 8>(scope, a, pairs);           \
     else if (k + 1 <= 16) launch_banded_one<SYM, 16>(scope, a, pairs);    \
     else if (k + 1 <= 36) launch_banded_one<SYM, 36>(scope, a, pairs);    \
-    else launch_banded_one<SYM, 64>(scope, a, pairs);
+    else if (k + 1 <= 64) launch_banded_one<SYM, 64>(scope, a, pairs);    \
+    else if (k + 1 <= 96) launch_banded_one<SYM, 96>(scope, a, pairs);    \
+    else launch_banded_one<SYM, 128>(scope, a, pairs);
     if (args.sym_bytes == 4) { SWH_BAND(uint32_t) } else { SWH_BAND(uint8_t) }
 #undef SWH_BAND
     SWH_HIP_CHECK(hipGetLastError());

@@ -126,6 +126,19 @@ __host__ __device__ __forceinline__ bool bp_pattern_is_a(uint32_t la, uint32_t l
     return ca <= cb;
 }
 
+// What the banded kernel (banded.hip) costs per column of 64 pairs, in wave instructions, against 28 (bytes) / 40 (code points)
+// per 32-row block for the bit-parallel kernels: 3 per window symbol + 45 for bounds up to 63 (one 64-bit window, the figures
+// plan_key() has always used). A two-word window (bounds 64 .. 127) adds its longer recurrence and its items of 16 pairs:
+// + 85, checked on config C3's lines (tools/bench_bounds.py: at 16 blocks, k = 64 / 100 / 127 take 0.70 / 0.80 / 0.87 of the
+// unbounded code-point kernel's time; + 170 sent the shorter half of the lines to that kernel at k = 127 and the call -- two
+// kernels, the second behind a plan read-back -- took 1.07 ms instead of 0.91). Must be used identically by plan_key() and
+// api.hip's route.
+constexpr uint32_t kBandMaxBound = 127;
+__host__ __device__ __forceinline__ uint32_t band_cost(uint32_t bound) {
+    const uint32_t base = 3 * (bound + 1) + 45;
+    return bound <= 63 ? base : base + 85;
+}
+
 // Levenshtein results honour the cutoff convention out = min(d, bound + 1).
 __device__ __forceinline__ uint32_t clamp_bound(uint32_t d, uint32_t bound) {
     return (bound != 0xFFFFFFFFu && d > bound) ? bound + 1 : d;
@@ -255,7 +268,7 @@ constexpr int kMaxPartials = 2048;
 // 65..72           : wavefront, 16 lanes per pair, W = class-64 columns per lane (cols <= 16*W)
 // 73..84           : wavefront, 64 lanes per pair, W = kWideW[class-73]
 // 85               : wavefront multi-pass (columns beyond 64*kWideW[last])
-// 86               : banded (bounded, k <= 63) Hyyro window, 64 pairs per wave
+// 86               : banded (bounded, k <= 127) Hyyro window of one or two words, <= 64 pairs per wave
 constexpr int kClassTrivial = 0;
 constexpr int kClassBp0 = 1;
 constexpr int kClassWf16 = 65;

@@ -30,7 +30,7 @@ __device__ __forceinline__ uint32_t plan_key(uint32_t la, uint32_t lb, uint32_t 
         // Banded window: ~(3 (k+1) + 45) wave instructions per column of 64 pairs, against 28 per step of
         // floor(64/G) pairs for the full bit-parallel kernel (bytes) or the u32 wavefront (code points).
         uint32_t g = (m + 31) >> 5;
-        bool use = 3 * (bound + 1) + 45 < (sym_bytes == 4 ? 40u : 28u) * g;
+        bool use = band_cost(bound) < (sym_bytes == 4 ? 40u : 28u) * g;
         if (use) {
             uint32_t bucket = m >> 4;  // text = shorter string = columns walked
             return kClassBanded * kBuckets + (bucket > 63 ? 63 : bucket);

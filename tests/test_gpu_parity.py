@@ -1951,3 +1951,45 @@ def test_engine_clones_go_with_their_engine(sw, orc):
         one_engine()                                   # 96 engines x 3 members x (64 KB matrix + class table) = 19 MB if the clones stayed
     torch.cuda.synchronize()
     assert free_before - torch.cuda.mem_get_info()[0] < 6 << 20
+
+
+@pytest.mark.parametrize("utf8", [False, True])
+def test_banded_windows_of_two_words(sw, orc, scope, utf8):
+    """Bounds of 64 .. 127 (`STRINGWARS_ERROR_BOUND` is free-form, README.md:311) on the banded kernel's two-word windows: strings long
+    enough for the band to pay (1200 .. 2600 symbols), edit counts below, at and above every bound, length differences up to the bound and
+    beyond, both argument orders, bytes and code points -- out = min(d, k + 1) against the oracle; the call must really run on `banded`.
+    Shorter strings in the same batch take the bit-parallel kernels and the clamp, and so do bounds beyond 127."""
+    rng = np.random.default_rng(91 + utf8)
+    alphabet = [chr(c) for c in range(0x61, 0x7B)] + (["é", "я", "語", "😀"] if utf8 else [])
+    items_a, items_b = [], []
+    for _ in range(260):
+        n = int(rng.integers(1200, 2600)) if rng.random() < 0.85 else int(rng.integers(1, 400))
+        a = [alphabet[int(i)] for i in rng.integers(0, len(alphabet), n)]
+        b = list(a)
+        for _ in range(int(rng.choice([0, 3, 40, 63, 64, 65, 90, 100, 127, 128, 129, 160, 191, 192, 200, 255, 256, 300]))):
+            op = int(rng.integers(0, 3))
+            if op == 0 and b:
+                b[int(rng.integers(0, len(b)))] = alphabet[int(rng.integers(0, len(alphabet)))]
+            elif op == 1:
+                b.insert(int(rng.integers(0, len(b) + 1)), alphabet[int(rng.integers(0, len(alphabet)))])
+            elif len(b) > 1:
+                del b[int(rng.integers(0, len(b)))]
+        if rng.random() < 0.15:  # pure deletions: length difference == distance
+            b = a[: max(1, n - int(rng.integers(0, 300)))]
+        items_a.append("".join(a))
+        items_b.append("".join(b))
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    full = orc.levenshtein_pairs(a, b, utf8=utf8)
+    engine = (sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances)(capabilities=scope)
+    for k in (64, 65, 95, 96, 97, 100, 126, 127):
+        scope.set_profiling(True)
+        got = engine.pairs(a, b, scope, bound=k)
+        timing = scope.last_timing()
+        scope.set_profiling(False)
+        want = np.minimum(full, k + 1)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (k, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+        assert timing["dominant_name"] == "banded", (k, timing)
+        assert (engine.pairs(b, a, scope, bound=k) == want).all(), k
+    for k in (128, 200, 255, 256):                                                      # beyond the band: unbounded kernels + the clamp
+        assert (engine.pairs(a, b, scope, bound=k) == np.minimum(full, k + 1)).all(), k

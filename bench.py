@@ -21,7 +21,7 @@ algorithm skips. Fields of the line:
   value_steady       the same calls over at least `--steady-seconds` (default 1 s) of wall time
   value_pipelined    K steps enqueued asynchronously on two internal lanes (not the reference's metric; what a caller
                      that does not need each result before the next call gets)
-  roofline           dominant kernel of the synchronous call: executed lane-ops (PMC constants, profiles/r3) over the kernel
+  roofline           dominant kernel of the synchronous call: executed lane-ops (PMC constants, profiles/r4) over the kernel
                      time measured live with hipEvents inside the library, on the kernel's own stream
   configs            (N = 1) every other BASELINE config at full size, same measurement per entry: C1, C3 prepared / raw,
                      C4 linear / affine / full byte alphabet, C5 at 20 M pairs per GPU -- each with its synchronous-call
@@ -69,7 +69,7 @@ PEAK_HBM_GBS = 8000.0
 NOMINAL_OPS_PER_CELL = {"lev": 5, "lev_utf8": 5, "nw_linear": 6, "nw_affine": 11}
 # Executed VALU instructions and HBM traffic per call come from rocprofv3 PMC passes over `bench.py --only-config ...`
 # (tools/refresh_profiles.sh -> tools/pmc_constants.py); they cannot be read from inside the process.
-PMC_CONSTANTS = os.path.join(ROOT, "profiles", "r3", "pmc_constants.json")
+PMC_CONSTANTS = os.path.join(ROOT, "profiles", "r4", "pmc_constants.json")
 PMC_CONSTANTS_NAME = os.path.relpath(PMC_CONSTANTS, ROOT)
 
 CONFIGS = {
@@ -91,16 +91,22 @@ LEGS = {
                text="C3: 100 K UTF-8 line pairs ~1 KB, bounded Levenshtein k = 32 over code points, tapes prepared (decoded once)"),
     "c3_raw": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, variant="k32", check=1_000,
                    text="C3 on raw device tapes: UTF-8 validated and decoded inside every call"),
-    "c4_linear": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=4,
+    "c4_linear": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=16,
                       text="C4: NW, 256x256 i8 matrix (20 amino acids + other), 10 K pairs ~4 KB, linear gaps -4"),
-    "c4_affine": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-11, -1), prepared=True, variant="affine", check=4,
+    "c4_affine": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-11, -1), prepared=True, variant="affine", check=16,
                       text="C4 with affine gaps (-11, -1)"),
-    "c4_bytes": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=4,
+    "c4_bytes": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=12,
                      text="C4 over the full byte alphabet (all 256 classes of the matrix in use), 2 K pairs ~4 KB, linear gaps -4"),
     "c5": dict(workload="short_words", pairs=20_000_000, kind="lev", prepared=True, check=200_000,
                text="C5: one GPU's share of the 100 M short-word pairs (20 M pairs <= 16 B, mean ~6), unbounded Levenshtein"),
+    # beyond BASELINE's five: what round 4 added kernels for
+    "c3_k100": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=100, prepared=True, variant="k100", check=1_000,
+                    text="C3's lines at k = 100 (STRINGWARS_ERROR_BOUND is free-form, README.md:311): the banded kernel's two-word window"),
+    "nw_words": dict(workload="words16", pairs=4_000_000, kind="nw", gaps=(-2, -2), unary=(2, -1), prepared=True, variant="unary_linear", check=20_000,
+                     text="NW on word-sized strings (the reference's default `words` token mode, bench.rs:271): 4 M pairs <= 16 B, "
+                          "unary_class_costs(2, -1) as a 32-class table, linear gaps -2 -- one pair per lane (alignshort.hip)"),
 }
-DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c4_linear", "c4_affine", "c4_bytes", "c5"]
+DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c5", "nw_words"]
 
 
 def parse_args():
@@ -149,7 +155,7 @@ def load_pmc_constants(path=PMC_CONSTANTS):
 def kernel_family(stamp):
     """The library stamps launches with the instantiation's name (`wavefront_class_g64_w80`, `nwprofile_w16`); PMC constants and
     source digests are kept per kernel family."""
-    for family in ("wavefront", "nwprofile"):
+    for family in ("wavefront", "nwprofile", "align_short", "align_wide"):
         if stamp.startswith(family):
             return family
     return stamp
@@ -318,7 +324,12 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
     db = sw.DeviceTape(tensors[2].data_ptr(), tensors[3].data_ptr(), b.count, b.offsets.dtype, keepalive=tensors[2:])
     kind, utf8 = leg["kind"], leg["kind"] == "lev_utf8"
     out = torch.zeros(pairs + 4, dtype=torch.int32, device=device)
-    if kind == "nw":
+    if kind == "nw" and leg.get("unary"):
+        byte_to_class, class_costs = sw.unary_class_costs(*leg["unary"])       # bench.rs:98-108: class = byte % 32
+        matrix = class_costs[byte_to_class][:, byte_to_class].astype(np.int8)  # the same scoring as a 256 x 256 table (what the oracle takes)
+        engine = sw.NeedlemanWunschScores(byte_to_class, class_costs, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)
+        model = "nw_linear" if leg["gaps"][0] == leg["gaps"][1] else "nw_affine"
+    elif kind == "nw":
         alphabet = None if leg["workload"] == "bytes4k" else sw.synth.AMINO_ACIDS
         matrix = sw.substitution_matrix(seed, alphabet)
         engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)

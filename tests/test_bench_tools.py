@@ -58,13 +58,16 @@ def test_source_digest_follows_the_kernel_sources(tmp_path, monkeypatch):
 
 def test_bench_legs_cover_every_baseline_config():
     """`configs` of the bench line: C1, C3 (prepared and raw), C4 linear / affine / full byte alphabet, C5 -- BASELINE.json's
-    configs beside the headline C2, each at its full size."""
+    configs beside the headline C2, each at its full size -- and the two shapes round 4 added kernels for (C3's lines at k = 100,
+    NW on word-sized strings)."""
     bench = load(os.path.join(ROOT, "bench.py"), "bench_module_legs")
-    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c4_linear", "c4_affine", "c4_bytes", "c5"]
+    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c5", "nw_words"]
     sizes = {name: (leg["workload"], leg["pairs"]) for name, leg in bench.LEGS.items()}
     assert sizes["c1"] == ("words16", 10_000) and sizes["c2"] == ("tokens64", 1_000_000) and sizes["c3"] == ("utf8_lines", 100_000)
     assert sizes["c4_linear"] == sizes["c4_affine"] == ("protein4k", 10_000) and sizes["c4_bytes"] == ("bytes4k", 2_000)
     assert sizes["c5"] == ("short_words", 20_000_000) and bench.LEGS["c3"]["bound"] == 32 and not bench.LEGS["c3_raw"]["prepared"]
+    assert sizes["c3_k100"] == ("utf8_lines", 100_000) and bench.LEGS["c3_k100"]["bound"] == 100 and sizes["nw_words"] == ("words16", 4_000_000)
+    assert bench.kernel_family("align_short_affine_w16") == "align_short" and bench.kernel_family("align_wide_local_w128") == "align_wide"
 
 
 def test_pmc_constants_folds_counter_passes(tmp_path):

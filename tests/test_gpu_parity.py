@@ -1716,7 +1716,7 @@ def test_bench_line_carries_every_config():
     assert line["value"] > 0 and line["value_steady"] > 0 and line["value_pipelined"] > 0 and line["parity_vs_oracle"] is True
     assert abs(line["value"] - line["config"]["cells_per_gpu"] * 5 / (line["ms_per_step"] * 5e-3) / 1e9) < 0.02 * line["value"]
     assert line["roofline"]["bound"] == "valu" and line["roofline"]["kernel_ms"] > 0 and line["roofline"]["kernel"] == "bitparallel_tiled"
-    assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c4_linear", "c4_affine", "c4_bytes", "c5"]
+    assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c5", "nw_words"]
     for entry in line["configs"]:
         assert "error" not in entry, entry
         assert entry["value"] > 0 and entry["parity_vs_oracle"] is True and entry["roofline"]["kernel_ms"] > 0 and entry["pairs"] == 600, entry

@@ -113,14 +113,17 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
         wave_lds_fence();  // params are read by other lanes in phase 1
         const uint32_t n_max = wave_max_u32(have ? len2 : 0);
         // recurrence state of my pair (phase 2): rows 0..dhi of column 0 carry vertical +1
-        unsigned long long vp[NW], vn[NW];
+        // (32-bit words: the carry chain, the funnel shift and the bit operations are what the machine has; the compiler's 64-bit
+        // forms of the same cost the one-word kernel 5 % when the window was first generalised)
+        constexpr int NV = 2 * NW;
+        uint32_t vp[NV], vn[NV];
         {
             // bits b with start0 + b >= 0  <=>  b >= kTop - dhi
             const int first = kTop - dhi;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const int from = first - 64 * w;     // first set bit inside word w
-                vp[w] = from <= 0 ? ~0ull : (from >= 64 ? 0ull : (~0ull << from));
+            for (int w = 0; w < NV; ++w) {
+                const int from = first - 32 * w;     // first set bit inside word w
+                vp[w] = from <= 0 ? 0xFFFFFFFFu : (from >= 32 ? 0u : (0xFFFFFFFFu << from));
                 vn[w] = 0;
             }
         }
@@ -213,34 +216,36 @@ __global__ __launch_bounds__(256) void k_banded(KernelArgs args, uint32_t cls) {
             for (int c = 0; c < kBandChunk; ++c) {
                 const uint32_t i = i0 + (uint32_t)c;
                 if (have && i < len2) {
-                    unsigned long long eq[NW], d0[NW], hp[NW], hn[NW];
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) eq[w] = eqbuf[((size_t)w * P + (lane < P ? lane : 0)) * kBandPitch + c];
-                    // D0 = (((Eq & VP) + VP) ^ VP) | Eq | VN   (one addition through all the words)
-                    unsigned long long carry = 0;
+                    uint32_t eq[NV], d0[NV], hp[NV], hn[NV];
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
-                        const unsigned long long x = eq[w] & vp[w];
-                        unsigned long long out = 0;
-                        const unsigned long long sum = __builtin_addcll(x, vp[w], carry, &out);
-                        carry = out;
-                        d0[w] = (sum ^ vp[w]) | eq[w] | vn[w];
+                        const unsigned long long e64 = eqbuf[((size_t)w * P + (lane < P ? lane : 0)) * kBandPitch + c];
+                        eq[2 * w] = (uint32_t)e64; eq[2 * w + 1] = (uint32_t)(e64 >> 32);
+                    }
+                    // D0 = (((Eq & VP) + VP) ^ VP) | Eq | VN   (one addition through all the words)
+                    uint32_t carry = 0;
+#pragma unroll
+                    for (int w = 0; w < NV; ++w) {
+                        const uint32_t x = eq[w] & vp[w];
+                        const unsigned long long sum = (unsigned long long)x + vp[w] + carry;
+                        carry = (uint32_t)(sum >> 32);
+                        d0[w] = ((uint32_t)sum ^ vp[w]) | eq[w] | vn[w];
                         hp[w] = vn[w] | ~(d0[w] | vp[w]);
                         hn[w] = d0[w] & vp[w];
                     }
                     if ((int)i < diag_cols) {
-                        cur += (d0[NW - 1] >> 63) ? 0 : 1;                // one step down the bottom diagonal
+                        cur += (d0[NV - 1] >> 31) ? 0 : 1;                // one step down the bottom diagonal
                     } else {
                         const int b = (int)len1 - 1 - (start0 + (int)i);  // last pattern row inside the window
-                        unsigned long long hp_w = hp[0], hn_w = hn[0];
+                        uint32_t hp_w = hp[0], hn_w = hn[0];
 #pragma unroll
-                        for (int w = 1; w < NW; ++w)
-                            if ((b >> 6) == w) { hp_w = hp[w]; hn_w = hn[w]; }
-                        cur += (int)((hp_w >> (b & 63)) & 1ull) - (int)((hn_w >> (b & 63)) & 1ull);
+                        for (int w = 1; w < NV; ++w)
+                            if ((b >> 5) == w) { hp_w = hp[w]; hn_w = hn[w]; }
+                        cur += (int)((hp_w >> (b & 31)) & 1u) - (int)((hn_w >> (b & 31)) & 1u);
                     }
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const unsigned long long d1 = (d0[w] >> 1) | (w + 1 < NW ? d0[w + 1 < NW ? w + 1 : w] << 63 : 0ull);   // D0 >> 1
+                    for (int w = 0; w < NV; ++w) {
+                        const uint32_t d1 = w + 1 < NV ? __builtin_amdgcn_alignbit(d0[w + 1 < NV ? w + 1 : w], d0[w], 1) : d0[w] >> 1;   // D0 >> 1
                         vp[w] = hn[w] | ~(d1 | hp[w]);
                         vn[w] = d1 & hp[w];
                     }

@@ -467,30 +467,41 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
                 // < 32 sees above bit 15 are its partner's rows, and nothing ever moves down across bit 16
                 __builtin_amdgcn_s_setprio(0);
                 uint32_t pv = 0xFFFFFFFFu, mv = 0;
+                // The item's pairs are sorted by text length first: lane 0 holds the shortest text, lane `last` the longest, and in
+                // most items the two are equal or one apart. Columns below the shortest length run WITHOUT the per-lane test (a
+                // compare, an exec-mask save / restore and a branch per column: a third of a column's issue slots; lanes past the
+                // item's pairs compute something nobody reads); only the columns between the two lengths are predicated.
+                const uint32_t n_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
                 auto columns = [&](auto one_tag) {
                     constexpr bool kOne = decltype(one_tag)::value;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        if ((uint32_t)w * 4 >= n_max) break;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if ((uint32_t)(w * 4 + u) >= n_max) break;
-                            if ((uint32_t)(w * 4 + u) < n) {
-                                const uint32_t x = tw[w];
-                                uint32_t both;
-                                if constexpr (kOne) both = u == 0 ? nib.template lookup_one<0>(x) : (u == 1 ? nib.template lookup_one<1>(x) : (u == 2 ? nib.template lookup_one<2>(x) : nib.template lookup_one<3>(x)));
-                                else both = u == 0 ? nib.template lookup<0>(x) : (u == 1 ? nib.template lookup<1>(x) : (u == 2 ? nib.template lookup<2>(x) : nib.template lookup<3>(x)));
-                                const uint32_t eq = both >> half_shift;
-                                const uint32_t xv = eq | mv;
-                                const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-                                uint32_t ph = mv | ~(xh | pv);
-                                const uint32_t mh = pv & xh;
-                                ph = (ph << 1) | 1u;
-                                pv = (mh + mh) | ~(xv | ph);   // (x + x: v_add_u32 issues in 2.5 cycles, a left shift in 4.4)
-                                mv = ph & xv;
-                            }
-                        }
-                    }
+                    auto one_column = [&](auto w_tag, auto u_tag) {
+                        constexpr int w = decltype(w_tag)::value, u = decltype(u_tag)::value;
+                        const uint32_t x = tw[w];
+                        uint32_t both;
+                        if constexpr (kOne) both = nib.template lookup_one<u>(x);
+                        else both = nib.template lookup<u>(x);
+                        const uint32_t eq = both >> half_shift;
+                        const uint32_t xv = eq | mv;
+                        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                        uint32_t ph = mv | ~(xh | pv);
+                        const uint32_t mh = pv & xh;
+                        ph = (ph << 1) | 1u;
+                        pv = (mh + mh) | ~(xv | ph);   // (x + x: v_add_u32 issues in 2.5 cycles, a left shift in 4.4)
+                        mv = ph & xv;
+                    };
+                    auto step = [&](auto w_tag, auto u_tag) -> bool {   // false: past the longest text of the item
+                        constexpr uint32_t col = (uint32_t)(decltype(w_tag)::value * 4 + decltype(u_tag)::value);
+                        if (col >= n_max) return false;
+                        if (col < n_min) one_column(w_tag, u_tag);
+                        else if (col < n) one_column(w_tag, u_tag);
+                        return true;
+                    };
+#define SWH_SHORT_COLUMN(W, U) if (!step(std::integral_constant<int, W>{}, std::integral_constant<int, U>{})) return;
+                    SWH_SHORT_COLUMN(0, 0) SWH_SHORT_COLUMN(0, 1) SWH_SHORT_COLUMN(0, 2) SWH_SHORT_COLUMN(0, 3)
+                    SWH_SHORT_COLUMN(1, 0) SWH_SHORT_COLUMN(1, 1) SWH_SHORT_COLUMN(1, 2) SWH_SHORT_COLUMN(1, 3)
+                    SWH_SHORT_COLUMN(2, 0) SWH_SHORT_COLUMN(2, 1) SWH_SHORT_COLUMN(2, 2) SWH_SHORT_COLUMN(2, 3)
+                    SWH_SHORT_COLUMN(3, 0) SWH_SHORT_COLUMN(3, 1) SWH_SHORT_COLUMN(3, 2) SWH_SHORT_COLUMN(3, 3)
+#undef SWH_SHORT_COLUMN
                 };
                 if (one_table) columns(std::true_type{});
                 else columns(std::false_type{});

@@ -73,7 +73,7 @@ def main():
         if kind in ("lev", "lev_utf8"):
             utf8 = kind == "lev_utf8"
             a, b = random_batch(rng, utf8)
-            bound = None if rng.random() < 0.5 else int(rng.integers(0, 80))
+            bound = None if rng.random() < 0.5 else int(rng.integers(0, 141))   # (64 .. 127: the banded kernel's two-word window)
             algorithm = str(rng.choice(["auto", "auto", "bitparallel", "wavefront", "tiled"]))
             if args.verbose:
                 print(f"batch {rounds}: {kind} pairs {len(a)} longest {int(max(a.lengths.max(), b.lengths.max()))} bound {bound} algorithm {algorithm}", flush=True)
@@ -148,7 +148,7 @@ def main():
                 matrix[np.ix_(other, other)] = matrix[other[0], other[0]]
             gaps = [(-4, -4), (-11, -1), (-2, -2), (-5, -1), (-1, -1)][int(rng.integers(0, 5))]
             items_a, items_b, cells = [], [], 0
-            lo, hi = [(0, 40), (20, 300), (200, 1500), (1000, 5000)][int(rng.integers(0, 4))]
+            lo, hi = [(0, 16), (0, 32), (0, 40), (20, 300), (200, 1500), (1000, 5000)][int(rng.integers(0, 6))]   # (<= 32: the lane-per-pair kernel)
             while cells < 1.5e8 and len(items_a) < 4000:
                 la, lb = int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))
                 items_a.append(bytes(alphabet[rng.integers(0, len(alphabet), la)].astype(np.uint8)))
@@ -167,6 +167,15 @@ def main():
             want = np.array([oracle.nw_score(x, y, matrix, gaps[0], gaps[1], local=(kind == "sw")) for x, y in zip(items_a, items_b)])
             bad = np.nonzero(got != want)[0]
             assert bad.size == 0, (kind, classes, gaps, bad[:5], got[bad[:5]], want[bad[:5]])
+            # again on the same scope (word-sized batches now take the plan-free lane-per-pair kernel on the lengths the first call saw), on
+            # prepared tapes, and a cross-product of strings cut to <= 128 bytes (small alphabets: the class-compacting kernel)
+            assert (engine.pairs(a, b, scope) == want).all(), ("second call", kind, classes, gaps, lo, hi)
+            pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
+            assert (engine.pairs(pa, pb, scope) == want).all(), ("prepared", kind, classes, gaps, lo, hi)
+            cut = int(rng.choice([16, 32, 64, 128]))
+            qs, cs = [x[:cut] for x in items_a[:23]], [x[:cut] for x in items_b[:150]]
+            flat = np.array([[oracle.nw_score(x, y, matrix, gaps[0], gaps[1], local=(kind == "sw")) for y in cs] for x in qs])
+            assert (engine(sw.PreparedTape(scope, sw.Strs(qs)), sw.PreparedTape(scope, sw.Strs(cs)), scope) == flat).all(), ("cross-product", kind, classes, gaps, cut)
             if rounds % 3 == 0:   # the same batch over the three-member scope (per-member engine clones), and a small cross-product
                 sharded_engine = cls(substitution_matrix=matrix, open=gaps[0], extend=gaps[1], capabilities=multi)
                 batch = sw.ShardedPairs(multi, a, b)

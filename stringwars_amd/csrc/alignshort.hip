@@ -19,6 +19,8 @@
 //
 // Exact for strings of up to W symbols; a longer string raises the call summary's `violation` flag and the host redoes the
 // call on the planned path (api.hip), as for the other plan-free kernels.
+#include <algorithm>
+
 #include "common.hpp"
 #include "bp_window.hpp"
 
@@ -653,6 +655,296 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
     }
     __syncthreads();
     report_call_summary(PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, lmisfit}, args.partials, args.done_counter, args.summary, summary_lds);
+}
+
+// ---- the same for strings of ANY length: the columns run as passes of W, the boundary column between passes travels through
+// global memory ------------------------------------------------------------------------------------------------------------------
+// A lane still owns a pair; its candidate's columns c0 + 1 .. c0 + W are one pass, the rows of the query stream by two at a time
+// (align_rows_uniform's scheme), and what the next pass needs of this one -- H (and Gotoh's E) of the pass's last column, one value
+// per row -- is parked in a lane-private column of a per-wave buffer: row r of all 64 lanes is one 256-byte line, written and read
+// back coalesced, 8 bytes per 128 cells. The baseline-relative forms carry over unchanged (their recurrences do not mention the
+// column index). With the register row bounded by the pass, Gotoh fits too: W = 64 columns of H and F. Queries are staged in LDS
+// one at a time (<= kAlignLongRows class bytes); the classes are compacted per work item over ALL of its candidates' columns.
+constexpr uint32_t kAlignLongRows = 4096;
+
+struct AlignLongLds {
+    uint8_t qcls[kAlignLongRows + 16];   // the current query as class bytes
+    uint8_t ctab[32][8];                 // cost of (row class, compact column class)
+    uint8_t cid[32];                     // class -> compact id
+};
+
+// One pass of one query over my candidate's columns (c0, c0 + W]. `first`: c0 == 0 (the DP's own left edge instead of a parked
+// column); `more`: another pass follows (park my right edge). bh / be: my lane's column of the wave's boundary buffer, entry r at
+// [64 r]. Returns nothing: H-of-my-last-column is captured into `result` when my string ends inside this pass; `best` runs on.
+template <int W, bool kAffine, bool kLocal>
+__device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, const uint32_t (&sel)[W / 4], uint32_t n_here, uint32_t cols_here,
+                                           const char *ctab, int open, int ext, bool first, bool more, int *bh, int *be, int &result, int &best) {
+    constexpr bool kSkew = !kAffine && !kLocal;
+    const int open_minus_ext = open - ext;
+    int H[W];
+    int F[kAffine ? W : 1];
+    const int edge = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);   // row 0 right of the corner, and the DP's own left edge below it
+    const int corner = kLocal ? open : (kSkew ? 0 : (first ? open_minus_ext : 2 * open_minus_ext));
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        H[k] = edge;
+        if constexpr (kAffine) F[k] = kAlignNegInf;
+    }
+    auto fetch = [&](uint32_t row, uint4 &lo) {
+        const uint32_t rc = row < m ? rowcls[row] : 0u;
+        const uint2 v = *(const uint2 *)(ctab + rc * 8);
+        lo = make_uint4(v.x, v.y, 0, 0);
+    };
+    const uint4 none{0, 0, 0, 0};
+    uint4 a_lo, b_lo;
+    fetch(0, a_lo);
+    fetch(1, b_lo);
+    // the parked column: rows i, i + 1 of this iteration, requested an iteration ahead (the buffer has slack rows)
+    int h_a = edge, h_b = edge, e_a0 = kAlignNegInf, e_b0 = kAlignNegInf;
+    if (!first) {
+        h_a = bh[0]; h_b = bh[64];
+        if constexpr (kAffine) { e_a0 = be[0]; e_b0 = be[64]; }
+    }
+    int above = corner;      // H of (row i, column c0): the diagonal of row i + 1's first cell
+    uint32_t i = 0;
+    for (; i + 1 < m; i += 2) {
+        const uint4 ra = a_lo, rb = b_lo;
+        fetch(i + 2, a_lo);
+        fetch(i + 3, b_lo);
+        int left_a = h_a, left_b = h_b, diag_a = above, diag_b = h_a, e_a = e_a0, e_b = e_b0;
+        above = h_b;
+        if (!first) {
+            h_a = bh[64 * (i + 2)]; h_b = bh[64 * (i + 3)];
+            if constexpr (kAffine) { e_a0 = be[64 * (i + 2)]; e_b0 = be[64 * (i + 3)]; }
+        }
+        int out_a = 0, out_b = 0, oute_a = 0, oute_b = 0;
+#pragma unroll
+        for (int g4 = 0; g4 <= W; g4 += 4) {
+            if (g4 < W && (uint32_t)g4 < cols_here) {
+                align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<1>(ra, none, sel + (g4 >> 2)), diag_a, left_a, e_a, best, open, ext, open_minus_ext);
+                if (g4 == W - 4) { out_a = left_a; oute_a = e_a; }
+            }
+            if (g4 >= 4 && (uint32_t)(g4 - 4) < cols_here) {
+                align_group<W, kAffine, kLocal>(H, F, g4 - 4, align_costs4<1>(rb, none, sel + ((g4 - 4) >> 2)), diag_b, left_b, e_b, best, open, ext, open_minus_ext);
+                if (g4 == W) { out_b = left_b; oute_b = e_b; }
+            }
+        }
+        if (more) {
+            bh[64 * i] = out_a; bh[64 * (i + 1)] = out_b;
+            if constexpr (kAffine) { be[64 * i] = oute_a; be[64 * (i + 1)] = oute_b; }
+        }
+    }
+    if (i < m) {   // an odd row count: the last row on its own
+        int left = h_a, diag = above, e = e_a0;
+#pragma unroll
+        for (int g4 = 0; g4 < W; g4 += 4)
+            if ((uint32_t)g4 < cols_here)
+                align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<1>(a_lo, none, sel + (g4 >> 2)), diag, left, e, best, open, ext, open_minus_ext);
+        if (more) {
+            bh[64 * i] = left;
+            if constexpr (kAffine) be[64 * i] = e;
+        }
+    }
+    if constexpr (!kLocal) {
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+            if ((uint32_t)k + 1 == n_here) result = H[k];
+    }
+}
+
+template <int W, bool kAffine, bool kLocal>
+__global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_long(AlignShortArgs args, int *boundary, uint32_t rows_cap) {
+    __shared__ __attribute__((aligned(16))) char ltable[kClassLdsBytes];
+    __shared__ __attribute__((aligned(16))) AlignLongLds wave_lds[kAlignWaves];
+    __shared__ SummaryLds summary_lds;
+    __shared__ unsigned long long lcells, lsyms;
+    __shared__ uint32_t lmaxa, lmaxb, lshorts, lmisfit;
+    {
+        const uint32_t *src = (const uint32_t *)args.class_table;
+        for (int i = threadIdx.x; i < (int)kClassLdsBytes / 4; i += blockDim.x) ((uint32_t *)ltable)[i] = src[i];
+    }
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; lmisfit = 0; }
+    __syncthreads();
+    const uint8_t *lclass_of = (const uint8_t *)ltable + 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    AlignLongLds &wl = wave_lds[wave];
+    const Job &job = args.job;
+    const uint8_t *a_data = (const uint8_t *)job.a.data, *b_data = (const uint8_t *)job.b.data;
+    const uint64_t na = job.a.count, nb = job.b.count;
+    uint64_t a_total, b_total;
+    { uint32_t unused; align_extent(job.a.offsets, args.off64, na, a_total, unused); align_extent(job.b.offsets, args.off64, nb, b_total, unused); }
+    const uint64_t waves_total = (uint64_t)gridDim.x * kAlignWaves, wave_id = (uint64_t)blockIdx.x * kAlignWaves + wave;
+    int *bh = boundary + wave_id * (uint64_t)rows_cap * 64 * (kAffine ? 2 : 1) + lane;
+    int *be = bh + (uint64_t)rows_cap * 64;
+    const int open = args.open, ext = args.extend, open_minus_ext = open - ext;
+    const size_t elem = job.out_elem64 ? 8 : 4;
+    unsigned long long cells = 0, syms = 0;
+    uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
+    const uint64_t chunks = (nb + 63) / 64, qblocks = (na + kAlignQueries - 1) / kAlignQueries;
+    const uint64_t items = chunks * qblocks;
+    for (uint64_t item = wave_id; item < items; item += waves_total) {
+        const uint64_t chunk = item / qblocks, qb = item - chunk * qblocks;
+        const uint64_t q_first = qb * kAlignQueries, q_last = q_first + kAlignQueries < na ? q_first + kAlignQueries : na;
+        const uint32_t q_count = (uint32_t)(q_last - q_first);
+        const uint64_t cand = chunk * 64 + (uint64_t)lane;
+        const bool have = cand < nb;
+        uint64_t b0 = 0;
+        uint32_t lb = 0;
+        if (have) align_extent(job.b.offsets, args.off64, cand, b0, lb);
+        const bool fits = have && lb <= 0x00FFFFFFu;
+        if (have && !fits) misfit = 1;
+        const uint32_t n = fits ? lb : 0u;
+        const uint32_t n_max = wave_max_u32(n);
+        const uint32_t passes = (n_max + W - 1) / W;
+        // -- the classes my candidate uses, over all of its columns
+        uint32_t used = 0;
+        for (uint32_t p = 0; p < passes; ++p) {
+            uint32_t bw[W / 4], bcls[W / 4];
+            align_fetch<W / 4>(b_data, b0 + (uint64_t)p * W, b_total, bw);
+            align_classes<W / 4>(lclass_of, bw, n_max - p * W, bcls);
+#pragma unroll
+            for (int g = 0; g < W / 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p * W + (uint32_t)(4 * g + u) < n) used |= 1u << ((bcls[g] >> (8 * u)) & 31u);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) used |= (uint32_t)__shfl_xor((int)used, off);
+        const bool compact = __popc(used) <= 8;
+        if (!compact) misfit = 1;
+        wave_lds_fence();                                  // the previous item's readers are done with the tables
+        if (lane < 32) {
+            wl.cid[lane] = (uint8_t)__popc(used & ((1u << lane) - 1u));
+            uint32_t rest = used, lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t cls = rest ? (uint32_t)__builtin_ctz(rest) : 0u;
+                const uint32_t cost = rest ? (uint32_t)(uint8_t)ltable[lane * 32 + cls] : 0u;
+                rest &= rest - 1u;
+                if (j < 4) lo |= cost << (8 * j); else hi |= cost << (8 * (j - 4));
+            }
+            *(uint2 *)wl.ctab[lane] = make_uint2(lo, hi);
+        }
+        wave_lds_fence();
+        unsigned long long sum_m = 0;
+        uint32_t item_maxa = 0;
+        for (uint32_t q = 0; q < q_count; ++q) {
+            uint64_t qa0 = 0;
+            uint32_t qlen = 0;
+            align_extent(job.a.offsets, args.off64, q_first + q, qa0, qlen);
+            sum_m += qlen;
+            item_maxa = qlen > item_maxa ? qlen : item_maxa;
+            if (qlen > kAlignLongRows || qlen + 4 > rows_cap) { misfit = 1; continue; }
+            if (!compact) continue;
+            // -- the query into LDS as class bytes, 1 KB per round
+            wave_lds_fence();
+            for (uint32_t at = 16u * (uint32_t)lane; at < qlen; at += 1024u) {
+                ByteWindow win;
+                win.init(a_data, qa0 + at, a_total);
+                uint32_t staged[4], scls[4];
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) staged[w4] = win.fetch4(4 * w4);
+                align_classes<4>(lclass_of, staged, 16, scls);
+                *(uint4 *)(wl.qcls + at) = make_uint4(scls[0], scls[1], scls[2], scls[3]);
+            }
+            wave_lds_fence();
+            int result = 0, best = 0;
+            for (uint32_t p = 0; p < passes; ++p) {
+                const uint32_t c0 = p * W;
+                // -- selectors of this pass's columns: the compact ids of my candidate's symbols (local: nothing right of the string)
+                uint32_t sel[W / 4];
+                {
+                    uint32_t bw[W / 4], bcls[W / 4];
+                    align_fetch<W / 4>(b_data, b0 + c0, b_total, bw);
+                    align_classes<W / 4>(lclass_of, bw, n_max - c0, bcls);
+                    const uint32_t n_rel = n > c0 ? n - c0 : 0u;
+#pragma unroll
+                    for (int g = 0; g < W / 4; ++g) {
+                        const uint32_t c = bcls[g];
+                        uint32_t ids = (uint32_t)wl.cid[c & 31u] | ((uint32_t)wl.cid[(c >> 8) & 31u] << 8) | ((uint32_t)wl.cid[(c >> 16) & 31u] << 16) | ((uint32_t)wl.cid[(c >> 24) & 31u] << 24);
+                        ids &= 0x07070707u;
+                        if constexpr (kLocal) {
+                            const uint32_t beyond = n_rel >= (uint32_t)(4 * g + 4) ? 0u : (n_rel <= (uint32_t)(4 * g) ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (n_rel - 4 * g)));
+                            ids = (ids & ~beyond) | (0x0C0C0C0Cu & beyond);
+                        }
+                        sel[g] = ids;
+                    }
+                }
+                const uint32_t cols_here = n_max - c0 < (uint32_t)W ? n_max - c0 : (uint32_t)W;
+                const uint32_t n_here = (n > c0 && n <= c0 + W) ? n - c0 : 0u;     // my string ends in this pass: capture
+                align_pass<W, kAffine, kLocal>(wl.qcls, qlen, sel, n_here, cols_here, (const char *)&wl.ctab[0][0], open, ext, p == 0, p + 1 < passes, bh, be, result, best);
+            }
+            if (fits) {
+                int score;
+                if (!n || !qlen) score = align_trivial(qlen, lb, kLocal, open, ext);
+                else if constexpr (kLocal) score = best;
+                else if constexpr (kAffine) score = result + (int)(qlen + n) * ext - open_minus_ext;
+                else score = result + (int)(qlen + n) * ext;
+                char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
+                if (job.out_elem64) *(int64_t *)dst = (int64_t)score;
+                else *(int32_t *)dst = score;
+            }
+        }
+        if (have) {
+            cells += sum_m * (unsigned long long)lb;
+            maxb = lb > maxb ? lb : maxb;
+            if (qb == 0) syms += lb;
+            if (fits) shorts += q_count;
+        }
+        if (lane == 0) {
+            maxa = item_maxa > maxa ? item_maxa : maxa;
+            if (chunk == 0) syms += sum_m;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cells += __shfl_xor(cells, off);
+        syms += __shfl_xor(syms, off);
+        shorts += __shfl_xor(shorts, off);
+        misfit |= __shfl_xor(misfit, off);
+        const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+        maxa = oa > maxa ? oa : maxa;
+        maxb = ob > maxb ? ob : maxb;
+    }
+    if (lane == 0) {
+        atomicAdd(&lcells, cells);
+        atomicAdd(&lsyms, syms);
+        atomicAdd(&lshorts, shorts);
+        atomicMax(&lmaxa, maxa);
+        atomicMax(&lmaxb, maxb);
+        atomicOr(&lmisfit, misfit);
+    }
+    __syncthreads();
+    report_call_summary(PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, lmisfit}, args.partials, args.done_counter, args.summary, summary_lds);
+}
+
+// waves (= boundary areas) a launch of the multi-pass kernel gets: two four-wave workgroups per CU (a 128-column row, or 64
+// columns of H and F, leave two waves per SIMD), never more than it has work items
+uint32_t align_long_waves(const Scope *scope, uint64_t items) {
+    const uint64_t blocks = std::min<uint64_t>((items + kAlignWaves - 1) / kAlignWaves, (uint64_t)scope->compute_units * 2);
+    return (uint32_t)(blocks ? blocks : 1) * kAlignWaves;
+}
+
+void launch_align_long(Scope *scope, const KernelArgs &k, uint32_t longest_rows) {
+    AlignShortArgs args{};
+    args.job = k.job; args.off64 = k.off64;
+    args.open = k.scoring.open; args.extend = k.scoring.extend;
+    args.class_table = k.scoring.class_table;
+    args.partials = scope->plan_partials; args.done_counter = scope->done_counter; args.summary = scope->summary_target();
+    const Job &job = k.job;
+    const uint64_t items = ((job.b.count + 63) / 64) * ((job.a.count + kAlignQueries - 1) / kAlignQueries);
+    const uint32_t waves = align_long_waves(scope, items);
+    const dim3 grid(waves / kAlignWaves), block(kAlignWaves * 64);
+    const bool affine = k.affine != 0, local = k.local != 0;
+    const uint32_t rows_cap = longest_rows + 8;
+    const char *name = affine ? (local ? "align_long_affine_local" : "align_long_affine") : (local ? "align_long_local" : "align_long");
+    StampGuard guard(scope, name);
+    int *boundary = (int *)k.boundary;
+    if (!affine && !local) hipLaunchKernelGGL((k_align_cross_long<128, false, false>), grid, block, 0, scope->stream, args, boundary, rows_cap);
+    else if (!affine) hipLaunchKernelGGL((k_align_cross_long<128, false, true>), grid, block, 0, scope->stream, args, boundary, rows_cap);
+    else if (!local) hipLaunchKernelGGL((k_align_cross_long<64, true, false>), grid, block, 0, scope->stream, args, boundary, rows_cap);
+    else hipLaunchKernelGGL((k_align_cross_long<64, true, true>), grid, block, 0, scope->stream, args, boundary, rows_cap);
+    SWH_HIP_CHECK(hipGetLastError());
 }
 
 template <int W, int PQ>

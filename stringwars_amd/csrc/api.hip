@@ -249,7 +249,7 @@ static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec 
 }
 
 // Which kernels a unit-cost Levenshtein call runs on.
-enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort, kRouteShortTiled, kRouteCrossShort, kRouteAlignShort };
+enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort, kRouteShortTiled, kRouteCrossShort, kRouteAlignShort, kRouteAlignLong };
 
 // Strings up to this many symbols (G <= 8 blocks) are scored by the tiled kernel when their lengths are known; beyond it
 // a tile holds too few pairs per block count and the global sort of the planned path packs the waves better.
@@ -432,6 +432,13 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             if (known && (guaranteed || can_verify) && (both <= 32 || wide)) {
                 route = kRouteAlignShort;
                 longest = both;
+            } else if (known && can_verify && spec.cross && !scope->align_wide_off && both <= 384) {
+                // up to 384 symbols -- below the column-profile kernel's range, where the wavefront class kernels used to run -- on the
+                // same small-alphabet condition: columns in passes of 128 (Gotoh: 64), the boundary column between passes through global
+                // memory (alignshort.hip: k_align_cross_long). (The kernel takes any length; on 1 K-symbol DNA its linear form measured
+                // 9.6 TCUPS against the profile kernel's 10.0, so longer strings stay there.)
+                route = kRouteAlignLong;
+                longest = la_max;
             }
         }
 
@@ -597,6 +604,13 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             }
             else if (route == kRouteCrossShort) launch_cross_short(scope, job, off64);
             else if (route == kRouteAlignShort) launch_align_short(scope, k, longest);
+            else if (route == kRouteAlignLong) {
+                const uint64_t items = ((uint64_t)(spec.b.count + 63) / 64) * ((uint64_t)(spec.a.count + 15) / 16);
+                const uint64_t ints = (uint64_t)align_long_waves(scope, items) * (longest + 8) * 64 * (k.affine ? 2 : 1);
+                ensure(scope->boundary, scope->boundary_bytes, ints * sizeof(int32_t));
+                k.boundary = (int32_t *)scope->boundary;
+                launch_align_long(scope, k, longest);
+            }
             else launch_bitparallel_tiled(scope, k, pairs, longest);
             if (invalid_dev) SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));
             copy_results_back();
@@ -611,7 +625,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 if (scope->summary_host[0].violation) {
                     // the belief about the lengths was wrong (it came from an earlier batch): redo on the planned path
                     scope->hint_lengths = false;
-                    if (route == kRouteAlignShort && longest > 32) scope->align_wide_off = true;   // (or: more than eight classes in an item)
+                    if ((route == kRouteAlignShort && longest > 32) || route == kRouteAlignLong) scope->align_wide_off = true;   // (or: more than eight classes in an item)
                     scope->summary_pending = false;
                     scope->stamps_pending = false;
                     CallSpec again = spec;

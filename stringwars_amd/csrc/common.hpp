@@ -473,6 +473,11 @@ void launch_nwprofile(Scope *scope, KernelArgs args, uint32_t first, uint32_t co
 int wavefront_strip_cap();
 // alignshort.hip: NW / SW scores on a class table, both strings <= 32 bytes (`longest`: of both tapes), one pair per lane; plan-free
 void launch_align_short(Scope *scope, const KernelArgs &args, uint32_t longest);
+// the same for queries x candidates of any length over a small alphabet (<= 8 classes per work item): columns in passes of 128
+// (Gotoh: 64), the boundary column between passes in args.boundary -- align_long_waves() areas of (longest_rows + 8) x 64 ints
+// (x 2 for Gotoh's E); queries of up to 4096 symbols
+uint32_t align_long_waves(const Scope *scope, uint64_t items);
+void launch_align_long(Scope *scope, const KernelArgs &args, uint32_t longest_rows);
 
 // UTF-8 staging: decodes a byte tape into u32 code points + u64 code-point offsets.
 constexpr int kUtf8Pass = 1024, kUtf8Passes = 8;     // a block walks its tile in passes of 256 threads x one dword

@@ -168,11 +168,11 @@ def main():
             bad = np.nonzero(got != want)[0]
             assert bad.size == 0, (kind, classes, gaps, bad[:5], got[bad[:5]], want[bad[:5]])
             # again on the same scope (word-sized batches now take the plan-free lane-per-pair kernel on the lengths the first call saw), on
-            # prepared tapes, and a cross-product of strings cut to <= 128 bytes (small alphabets: the class-compacting kernel)
+            # prepared tapes, and a cross-product of strings cut to <= 384 bytes (small alphabets: the class-compacting kernels)
             assert (engine.pairs(a, b, scope) == want).all(), ("second call", kind, classes, gaps, lo, hi)
             pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
             assert (engine.pairs(pa, pb, scope) == want).all(), ("prepared", kind, classes, gaps, lo, hi)
-            cut = int(rng.choice([16, 32, 64, 128]))
+            cut = int(rng.choice([16, 32, 64, 128, 200, 384]))   # (beyond 128: columns in passes, k_align_cross_long)
             qs, cs = [x[:cut] for x in items_a[:23]], [x[:cut] for x in items_b[:150]]
             flat = np.array([[oracle.nw_score(x, y, matrix, gaps[0], gaps[1], local=(kind == "sw")) for y in cs] for x in qs])
             assert (engine(sw.PreparedTape(scope, sw.Strs(qs)), sw.PreparedTape(scope, sw.Strs(cs)), scope) == flat).all(), ("cross-product", kind, classes, gaps, cut)

@@ -1993,3 +1993,48 @@ def test_banded_windows_of_two_words(sw, orc, scope, utf8):
         assert (engine.pairs(b, a, scope, bound=k) == want).all(), k
     for k in (128, 200, 255, 256):                                                      # beyond the band: unbounded kernels + the clamp
         assert (engine.pairs(a, b, scope, bound=k) == np.minimum(full, k + 1)).all(), k
+
+
+@pytest.mark.parametrize("local", [False, True])
+@pytest.mark.parametrize("gaps", [(-2, -2), (-5, -1)])
+def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps):
+    """k_align_cross_long (alignshort.hip): queries x candidates of up to 384 symbols over a small alphabet, the columns run as passes of
+    128 (Gotoh: 64) with the boundary column between passes parked in global memory. Candidate lengths around every pass boundary (0, 1,
+    63 .. 65, 127 .. 129, 255 .. 257, 300, 384), query lengths odd and even, linear and affine gaps, global and local, the reference's
+    unary class costs and a random asymmetric table -- every score against the oracle. The call must run on `align_long`; longer strings,
+    or candidates over 26 letters, take the planned path (and score the same)."""
+    rng = np.random.default_rng(300 + local + gaps[0])
+    Engine = sw.SmithWatermanScores if local else sw.NeedlemanWunschScores
+    byte_to_class, costs = sw.unary_class_costs(2, -1)
+    random_costs = rng.integers(-9, 12, (32, 32)).astype(np.int8)
+
+    def dna(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(n)))
+
+    for table in (costs, random_costs):
+        full = np.array([[table[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+        engine = Engine(byte_to_class, table, open=gaps[0], extend=gaps[1], capabilities=scope)
+        queries = [dna(n) for n in (0, 1, 2, 33, 100, 129, 300, 383, 384)]
+        candidates = [dna(n) for n in [0, 1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 384] + list(rng.integers(0, 385, 70))]
+        candidates[20] = queries[6][:280] + dna(15)                              # related strings, too
+        q, c = sw.PreparedTape(scope, sw.Strs(queries)), sw.PreparedTape(scope, sw.Strs(candidates))
+        scope.set_profiling(True)
+        got = engine(q, c, scope)
+        name = scope.last_timing()["dominant_name"]
+        scope.set_profiling(False)
+        assert name.startswith("align_long"), name
+        want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (gaps, local, bad[:5], [(len(queries[i]), len(candidates[j]), got[i, j], want[i, j]) for i, j in bad[:5]])
+    fresh = sw.DeviceScope(gpu_device=0)
+    engine = Engine(byte_to_class, costs, open=gaps[0], extend=gaps[1], capabilities=fresh)
+    full = np.array([[costs[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+    queries, candidates = [dna(200), dna(1400)], [dna(150), dna(40), dna(700)]
+    want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
+    assert (engine(sw.PreparedTape(fresh, sw.Strs(queries)), sw.PreparedTape(fresh, sw.Strs(candidates)), fresh) == want).all()
+    text = [bytes(rng.integers(97, 123, int(n), dtype=np.uint8)) for n in rng.integers(150, 420, 80)]
+    want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in text[10:]] for x in text[:10]])
+    fresh2 = sw.DeviceScope(gpu_device=0)
+    engine2 = Engine(byte_to_class, costs, open=gaps[0], extend=gaps[1], capabilities=fresh2)
+    for _ in range(2):
+        assert (engine2(sw.PreparedTape(fresh2, sw.Strs(text[:10])), sw.PreparedTape(fresh2, sw.Strs(text[10:])), fresh2) == want).all()

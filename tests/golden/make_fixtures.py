@@ -52,6 +52,22 @@ def main():
             cp = oracle.levenshtein_pairs(a, b, utf8=True)
             out[f"{name}.lev_utf8"] = cp[:verbatim]
             out[f"{name}.n256.lev_utf8"] = cp
+        if name == "words16":
+            # The reference's alignment rows on its default `words` tokens (bench.rs:271): unary_class_costs(2, -1) folded into the
+            # 32-class table (bench.rs:98-108, :655), linear gaps -2 / -2 (bench.rs:640) and affine -5 / -1 (bench.rs:966), global and
+            # local -- pairwise over the 256 pairs, and the 16 x 16 cross-product of the first 16 a-strings with the first 16 b-strings
+            byte_to_class, class_costs = sw.unary_class_costs(2, -1)
+            unary = class_costs[byte_to_class][:, byte_to_class].astype(np.int8)
+            for tag, (open_, extend) in {"linear_m2": (-2, -2), "affine_m5_m1": (-5, -1)}.items():
+                for kind, local in (("nw", False), ("sw", True)):
+                    pairs = np.array([oracle.nw_score(a[i], b[i], unary, open_, extend, local=local) for i in range(FULL)], dtype=np.int64)
+                    if not local:
+                        assert (pairs == oracle.nw_pairs(a, b, unary, open_, extend)).all()
+                    for i in range(64):   # the cubic second implementation
+                        assert pairs[i] == oracle.align_score_general(a[i], b[i], unary, open_, extend, local=local)
+                    out[f"{name}.n256.{kind}_unary_{tag}"] = pairs
+                    out[f"{name}.cross16.{kind}_unary_{tag}"] = np.array(
+                        [[oracle.nw_score(a[i], b[j], unary, open_, extend, local=local) for j in range(16)] for i in range(16)], dtype=np.int64)
         if name in ("protein4k", "bytes4k"):
             alphabet = sw.synth.AMINO_ACIDS if name == "protein4k" else None
             matrix = sw.substitution_matrix(42, alphabet)

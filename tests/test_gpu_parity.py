@@ -2038,3 +2038,26 @@ def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps)
     engine2 = Engine(byte_to_class, costs, open=gaps[0], extend=gaps[1], capabilities=fresh2)
     for _ in range(2):
         assert (engine2(sw.PreparedTape(fresh2, sw.Strs(text[:10])), sw.PreparedTape(fresh2, sw.Strs(text[10:])), fresh2) == want).all()
+
+
+def test_golden_words_alignment_rows(sw, scope):
+    """tests/golden/slices.npz: the reference's alignment rows on word-sized tokens -- `unary_class_costs(2, -1)`, linear -2 / -2 and
+    affine -5 / -1 (bench.rs:640, :655, :966), NW and SW -- for the first 256 `words16` pairs (pairwise, prepared and raw tapes) and the
+    16 x 16 cross-product of the first 16 strings of either tape: the committed oracle outputs against k_align_short."""
+    z = np.load(os.path.join(GOLDEN, "slices.npz"))
+    a = sw.Strs(data=z["words16.a_data"], offsets=z["words16.a_offsets"])
+    b = sw.Strs(data=z["words16.b_data"], offsets=z["words16.b_offsets"])
+    byte_to_class, class_costs = sw.unary_class_costs(2, -1)
+    for tag, gaps in (("linear_m2", (-2, -2)), ("affine_m5_m1", (-5, -1))):
+        for kind, Engine in (("nw", sw.NeedlemanWunschScores), ("sw", sw.SmithWatermanScores)):
+            engine = Engine(byte_to_class, class_costs, open=gaps[0], extend=gaps[1], capabilities=scope)
+            want = z[f"words16.n256.{kind}_unary_{tag}"]
+            pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
+            scope.set_profiling(True)
+            got = engine.pairs(pa, pb, scope)
+            assert scope.last_timing()["dominant_name"].startswith("align_short"), scope.last_timing()
+            scope.set_profiling(False)
+            assert (got == want).all(), (kind, tag)
+            assert (engine.pairs(a, b, scope) == want).all() and (engine.pairs(a, b, scope) == want).all(), (kind, tag, "raw tapes, twice")
+            cross = engine(sw.PreparedTape(scope, a.subview(0, 16)), sw.PreparedTape(scope, b.subview(0, 16)), scope)
+            assert (cross == z[f"words16.cross16.{kind}_unary_{tag}"]).all(), (kind, tag, "cross-product")

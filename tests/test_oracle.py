@@ -223,6 +223,15 @@ def test_golden_slices_reproducible(orc, sw):
         assert (orc.levenshtein_pairs(a, b) == z[f"{name}.n256.lev_bytes"]).all()
     a, b = sw.generate_pairs("utf8_lines", 32, seed=42)
     assert (orc.levenshtein_pairs(a, b, utf8=True) == z["utf8_lines.n256.lev_utf8"][:32]).all()
+    # the reference's alignment rows on word-sized tokens: unary_class_costs(2, -1), linear -2 / -2 and affine -5 / -1, NW and SW
+    a, b = sw.generate_pairs("words16", 256, seed=42)
+    byte_to_class, class_costs = sw.unary_class_costs(2, -1)
+    unary = class_costs[byte_to_class][:, byte_to_class].astype(np.int8)
+    for tag, gaps in (("linear_m2", (-2, -2)), ("affine_m5_m1", (-5, -1))):
+        assert (orc.nw_pairs(a, b, unary, *gaps) == z[f"words16.n256.nw_unary_{tag}"]).all()
+        for kind, local in (("nw", False), ("sw", True)):
+            assert [orc.nw_score(a[i], b[i], unary, *gaps, local=local) for i in range(0, 256, 5)] == z[f"words16.n256.{kind}_unary_{tag}"][::5].tolist()
+            assert [[orc.nw_score(a[i], b[j], unary, *gaps, local=local) for j in range(16)] for i in range(16)] == z[f"words16.cross16.{kind}_unary_{tag}"].tolist()
     a, b = sw.generate_pairs("protein4k", 2, seed=42)
     assert (orc.nw_pairs(a, b, z["protein4k.matrix"], -4, -4) == z["protein4k.n256.nw_linear_m4"][:2]).all()
     assert orc.nw_score(a[0], b[0], z["protein4k.matrix"], -11, -1, local=True) == z["protein4k.n256.sw_affine_m11_m1"][0]

@@ -155,7 +155,7 @@ def load_pmc_constants(path=PMC_CONSTANTS):
 def kernel_family(stamp):
     """The library stamps launches with the instantiation's name (`wavefront_class_g64_w80`, `nwprofile_w16`); PMC constants and
     source digests are kept per kernel family."""
-    for family in ("wavefront", "nwprofile", "align_short", "align_wide"):
+    for family in ("wavefront", "nwprofile", "align_short", "align_wide", "align_long"):
         if stamp.startswith(family):
             return family
     return stamp

@@ -676,7 +676,8 @@ struct AlignLongLds {
 // One pass of one query over my candidate's columns (c0, c0 + W]. `first`: c0 == 0 (the DP's own left edge instead of a parked
 // column); `more`: another pass follows (park my right edge). bh / be: my lane's column of the wave's boundary buffer, entry r at
 // [64 r]. Returns nothing: H-of-my-last-column is captured into `result` when my string ends inside this pass; `best` runs on.
-template <int W, bool kAffine, bool kLocal>
+// kFull: every column of the pass is a column of some candidate of the wave (all passes but a work item's last): no test per group.
+template <int W, bool kAffine, bool kLocal, bool kFull>
 __device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, const uint32_t (&sel)[W / 4], uint32_t n_here, uint32_t cols_here,
                                            const char *ctab, int open, int ext, bool first, bool more, int *bh, int *be, int &result, int &best) {
     constexpr bool kSkew = !kAffine && !kLocal;
@@ -699,11 +700,14 @@ __device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, co
     uint4 a_lo, b_lo;
     fetch(0, a_lo);
     fetch(1, b_lo);
-    // the parked column: rows i, i + 1 of this iteration, requested an iteration ahead (the buffer has slack rows)
+    // the parked column: rows i, i + 1 of this iteration, requested TWO iterations ahead (an iteration is ~660 instructions, ~3300
+    // cycles at two waves per SIMD; a global round trip under this load is longer: one iteration of lead left a third of the time
+    // in waits on 1 K-symbol strings). The buffer has slack rows for the requests past the query's end.
     int h_a = edge, h_b = edge, e_a0 = kAlignNegInf, e_b0 = kAlignNegInf;
+    int h_a1 = edge, h_b1 = edge, e_a1 = kAlignNegInf, e_b1 = kAlignNegInf;    // rows i + 2, i + 3
     if (!first) {
-        h_a = bh[0]; h_b = bh[64];
-        if constexpr (kAffine) { e_a0 = be[0]; e_b0 = be[64]; }
+        h_a = bh[0]; h_b = bh[64]; h_a1 = bh[128]; h_b1 = bh[192];
+        if constexpr (kAffine) { e_a0 = be[0]; e_b0 = be[64]; e_a1 = be[128]; e_b1 = be[192]; }
     }
     int above = corner;      // H of (row i, column c0): the diagonal of row i + 1's first cell
     uint32_t i = 0;
@@ -713,18 +717,19 @@ __device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, co
         fetch(i + 3, b_lo);
         int left_a = h_a, left_b = h_b, diag_a = above, diag_b = h_a, e_a = e_a0, e_b = e_b0;
         above = h_b;
+        h_a = h_a1; h_b = h_b1; e_a0 = e_a1; e_b0 = e_b1;
         if (!first) {
-            h_a = bh[64 * (i + 2)]; h_b = bh[64 * (i + 3)];
-            if constexpr (kAffine) { e_a0 = be[64 * (i + 2)]; e_b0 = be[64 * (i + 3)]; }
+            h_a1 = bh[64 * (i + 4)]; h_b1 = bh[64 * (i + 5)];
+            if constexpr (kAffine) { e_a1 = be[64 * (i + 4)]; e_b1 = be[64 * (i + 5)]; }
         }
         int out_a = 0, out_b = 0, oute_a = 0, oute_b = 0;
 #pragma unroll
         for (int g4 = 0; g4 <= W; g4 += 4) {
-            if (g4 < W && (uint32_t)g4 < cols_here) {
+            if (g4 < W && (kFull || (uint32_t)g4 < cols_here)) {
                 align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<1>(ra, none, sel + (g4 >> 2)), diag_a, left_a, e_a, best, open, ext, open_minus_ext);
                 if (g4 == W - 4) { out_a = left_a; oute_a = e_a; }
             }
-            if (g4 >= 4 && (uint32_t)(g4 - 4) < cols_here) {
+            if (g4 >= 4 && (kFull || (uint32_t)(g4 - 4) < cols_here)) {
                 align_group<W, kAffine, kLocal>(H, F, g4 - 4, align_costs4<1>(rb, none, sel + ((g4 - 4) >> 2)), diag_b, left_b, e_b, best, open, ext, open_minus_ext);
                 if (g4 == W) { out_b = left_b; oute_b = e_b; }
             }
@@ -738,7 +743,7 @@ __device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, co
         int left = h_a, diag = above, e = e_a0;
 #pragma unroll
         for (int g4 = 0; g4 < W; g4 += 4)
-            if ((uint32_t)g4 < cols_here)
+            if (kFull || (uint32_t)g4 < cols_here)
                 align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<1>(a_lo, none, sel + (g4 >> 2)), diag, left, e, best, open, ext, open_minus_ext);
         if (more) {
             bh[64 * i] = left;
@@ -872,7 +877,10 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_long(AlignShor
                 }
                 const uint32_t cols_here = n_max - c0 < (uint32_t)W ? n_max - c0 : (uint32_t)W;
                 const uint32_t n_here = (n > c0 && n <= c0 + W) ? n - c0 : 0u;     // my string ends in this pass: capture
-                align_pass<W, kAffine, kLocal>(wl.qcls, qlen, sel, n_here, cols_here, (const char *)&wl.ctab[0][0], open, ext, p == 0, p + 1 < passes, bh, be, result, best);
+                if (cols_here == (uint32_t)W)
+                    align_pass<W, kAffine, kLocal, true>(wl.qcls, qlen, sel, n_here, cols_here, (const char *)&wl.ctab[0][0], open, ext, p == 0, p + 1 < passes, bh, be, result, best);
+                else
+                    align_pass<W, kAffine, kLocal, false>(wl.qcls, qlen, sel, n_here, cols_here, (const char *)&wl.ctab[0][0], open, ext, p == 0, p + 1 < passes, bh, be, result, best);
             }
             if (fits) {
                 int score;

@@ -270,6 +270,11 @@ static uint32_t band_max_bound() {
     static const uint32_t most = [] { const char *e = getenv("STRINGWARS_AMD_BAND_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : kBandMaxBound; return v > kBandMaxBound ? kBandMaxBound : v; }();
     return most;
 }
+// Longest string k_align_cross_long is chosen for (STRINGWARS_AMD_ALIGN_LONG_MAX=n moves it; the kernel itself takes queries up to 4096)
+static uint32_t align_long_limit() {
+    static const uint32_t limit = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_LONG_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : 384u; return v > 4096u ? 4096u : v; }();
+    return limit;
+}
 static int short_route_choice() {
     static const int choice = [] {
         const char *e = getenv("STRINGWARS_AMD_SHORT");
@@ -432,11 +437,13 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             if (known && (guaranteed || can_verify) && (both <= 32 || wide)) {
                 route = kRouteAlignShort;
                 longest = both;
-            } else if (known && can_verify && spec.cross && !scope->align_wide_off && both <= 384) {
+            } else if (known && can_verify && spec.cross && !scope->align_wide_off &&
+                       (both <= align_long_limit() || (engine->kind == 1 && engine->scoring.open != engine->scoring.extend && both <= 2048 && align_long_limit() >= 384))) {
                 // up to 384 symbols -- below the column-profile kernel's range, where the wavefront class kernels used to run -- on the
                 // same small-alphabet condition: columns in passes of 128 (Gotoh: 64), the boundary column between passes through global
-                // memory (alignshort.hip: k_align_cross_long). (The kernel takes any length; on 1 K-symbol DNA its linear form measured
-                // 9.6 TCUPS against the profile kernel's 10.0, so longer strings stay there.)
+                // memory (alignshort.hip: k_align_cross_long). The kernel takes any length; on 1 K-symbol DNA its linear forms measured
+                // 9.6 (NW) / 5.3 (SW) TCUPS against the profile kernel's 10.0 / 6.2, so longer strings stay there -- except global
+                // Gotoh, which it runs at 6.1 against 5.7: that one goes up to 2048 symbols (a boundary buffer of ~2 GB).
                 route = kRouteAlignLong;
                 longest = la_max;
             }

@@ -25,6 +25,7 @@ KERNELS = {
     "nwprofile": ("k_nwprofile<", ("nwprofile.hip", "common.hpp")),
     "align_short": ("swh::k_align_short<", ("alignshort.hip", "bp_window.hpp", "common.hpp")),
     "align_wide": ("swh::k_align_cross_wide<", ("alignshort.hip", "bp_window.hpp", "common.hpp")),
+    "align_long": ("swh::k_align_cross_long<", ("alignshort.hip", "bp_window.hpp", "common.hpp")),
 }
 
 

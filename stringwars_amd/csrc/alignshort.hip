@@ -691,46 +691,42 @@ __device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, co
         H[k] = edge;
         if constexpr (kAffine) F[k] = kAlignNegInf;
     }
-    auto fetch = [&](uint32_t row, uint4 &lo) {
+    auto fetch = [&](uint32_t row, uint2 &lo) {
         const uint32_t rc = row < m ? rowcls[row] : 0u;
-        const uint2 v = *(const uint2 *)(ctab + rc * 8);
-        lo = make_uint4(v.x, v.y, 0, 0);
+        lo = *(const uint2 *)(ctab + rc * 8);
     };
-    const uint4 none{0, 0, 0, 0};
-    uint4 a_lo, b_lo;
+    auto costs4 = [](const uint2 &r, uint32_t selector) -> uint32_t { return __builtin_amdgcn_perm(r.y, r.x, selector); };
+    uint2 a_lo, b_lo;
     fetch(0, a_lo);
     fetch(1, b_lo);
-    // the parked column: rows i, i + 1 of this iteration, requested TWO iterations ahead (an iteration is ~660 instructions, ~3300
-    // cycles at two waves per SIMD; a global round trip under this load is longer: one iteration of lead left a third of the time
-    // in waits on 1 K-symbol strings). The buffer has slack rows for the requests past the query's end.
+    // the parked column: rows i, i + 1 of this iteration, requested an iteration ahead (two iterations ahead measured the same and
+    // cost the registers that decide between one and two waves per SIMD); the buffer has slack rows for requests past the query's end
     int h_a = edge, h_b = edge, e_a0 = kAlignNegInf, e_b0 = kAlignNegInf;
-    int h_a1 = edge, h_b1 = edge, e_a1 = kAlignNegInf, e_b1 = kAlignNegInf;    // rows i + 2, i + 3
     if (!first) {
-        h_a = bh[0]; h_b = bh[64]; h_a1 = bh[128]; h_b1 = bh[192];
-        if constexpr (kAffine) { e_a0 = be[0]; e_b0 = be[64]; e_a1 = be[128]; e_b1 = be[192]; }
+        h_a = bh[0]; h_b = bh[64];
+        if constexpr (kAffine) { e_a0 = be[0]; e_b0 = be[64]; }
     }
     int above = corner;      // H of (row i, column c0): the diagonal of row i + 1's first cell
     uint32_t i = 0;
     for (; i + 1 < m; i += 2) {
-        const uint4 ra = a_lo, rb = b_lo;
+        const uint2 ra = a_lo, rb = b_lo;
         fetch(i + 2, a_lo);
         fetch(i + 3, b_lo);
         int left_a = h_a, left_b = h_b, diag_a = above, diag_b = h_a, e_a = e_a0, e_b = e_b0;
         above = h_b;
-        h_a = h_a1; h_b = h_b1; e_a0 = e_a1; e_b0 = e_b1;
         if (!first) {
-            h_a1 = bh[64 * (i + 4)]; h_b1 = bh[64 * (i + 5)];
-            if constexpr (kAffine) { e_a1 = be[64 * (i + 4)]; e_b1 = be[64 * (i + 5)]; }
+            h_a = bh[64 * (i + 2)]; h_b = bh[64 * (i + 3)];
+            if constexpr (kAffine) { e_a0 = be[64 * (i + 2)]; e_b0 = be[64 * (i + 3)]; }
         }
         int out_a = 0, out_b = 0, oute_a = 0, oute_b = 0;
 #pragma unroll
         for (int g4 = 0; g4 <= W; g4 += 4) {
             if (g4 < W && (kFull || (uint32_t)g4 < cols_here)) {
-                align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<1>(ra, none, sel + (g4 >> 2)), diag_a, left_a, e_a, best, open, ext, open_minus_ext);
+                align_group<W, kAffine, kLocal>(H, F, g4, costs4(ra, sel[g4 >> 2]), diag_a, left_a, e_a, best, open, ext, open_minus_ext);
                 if (g4 == W - 4) { out_a = left_a; oute_a = e_a; }
             }
             if (g4 >= 4 && (kFull || (uint32_t)(g4 - 4) < cols_here)) {
-                align_group<W, kAffine, kLocal>(H, F, g4 - 4, align_costs4<1>(rb, none, sel + ((g4 - 4) >> 2)), diag_b, left_b, e_b, best, open, ext, open_minus_ext);
+                align_group<W, kAffine, kLocal>(H, F, g4 - 4, costs4(rb, sel[(g4 - 4) >> 2]), diag_b, left_b, e_b, best, open, ext, open_minus_ext);
                 if (g4 == W) { out_b = left_b; oute_b = e_b; }
             }
         }
@@ -744,7 +740,7 @@ __device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, co
 #pragma unroll
         for (int g4 = 0; g4 < W; g4 += 4)
             if (kFull || (uint32_t)g4 < cols_here)
-                align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<1>(a_lo, none, sel + (g4 >> 2)), diag, left, e, best, open, ext, open_minus_ext);
+                align_group<W, kAffine, kLocal>(H, F, g4, costs4(a_lo, sel[g4 >> 2]), diag, left, e, best, open, ext, open_minus_ext);
         if (more) {
             bh[64 * i] = left;
             if constexpr (kAffine) be[64 * i] = e;
@@ -757,8 +753,9 @@ __device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, co
     }
 }
 
+// (two waves per SIMD: past 256 registers hipcc parks values in the accumulator file and the kernel runs alone on its SIMD, at half the rate)
 template <int W, bool kAffine, bool kLocal>
-__global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_long(AlignShortArgs args, int *boundary, uint32_t rows_cap) {
+__global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignShortArgs args, int *boundary, uint32_t rows_cap, uint32_t queries_per_item) {
     __shared__ __attribute__((aligned(16))) char ltable[kClassLdsBytes];
     __shared__ __attribute__((aligned(16))) AlignLongLds wave_lds[kAlignWaves];
     __shared__ SummaryLds summary_lds;
@@ -785,11 +782,11 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_long(AlignShor
     const size_t elem = job.out_elem64 ? 8 : 4;
     unsigned long long cells = 0, syms = 0;
     uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
-    const uint64_t chunks = (nb + 63) / 64, qblocks = (na + kAlignQueries - 1) / kAlignQueries;
+    const uint64_t chunks = (nb + 63) / 64, qblocks = (na + queries_per_item - 1) / queries_per_item;
     const uint64_t items = chunks * qblocks;
     for (uint64_t item = wave_id; item < items; item += waves_total) {
         const uint64_t chunk = item / qblocks, qb = item - chunk * qblocks;
-        const uint64_t q_first = qb * kAlignQueries, q_last = q_first + kAlignQueries < na ? q_first + kAlignQueries : na;
+        const uint64_t q_first = qb * queries_per_item, q_last = q_first + queries_per_item < na ? q_first + queries_per_item : na;
         const uint32_t q_count = (uint32_t)(q_last - q_first);
         const uint64_t cand = chunk * 64 + (uint64_t)lane;
         const bool have = cand < nb;
@@ -933,6 +930,18 @@ uint32_t align_long_waves(const Scope *scope, uint64_t items) {
     return (uint32_t)(blocks ? blocks : 1) * kAlignWaves;
 }
 
+// Queries per work item (one item = those queries x 64 candidates, walked by one wave from start to end). An item of 16 queries of
+// 1 K symbols is 10^9 cells -- a sixth of a second -- and the items go round-robin over the resident waves, so a cross-product of
+// 1774 x 1774 such strings (3108 items on 2048 waves) ran its second round half empty: 9.6 TCUPS where 2048 x 2048 (exactly two
+// rounds) ran 12.8. What an item shares between its queries is only the scan of its candidates' classes (one read of 64 strings),
+// so the items are cut finer until there are sixteen rounds of them, down to one query each.
+uint32_t align_long_queries(const Scope *scope, uint64_t queries, uint64_t candidates) {
+    const uint64_t chunks = (candidates + 63) / 64, resident = (uint64_t)scope->compute_units * 2 * kAlignWaves;
+    uint32_t per_item = kAlignQueries;
+    while (per_item > 1 && chunks * ((queries + per_item - 1) / per_item) < 16 * resident) per_item >>= 1;
+    return per_item;
+}
+
 void launch_align_long(Scope *scope, const KernelArgs &k, uint32_t longest_rows) {
     AlignShortArgs args{};
     args.job = k.job; args.off64 = k.off64;
@@ -940,7 +949,8 @@ void launch_align_long(Scope *scope, const KernelArgs &k, uint32_t longest_rows)
     args.class_table = k.scoring.class_table;
     args.partials = scope->plan_partials; args.done_counter = scope->done_counter; args.summary = scope->summary_target();
     const Job &job = k.job;
-    const uint64_t items = ((job.b.count + 63) / 64) * ((job.a.count + kAlignQueries - 1) / kAlignQueries);
+    const uint32_t per_item = align_long_queries(scope, job.a.count, job.b.count);
+    const uint64_t items = ((job.b.count + 63) / 64) * ((job.a.count + per_item - 1) / per_item);
     const uint32_t waves = align_long_waves(scope, items);
     const dim3 grid(waves / kAlignWaves), block(kAlignWaves * 64);
     const bool affine = k.affine != 0, local = k.local != 0;
@@ -948,10 +958,12 @@ void launch_align_long(Scope *scope, const KernelArgs &k, uint32_t longest_rows)
     const char *name = affine ? (local ? "align_long_affine_local" : "align_long_affine") : (local ? "align_long_local" : "align_long");
     StampGuard guard(scope, name);
     int *boundary = (int *)k.boundary;
-    if (!affine && !local) hipLaunchKernelGGL((k_align_cross_long<128, false, false>), grid, block, 0, scope->stream, args, boundary, rows_cap);
-    else if (!affine) hipLaunchKernelGGL((k_align_cross_long<128, false, true>), grid, block, 0, scope->stream, args, boundary, rows_cap);
-    else if (!local) hipLaunchKernelGGL((k_align_cross_long<64, true, false>), grid, block, 0, scope->stream, args, boundary, rows_cap);
-    else hipLaunchKernelGGL((k_align_cross_long<64, true, true>), grid, block, 0, scope->stream, args, boundary, rows_cap);
+    // pass widths by what fits 256 registers at two waves per SIMD without spilling: a row of 128 for linear global alignment; the local
+    // forms carry the running maximum and their floor, Gotoh a second row (128 columns of local linear spilled 972 bytes per lane to scratch)
+    if (!affine && !local) hipLaunchKernelGGL((k_align_cross_long<128, false, false>), grid, block, 0, scope->stream, args, boundary, rows_cap, per_item);
+    else if (!affine) hipLaunchKernelGGL((k_align_cross_long<64, false, true>), grid, block, 0, scope->stream, args, boundary, rows_cap, per_item);
+    else if (!local) hipLaunchKernelGGL((k_align_cross_long<64, true, false>), grid, block, 0, scope->stream, args, boundary, rows_cap, per_item);
+    else hipLaunchKernelGGL((k_align_cross_long<32, true, true>), grid, block, 0, scope->stream, args, boundary, rows_cap, per_item);
     SWH_HIP_CHECK(hipGetLastError());
 }
 

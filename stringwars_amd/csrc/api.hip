@@ -270,11 +270,18 @@ static uint32_t band_max_bound() {
     static const uint32_t most = [] { const char *e = getenv("STRINGWARS_AMD_BAND_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : kBandMaxBound; return v > kBandMaxBound ? kBandMaxBound : v; }();
     return most;
 }
-// Longest string k_align_cross_long is chosen for (STRINGWARS_AMD_ALIGN_LONG_MAX=n moves it; the kernel itself takes queries up to 4096)
+// Longest string k_align_cross_long is chosen for: the longest query it takes (STRINGWARS_AMD_ALIGN_LONG_MAX=n lowers it) ...
 static uint32_t align_long_limit() {
-    static const uint32_t limit = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_LONG_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : 384u; return v > 4096u ? 4096u : v; }();
+    static const uint32_t limit = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_LONG_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : 4096u; return v > 4096u ? 4096u : v; }();
     return limit;
 }
+// ... and per form, the length up to which it measured faster than the column-profile kernel on DNA cross-products (TCUPS, long
+// kernel : profile kernel):       1 K symbols        3 K symbols
+//      NW linear  (W = 128)       12.8 :  9.9        12.6 : 10.5       -> as far as the kernel goes (a boundary buffer of 4 GB there)
+//      NW affine  (W =  64)        6.1 :  5.7         5.8 :  6.1       -> 2048
+//      SW linear  (W =  64)        6.9 :  6.1         6.6 :  6.6       -> 2048
+//      SW affine  (W =  32)        3.7 :  3.7         3.9 :  3.9       -> stays where the wavefront class kernels were the alternative
+static uint32_t align_long_pays(bool local, bool affine) { return local && affine ? 384u : (local || affine ? 2048u : 4096u); }
 static int short_route_choice() {
     static const int choice = [] {
         const char *e = getenv("STRINGWARS_AMD_SHORT");
@@ -433,17 +440,16 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             const uint32_t both = la_max > lb_max ? la_max : lb_max;
             // up to 128 symbols for cross-products with linear gaps, as long as the candidates of a work item use at most eight symbol
             // classes (DNA; the kernel checks per item, a scope that met richer text stops trying -- `align_wide_off`)
-            const bool wide = spec.cross && both <= 128 && engine->scoring.open == engine->scoring.extend && !scope->align_wide_off && can_verify;
+            static const bool wide_on = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_WIDE"); return !e || atoi(e) != 0; }();   // comparison knob: 0 = the multi-pass kernel instead
+            const bool wide = wide_on && spec.cross && both <= 128 && engine->scoring.open == engine->scoring.extend && !scope->align_wide_off && can_verify;
             if (known && (guaranteed || can_verify) && (both <= 32 || wide)) {
                 route = kRouteAlignShort;
                 longest = both;
             } else if (known && can_verify && spec.cross && !scope->align_wide_off &&
-                       (both <= align_long_limit() || (engine->kind == 1 && engine->scoring.open != engine->scoring.extend && both <= 2048 && align_long_limit() >= 384))) {
-                // up to 384 symbols -- below the column-profile kernel's range, where the wavefront class kernels used to run -- on the
-                // same small-alphabet condition: columns in passes of 128 (Gotoh: 64), the boundary column between passes through global
-                // memory (alignshort.hip: k_align_cross_long). The kernel takes any length; on 1 K-symbol DNA its linear forms measured
-                // 9.6 (NW) / 5.3 (SW) TCUPS against the profile kernel's 10.0 / 6.2, so longer strings stay there -- except global
-                // Gotoh, which it runs at 6.1 against 5.7: that one goes up to 2048 symbols (a boundary buffer of ~2 GB).
+                       both <= std::min(align_long_limit(), align_long_pays(engine->kind == 2, engine->scoring.open != engine->scoring.extend))) {
+                // longer ones on the same small-alphabet condition: columns in passes of 128 (local or Gotoh: 64, both: 32), the boundary
+                // column between passes through global memory (alignshort.hip: k_align_cross_long), up to where it beats the
+                // column-profile kernel (align_long_pays)
                 route = kRouteAlignLong;
                 longest = la_max;
             }
@@ -612,7 +618,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             else if (route == kRouteCrossShort) launch_cross_short(scope, job, off64);
             else if (route == kRouteAlignShort) launch_align_short(scope, k, longest);
             else if (route == kRouteAlignLong) {
-                const uint64_t items = ((uint64_t)(spec.b.count + 63) / 64) * ((uint64_t)(spec.a.count + 15) / 16);
+                const uint32_t per_item = align_long_queries(scope, spec.a.count, spec.b.count);
+                const uint64_t items = ((uint64_t)(spec.b.count + 63) / 64) * ((uint64_t)(spec.a.count + per_item - 1) / per_item);
                 const uint64_t ints = (uint64_t)align_long_waves(scope, items) * (longest + 8) * 64 * (k.affine ? 2 : 1);
                 ensure(scope->boundary, scope->boundary_bytes, ints * sizeof(int32_t));
                 k.boundary = (int32_t *)scope->boundary;

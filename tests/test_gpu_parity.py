@@ -1998,8 +1998,8 @@ def test_banded_windows_of_two_words(sw, orc, scope, utf8):
 @pytest.mark.parametrize("local", [False, True])
 @pytest.mark.parametrize("gaps", [(-2, -2), (-5, -1)])
 def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps):
-    """k_align_cross_long (alignshort.hip): queries x candidates of up to 384 symbols over a small alphabet, the columns run as passes of
-    128 (Gotoh: 64) with the boundary column between passes parked in global memory. Candidate lengths around every pass boundary (0, 1,
+    """k_align_cross_long (alignshort.hip): queries x candidates of any length (up to 4096 symbols) over a small alphabet, the columns run as
+    passes of 128 (local or Gotoh: 64, both: 32) with the boundary column between passes parked in global memory. Candidate lengths around every pass boundary (0, 1,
     63 .. 65, 127 .. 129, 255 .. 257, 300, 384), query lengths odd and even, linear and affine gaps, global and local, the reference's
     unary class costs and a random asymmetric table -- every score against the oracle. The call must run on `align_long`; longer strings,
     or candidates over 26 letters, take the planned path (and score the same)."""
@@ -2032,6 +2032,19 @@ def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps)
     queries, candidates = [dna(200), dna(1400)], [dna(150), dna(40), dna(700)]
     want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
     assert (engine(sw.PreparedTape(fresh, sw.Strs(queries)), sw.PreparedTape(fresh, sw.Strs(candidates)), fresh) == want).all()
+    # longer ones: the kernel is chosen as far as it measured faster than the column profiles (api.hip: align_long_pays) -- 4096 symbols
+    # for linear global alignment, 2048 for Gotoh or local, 384 for both -- and the scores are the oracle's on either side of that
+    limit = 384 if (local and gaps[0] != gaps[1]) else (2048 if (local or gaps[0] != gaps[1]) else 4096)
+    for top in (2048, 4096):
+        queries = [dna(top), dna(top - 1), dna(top // 2 + 3)]
+        candidates = [dna(n) for n in (150, 40, 700, top, top // 2 + 1, top - 511, 0)] + [dna(n) for n in rng.integers(1, top + 1, 60)]
+        fresh.set_profiling(True)
+        got = engine(sw.PreparedTape(fresh, sw.Strs(queries)), sw.PreparedTape(fresh, sw.Strs(candidates)), fresh)
+        name = fresh.last_timing()["dominant_name"]
+        fresh.set_profiling(False)
+        assert name.startswith("align_long") == (top <= limit), (top, limit, name)
+        want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
+        assert (got == want).all(), (top, np.argwhere(got != want)[:5])
     text = [bytes(rng.integers(97, 123, int(n), dtype=np.uint8)) for n in rng.integers(150, 420, 80)]
     want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in text[10:]] for x in text[:10]])
     fresh2 = sw.DeviceScope(gpu_device=0)

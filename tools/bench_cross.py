@@ -15,6 +15,8 @@ def tokens(kind, count, rng):
         lens = np.full(count, 100)
     elif kind == "acgt1k":
         lens = np.full(count, 1000)
+    elif kind.startswith("acgt"):   # acgt<N>: any other fixed length, for route experiments
+        lens = np.full(count, int(kind[4:]))
     elif kind == "words":
         lens = np.clip(rng.poisson(4.0, count) + 1, 1, 24)
     elif kind == "lines":
@@ -49,6 +51,7 @@ def main():
             "linear/NeedlemanWunschScores": sw.NeedlemanWunschScores(classes, costs, open=-2, extend=-2, capabilities=scope),
             "affine/NeedlemanWunschScores": sw.NeedlemanWunschScores(classes, costs, open=-5, extend=-1, capabilities=scope),
             "linear/SmithWatermanScores": sw.SmithWatermanScores(classes, costs, open=-2, extend=-2, capabilities=scope),
+            "affine/SmithWatermanScores": sw.SmithWatermanScores(classes, costs, open=-5, extend=-1, capabilities=scope),
         }
         for name, engine in engines.items():
             call = lambda: engine(q, c, scope, out=int(out_ptr.value))

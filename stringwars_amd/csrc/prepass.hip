@@ -1168,6 +1168,43 @@ __device__ __forceinline__ uint32_t status_flag(unsigned long long word, uint32_
     return (uint32_t)(word >> 48) == epoch ? (uint32_t)(word >> 46) & 3u : 0u;
 }
 
+// What the first byte of a sequence says about it, one 16-byte entry per byte value (a workgroup keeps the table in LDS):
+//   lead  -- its payload bits where they sit in the scalar value (<< 6 per continuation byte);
+//   shape -- bits 0..4: how far the 18 payload bits of the three bytes after it are shifted down (6 per byte the sequence does not
+//            have), bits 16..: the sequence's length in bytes (summed per thread: the balance of claimed and held bytes);
+//   cont  -- bits 0..4: how many of those payload bits belong to the sequence (the width of a v_bfe), bits 22, 23, 30, 31: the top
+//            two bits of its third and fourth byte where it has them -- they must read 10;
+//   range -- low half / high half: the range of (second byte << 8 | first byte): the second byte is a continuation byte, E0 / F0
+//            are not followed by an overlong form, ED not by a surrogate, F4 by nothing past U+10FFFF; C0, C1, F5..FF are never
+//            valid (an empty range: no value is its own median there).
+// Continuation bytes get a neutral entry (length 0, any second byte): every byte position is looked up, only lead bytes store.
+struct alignas(16) Utf8Lead { uint32_t lead, shape, cont, range; };
+constexpr Utf8Lead utf8_lead(uint32_t b) {
+    if (b < 0x80u) return Utf8Lead{b, 18u | 1u << 16, 0u, (0xFF00u | b) << 16 | b};
+    if (b < 0xC0u) return Utf8Lead{0u, 18u, 0u, 0xFFFF0000u};
+    if (b < 0xC2u || b > 0xF4u) return Utf8Lead{0u, 18u | 1u << 16, 0u, (b ^ 0xFFu) << 16 | (b ^ 0xFFu)};
+    const uint32_t lo = b == 0xE0u ? 0xA0u : (b == 0xF0u ? 0x90u : 0x80u), hi = b == 0xEDu ? 0x9Fu : (b == 0xF4u ? 0x8Fu : 0xBFu);
+    const uint32_t need = b < 0xE0u ? 1u : (b < 0xF0u ? 2u : 3u);
+    const uint32_t payload = b & (0x3Fu >> need);
+    const uint32_t tops = need == 3u ? 0xC0C00000u : (need == 2u ? 0x00C00000u : 0u);
+    return Utf8Lead{payload << (6u * need), (18u - 6u * need) | (need + 1u) << 16, tops | 6u * need, (hi << 8 | b) << 16 | (lo << 8 | b)};
+}
+struct Utf8LeadTable { Utf8Lead e[256]; };
+constexpr Utf8LeadTable make_utf8_leads() {
+    Utf8LeadTable t{};
+    for (uint32_t b = 0; b < 256; ++b) t.e[b] = utf8_lead(b);
+    return t;
+}
+__device__ const Utf8LeadTable kUtf8Leads = make_utf8_leads();
+
+struct Utf8DecodeLds {
+    uint32_t wave_tot[kUtf8Passes][4];
+    int wave_bal[4];
+    uint16_t leads[kUtf8Tile];          // byte positions of the tile's lead bytes in rank order
+    uint32_t raw[kUtf8Tile / 4 + 4];    // the tile's bytes (+ the word after it)
+    Utf8Lead table[256];
+};
+
 // One tape of a staging launch (both tapes of a call are staged by ONE launch: tickets [0, a.tiles) are tape a's tiles).
 struct Utf8TileJob {
     const uint8_t *data; uint64_t total, tiles;
@@ -1175,7 +1212,7 @@ struct Utf8TileJob {
 };
 
 __global__ __launch_bounds__(256) void k_utf8_tile_decode(Utf8TileJob job_a, Utf8TileJob job_b, uint32_t *ticket, uint32_t *invalid, uint32_t epoch) {
-    __shared__ Utf8WriteLds lds;
+    __shared__ Utf8DecodeLds lds;
     __shared__ unsigned long long tile_base;
     __shared__ uint32_t my_tile;
     // One workgroup per tile. (Workgroups that loop over the ticket -- a grid of what the device holds at once -- take the same
@@ -1217,6 +1254,7 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(Utf8TileJob job_a, Utf
     uint32_t curs[kUtf8Passes], flags[kUtf8Passes];
     uint32_t after = 0;   // the word after the tile: look-ahead of its last sequences
     int held = 0;         // continuation bytes in my words
+    *(uint4 *)&lds.table[threadIdx.x] = *(const uint4 *)&kUtf8Leads.e[threadIdx.x];
     if (!edge) {
         const uint8_t *src = data + tile * kUtf8Tile + threadIdx.x * 4;
 #pragma unroll
@@ -1298,29 +1336,41 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(Utf8TileJob job_a, Utf
     }
     __syncthreads();
     uint32_t *out = symbols + tile_base;
-    int bal = -held;   // continuation bytes the sequences I decode expect, minus continuation bytes I hold
-    bool bad = false;
-    uint32_t bad_at = 0;
-    // (four sequences per thread and round, their LDS reads issued together, changed nothing: the kernel is bound by its VALU
-    // instructions -- 43 lane operations per byte, two thirds of them in this loop -- not by LDS latency)
+    // One code point per lane and round, in rank order (the stores are full lines): the lead's byte position, the four bytes from
+    // it on, one ds_read_b128 of what the lead byte says (table above), the range of the first two bytes (v_med3_u16: a value
+    // inside the range is its own median), the third and fourth byte's top bits, the length, the payload of the three bytes after
+    // it (three v_bfe, two v_lshl_or) cut to the sequence's own (v_bfe) under the lead's.
+    // (27 instructions per code point where the scalar-assembling decode of round 3 took 65 -- and the same 0.25 ms for C3's two
+    // tapes side by side: what bounds this kernel is the tiles in flight over a tile's latencies, not its instructions. Measured
+    // on the way, all slower or equal, DESIGN 4.4: every byte position decoded in place with the lanes storing their own code
+    // points (0.33 ms: the lines arrive in pieces), the same staged through LDS and stored in full lines (0.29), counts published
+    // 2048 tiles ahead + the look-back before the scan (0.29), barriers that do not wait for stores (no change), half a tile of
+    // lead positions at a time for 7 workgroups per CU instead of 5 (0.28). Timestamps per tile: ticket + loads ~3 us, look-back
+    // ~5 us -- a round trip of the status words under the stores of 1.3 K tiles in flight --, decode + stores ~5 us.)
+    uint32_t wrong_pair = 0, wrong_tops = 0, shapes = 0;
     for (uint32_t i = threadIdx.x; i < tile_total; i += 256) {
         const uint32_t at = lds.leads[i];
         const uint32_t lo = lds.raw[at >> 2], hi = lds.raw[(at >> 2) + 1];
-        const uint32_t seq = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (at & 3u)));
-        uint32_t need;
-        bool bad_here;
-        const uint32_t cp = utf8_decode_one(seq, need, bad_here);
-        bal += (int)need;
-        // a sequence may not run past the end of the tape (the zero bytes read there are no continuation bytes, so `bad_here` has it)
-        if (bad_here && !bad) { bad = true; bad_at = at; }
-        out[i] = cp;
+        const uint32_t sq = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (at & 3u)));
+        const uint4 e = *(const uint4 *)&lds.table[sq & 0xFFu];   // x lead, y shape, z cont, w range
+        uint32_t inside;
+        asm volatile("v_med3_u16 %0, %1, %2, %2 op_sel:[0,0,1,0]" : "=v"(inside) : "v"(sq), "v"(e.w));
+        wrong_pair |= inside ^ sq;                       // (bits 16.. are noise: the low half is tested)
+        wrong_tops |= (sq ^ 0x80800000u) & e.z;          // (bits 0..4 are noise: the top bits are tested)
+        shapes += e.y;
+        const uint32_t after3 = (((sq >> 8 & 0x3Fu) << 6 | (sq >> 16 & 0x3Fu)) << 6) | (sq >> 24 & 0x3Fu);
+        out[i] = e.x | __builtin_amdgcn_ubfe(after3, e.y, e.z);
     }
+    // the bytes my sequences claim minus the continuation bytes I hold (and, below, the tile's lead bytes): zero over a valid tape
+    int bal = (int)(shapes >> 16) - held;
+    const bool bad = ((wrong_pair & 0xFFFFu) | (wrong_tops & 0xC0C00000u)) != 0;
+    const uint32_t bad_at = threadIdx.x * 4;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) bal += __shfl_xor(bal, off);
     if (lane == 0) lds.wave_bal[wave] = bal;
     if (bad) atomicCAS(invalid, 0u, (uint32_t)((tile * kUtf8Tile + bad_at) >> 2) + 1u);
     __syncthreads();
-    if (threadIdx.x == 0) balance[tile] = lds.wave_bal[0] + lds.wave_bal[1] + lds.wave_bal[2] + lds.wave_bal[3];
+    if (threadIdx.x == 0) balance[tile] = lds.wave_bal[0] + lds.wave_bal[1] + lds.wave_bal[2] + lds.wave_bal[3] - (int)tile_total;
     }
 }
 

@@ -924,9 +924,16 @@ __global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignS
 }
 
 // waves (= boundary areas) a launch of the multi-pass kernel gets: two four-wave workgroups per CU (a 128-column row, or 64
-// columns of H and F, leave two waves per SIMD), never more than it has work items
-uint32_t align_long_waves(const Scope *scope, uint64_t items) {
-    const uint64_t blocks = std::min<uint64_t>((items + kAlignWaves - 1) / kAlignWaves, (uint64_t)scope->compute_units * 2);
+// columns of H and F, leave two waves per SIMD), never more than it has work items -- and never more than kAlignBoundaryBytes of
+// boundary columns (an area is (longest_rows + 8) x 64 ints, twice that for Gotoh's E: queries of 4096 symbols on the 2048 waves of
+// 256 compute units are 2.2 GB, 4.3 for Gotoh; past the budget the launch gets fewer waves instead of a bigger buffer)
+constexpr uint64_t kAlignBoundaryBytes = 4ull << 30;
+uint32_t align_long_waves(const Scope *scope, uint64_t items, uint32_t longest_rows, bool affine) {
+    const uint64_t area = (uint64_t)(longest_rows + 8) * 64 * sizeof(int32_t) * (affine ? 2 : 1) * kAlignWaves;   // per workgroup
+    uint64_t blocks = std::min<uint64_t>((items + kAlignWaves - 1) / kAlignWaves, (uint64_t)scope->compute_units * 2);
+    const char *e = getenv("STRINGWARS_AMD_ALIGN_BOUNDARY_MB");   // (read per launch: a test lowers it to meet the cap on small inputs)
+    const uint64_t budget = e ? (uint64_t)atoll(e) << 20 : kAlignBoundaryBytes;
+    blocks = std::min<uint64_t>(blocks, budget / area);
     return (uint32_t)(blocks ? blocks : 1) * kAlignWaves;
 }
 
@@ -951,7 +958,7 @@ void launch_align_long(Scope *scope, const KernelArgs &k, uint32_t longest_rows)
     const Job &job = k.job;
     const uint32_t per_item = align_long_queries(scope, job.a.count, job.b.count);
     const uint64_t items = ((job.b.count + 63) / 64) * ((job.a.count + per_item - 1) / per_item);
-    const uint32_t waves = align_long_waves(scope, items);
+    const uint32_t waves = align_long_waves(scope, items, longest_rows, k.affine != 0);
     const dim3 grid(waves / kAlignWaves), block(kAlignWaves * 64);
     const bool affine = k.affine != 0, local = k.local != 0;
     const uint32_t rows_cap = longest_rows + 8;

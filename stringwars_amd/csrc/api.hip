@@ -277,7 +277,7 @@ static uint32_t align_long_limit() {
 }
 // ... and per form, the length up to which it measured faster than the column-profile kernel on DNA cross-products (TCUPS, long
 // kernel : profile kernel):       1 K symbols        3 K symbols
-//      NW linear  (W = 128)       12.8 :  9.9        12.6 : 10.5       -> as far as the kernel goes (a boundary buffer of 4 GB there)
+//      NW linear  (W = 128)       12.8 :  9.9        12.6 : 10.5       -> as far as the kernel goes (a boundary buffer of 2.2 GB there)
 //      NW affine  (W =  64)        6.1 :  5.7         5.8 :  6.1       -> 2048
 //      SW linear  (W =  64)        6.9 :  6.1         6.6 :  6.6       -> 2048
 //      SW affine  (W =  32)        3.7 :  3.7         3.9 :  3.9       -> stays where the wavefront class kernels were the alternative
@@ -620,7 +620,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             else if (route == kRouteAlignLong) {
                 const uint32_t per_item = align_long_queries(scope, spec.a.count, spec.b.count);
                 const uint64_t items = ((uint64_t)(spec.b.count + 63) / 64) * ((uint64_t)(spec.a.count + per_item - 1) / per_item);
-                const uint64_t ints = (uint64_t)align_long_waves(scope, items) * (longest + 8) * 64 * (k.affine ? 2 : 1);
+                const uint64_t ints = (uint64_t)align_long_waves(scope, items, longest, k.affine != 0) * (longest + 8) * 64 * (k.affine ? 2 : 1);
                 ensure(scope->boundary, scope->boundary_bytes, ints * sizeof(int32_t));
                 k.boundary = (int32_t *)scope->boundary;
                 launch_align_long(scope, k, longest);

@@ -476,7 +476,7 @@ void launch_align_short(Scope *scope, const KernelArgs &args, uint32_t longest);
 // the same for queries x candidates of any length over a small alphabet (<= 8 classes per work item): columns in passes of 128
 // (Gotoh: 64), the boundary column between passes in args.boundary -- align_long_waves() areas of (longest_rows + 8) x 64 ints
 // (x 2 for Gotoh's E); queries of up to 4096 symbols
-uint32_t align_long_waves(const Scope *scope, uint64_t items);
+uint32_t align_long_waves(const Scope *scope, uint64_t items, uint32_t longest_rows, bool affine);   // (capped at 4 GB of boundary columns)
 uint32_t align_long_queries(const Scope *scope, uint64_t queries, uint64_t candidates);   // queries per work item (16 .. 1)
 void launch_align_long(Scope *scope, const KernelArgs &args, uint32_t longest_rows);
 

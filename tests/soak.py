@@ -172,8 +172,9 @@ def main():
             assert (engine.pairs(a, b, scope) == want).all(), ("second call", kind, classes, gaps, lo, hi)
             pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
             assert (engine.pairs(pa, pb, scope) == want).all(), ("prepared", kind, classes, gaps, lo, hi)
-            cut = int(rng.choice([16, 32, 64, 128, 200, 384]))   # (beyond 128: columns in passes, k_align_cross_long)
-            qs, cs = [x[:cut] for x in items_a[:23]], [x[:cut] for x in items_b[:150]]
+            cut = int(rng.choice([16, 32, 64, 128, 200, 384, 1000, 2048, 4096]))   # (beyond 128: columns in passes, k_align_cross_long)
+            few = cut > 384   # (the oracle's share: 7 x 70 strings of up to 4 K symbols are ~10^9 cells)
+            qs, cs = [x[:cut] for x in items_a[:7 if few else 23]], [x[:cut] for x in items_b[:70 if few else 150]]
             flat = np.array([[oracle.nw_score(x, y, matrix, gaps[0], gaps[1], local=(kind == "sw")) for y in cs] for x in qs])
             assert (engine(sw.PreparedTape(scope, sw.Strs(qs)), sw.PreparedTape(scope, sw.Strs(cs)), scope) == flat).all(), ("cross-product", kind, classes, gaps, cut)
             if rounds % 3 == 0:   # the same batch over the three-member scope (per-member engine clones), and a small cross-product

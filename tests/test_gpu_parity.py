@@ -2045,6 +2045,20 @@ def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps)
         assert name.startswith("align_long") == (top <= limit), (top, limit, name)
         want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
         assert (got == want).all(), (top, np.argwhere(got != want)[:5])
+    # the boundary columns are capped (4 GB; a launch past that gets fewer waves): with a budget of 3 MB the 200 x 70 strings below
+    # run on one or two workgroups, every wave taking many work items in turn
+    os.environ["STRINGWARS_AMD_ALIGN_BOUNDARY_MB"] = "3"
+    try:
+        queries, candidates = [dna(n) for n in rng.integers(300, 385, 200)], [dna(n) for n in rng.integers(1, 385, 70)]
+        fresh.set_profiling(True)
+        got = engine(sw.PreparedTape(fresh, sw.Strs(queries)), sw.PreparedTape(fresh, sw.Strs(candidates)), fresh)
+        name = fresh.last_timing()["dominant_name"]
+        fresh.set_profiling(False)
+    finally:
+        del os.environ["STRINGWARS_AMD_ALIGN_BOUNDARY_MB"]
+    assert name.startswith("align_long"), name
+    want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
+    assert (got == want).all(), np.argwhere(got != want)[:5]
     text = [bytes(rng.integers(97, 123, int(n), dtype=np.uint8)) for n in rng.integers(150, 420, 80)]
     want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in text[10:]] for x in text[:10]])
     fresh2 = sw.DeviceScope(gpu_device=0)

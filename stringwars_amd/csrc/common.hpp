@@ -260,7 +260,7 @@ __device__ __forceinline__ void report_call_summary(const PlanPartial &mine, Pla
 }
 
 // partials[0, kMaxPartials) belong to k_plan_hist, [kMaxPartials, 2 kMaxPartials) to k_direct_short (see PrepassArgs::leftover)
-constexpr int kMaxPartials = 2048;
+constexpr int kMaxPartials = 4096;
 
 // Class numbering --------------------------------------------------------------------------------
 // 0                : trivial pairs (an empty side, or cutoff decided by lengths) -- finished in the pre-pass

@@ -23,10 +23,16 @@
 
 namespace swh {
 
-constexpr int kShortThreads = 256, kShortWaves = 4, kShortPer = 4;
+// (make EXTRA=-DSWH_SHORT_THREADS=64 builds the kernel with one-wave workgroups and chunks of 256 pairs -- a wave owning its chunk
+// end to end, no barrier that costs anything, no ticket between waves: bit-exact, and 0.386 ms for C5's 20 M pairs against 0.187)
+#ifndef SWH_SHORT_THREADS
+#define SWH_SHORT_THREADS 256
+#endif
+constexpr int kShortThreads = SWH_SHORT_THREADS, kShortWaves = kShortThreads / 64, kShortPer = 4;
 constexpr int kShortChunk = kShortThreads * kShortPer;   // pairs per chunk
 constexpr int kShortMaxLen = 16;
-constexpr int kShortCap = 6912;      // bytes of one tape's segment a chunk may bring into LDS (432 units of 16; keeps the workgroup below 40 KB)
+constexpr int kShortCap = 6912 * kShortThreads / 256;      // bytes of one tape's segment a chunk may bring into LDS (432 units of 16; keeps the workgroup below 40 KB)
+constexpr int kShortPerCu = kShortThreads == 256 ? 4 : 13;   // workgroups a compute unit holds (LDS)
 constexpr int kShortPad = 16;        // before (tail windows reach back 8 bytes) and after (16-byte windows reach forward)
 constexpr int kShortKeys = 256;      // (text length - 1) * 16 + (pattern length - 1)
 
@@ -48,7 +54,7 @@ struct __attribute__((aligned(4096))) ShortLds {
     uint32_t mixed;                                     // some byte of the chunk differs from its wave's first byte in the upper three bits
     uint32_t refs[kShortWaves];                         // those first bytes' upper three bits, broadcast over a dword
 };
-static_assert(sizeof(ShortLds) <= 40960, "four workgroups per compute unit");
+static_assert(sizeof(ShortLds) <= 163840 / kShortPerCu, "workgroups per compute unit");
 
 // NibbleTables (bp_window.hpp) for 16-row patterns: entry v of Lo sits at tbase + (v << 7), of Hi at tbase + 2048 + (v << 7),
 // tbase = the wave's table + 4 * (lane & 31); lanes >= 32 keep their bits in the upper half of the shared dword.
@@ -278,7 +284,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         // ---- A: the chunk's segments into LDS (requested while the previous chunk's work items ran) ---------------------------
         const bool cand = candidate(cand_base, cand_len);
         const Off cand_bounds = bounds_request(cand, cand_base, cand_len);
-        lds.hist[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < kShortKeys; i += kShortThreads) lds.hist[i] = 0;
         if (threadIdx.x == 0) lds.ticket = 0;
         // Do all bytes of the chunk share their upper three bits? (Checked on the 16-byte units as they arrive -- units past
         // the segments hold the tapes' next bytes: a false alarm there only costs the chunk its fast path.) The previous
@@ -314,7 +320,9 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         SHORT_STAMP(0);   // A: copy
         __syncthreads();
         SHORT_STAMP(1);   // barrier after A
-        const bool one_table = kWide && !lds.mixed && lds.refs[0] == lds.refs[1] && lds.refs[0] == lds.refs[2] && lds.refs[0] == lds.refs[3];
+        bool one_table = kWide && !lds.mixed;
+#pragma unroll
+        for (int w = 1; w < kShortWaves; ++w) one_table = one_table && lds.refs[0] == lds.refs[w];
         // ---- B: cut the common affixes, finish what is trivial, count the rest by (text, pattern) length -------------
         // (the LDS windows of two pairs are requested before the first one is used, no branch in between; all four at once
         // hold 48 dwords in flight and spill)
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(kShortThreads, 4) void k_short_tiled(ShortArgs args
 }
 
 void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64, uint32_t mean_bytes_x16) {
-    int per_cu = 4;
+    int per_cu = kShortPerCu;
     uint32_t slots = (uint32_t)scope->compute_units * (uint32_t)per_cu;
     if (slots > (uint32_t)kMaxPartials) slots = kMaxPartials;
     // A chunk's segments must fit the LDS arrays: with strings of `mean` bytes a chunk holds kShortCap / mean pairs, less a

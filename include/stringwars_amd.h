@@ -13,7 +13,10 @@
  * torch CUDA tensors) -- used in place, the steady state the benchmark times -- or HOST memory
  * (pageable, pinned, managed), in which case the call stages it through PCIe itself. Calls are
  * synchronous (results are visible on return, like `compute_into`, bench.rs:478-486) unless the
- * scope was switched to asynchronous mode with `swh_scope_set_async`.
+ * scope was switched to asynchronous mode with `swh_scope_set_async`. "Visible on return" for an
+ * output in device memory: every result has been written through to memory and acknowledged, any
+ * stream, device or copy may read it; the scope's own stream may still be retiring the kernel
+ * (the call returns on the kernel's summary, not on the stream: DESIGN.md section 3).
  */
 #ifndef STRINGWARS_AMD_H_
 #define STRINGWARS_AMD_H_

@@ -371,8 +371,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
             if (fits) {
                 if (!runs) score = align_trivial(la, lb, kLocal, open, ext);
                 char *dst = job.out + p * job.out_stride;
-                if (job.out_elem64) *(int64_t *)dst = (int64_t)score;
-                else *(int32_t *)dst = score;
+                store_out(dst, job.out_elem64 != 0, (int64_t)score);
                 shorts += 1;
             }
             if (have) {
@@ -443,8 +442,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
                 if (fits) {
                     if (!m) score = align_trivial(qlen, lb, kLocal, open, ext);
                     char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
-                    if (job.out_elem64) *(int64_t *)dst = (int64_t)score;
-                    else *(int32_t *)dst = score;
+                    store_out(dst, job.out_elem64 != 0, (int64_t)score);
                 }
             }
             if (have) {
@@ -620,8 +618,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
             if (fits) {
                 if (!n || !qlen) score = align_trivial(qlen, lb, kLocal, open, ext);
                 char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
-                if (job.out_elem64) *(int64_t *)dst = (int64_t)score;
-                else *(int32_t *)dst = score;
+                store_out(dst, job.out_elem64 != 0, (int64_t)score);
             }
         }
         if (have) {
@@ -886,8 +883,7 @@ __global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignS
                 else if constexpr (kAffine) score = result + (int)(qlen + n) * ext - open_minus_ext;
                 else score = result + (int)(qlen + n) * ext;
                 char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
-                if (job.out_elem64) *(int64_t *)dst = (int64_t)score;
-                else *(int32_t *)dst = score;
+                store_out(dst, job.out_elem64 != 0, (int64_t)score);
             }
         }
         if (have) {

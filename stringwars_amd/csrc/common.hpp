@@ -67,6 +67,15 @@ __device__ __forceinline__ void pair_extent(const Job &job, uint64_t p, uint64_t
     b0 = (uint64_t)y0; lb = (uint32_t)(y1 - y0);
 }
 
+// A result leaves as an agent-scope atomic store (`global_store ... sc1`): written through to where every XCD -- and a copy engine --
+// reads it, where a plain store to coarse-grained device memory stays in the writing XCD's L2 until the kernel's end. The kernels
+// that report a call summary promise "every result is out" with it (report_call_summary), and a synchronous call returns on that
+// word instead of on the stream (api.hip: wait_for_summary); results are written once, so nothing is lost by not caching them.
+__device__ __forceinline__ void store_out(char *dst, bool elem64, int64_t value) {
+    if (elem64) __hip_atomic_store((long long *)dst, (long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store((int *)dst, (int)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void store_result(const Job &job, uint64_t p, int64_t value) {
     char *dst;
     if (job.cross) {
@@ -76,8 +85,7 @@ __device__ __forceinline__ void store_result(const Job &job, uint64_t p, int64_t
     } else {
         dst = job.out + p * job.out_stride;
     }
-    if (job.out_elem64) *(int64_t *)dst = value;
-    else *(int32_t *)dst = (int32_t)value;
+    store_out(dst, job.out_elem64 != 0, value);
 }
 
 // Lanes of one wave that hand data to each other through LDS still need a fence: the compiler reasons per
@@ -177,7 +185,9 @@ struct CallSummary {
     // summary is only READ when the host happens to synchronise right behind it (pipelined lanes carry two calls between
     // synchronisations, a sharded call four pieces). Asynchronous calls report into slot 1 of the scope's summary block and
     // swh_scope_synchronize looks at slot 1's `sticky`; synchronous calls (slot 0) handle `violation` on the spot.
-    uint32_t sticky, pad;
+    // `landed`: written (1) after everything else, by the last workgroup, once every workgroup's result stores were acknowledged:
+    // the host clears it before a synchronous call's launch and returns when it reads 1 (api.hip: wait_for_summary).
+    uint32_t sticky, landed;
 };
 static_assert(sizeof(CallSummary) == 40, "two summary slots share the scope's 256-byte host-mapped block");
 // Tail of the kernels that run without the planning pre-pass, called by every thread of the workgroup; thread 0 passes the
@@ -200,6 +210,9 @@ __device__ __forceinline__ void report_call_summary(const PlanPartial &mine, Pla
                                                     CallSummary *summary, SummaryLds &lds) {
     auto &rcells = lds.rcells; auto &rsyms = lds.rsyms;
     auto &rmaxa = lds.rmaxa; auto &rmaxb = lds.rmaxb; auto &rshort = lds.rshort; auto &rviol = lds.rviol;
+    // every wave's result stores are acknowledged before the workgroup counts as done (a workgroup barrier waits for LDS, not for them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         // The row goes out as agent-scope atomic stores (written through to where every XCD sees them) and the counter is
         // bumped once they are acknowledged: ordering by completion, without `__threadfence()` -- a release/acquire pair at
@@ -256,6 +269,8 @@ __device__ __forceinline__ void report_call_summary(const PlanPartial &mine, Pla
         __hip_atomic_store(&summary->violation, viol ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (viol) __hip_atomic_store(&summary->sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the summary's words (and the counter's reset) before the word that says so
+        __hip_atomic_store(&summary->landed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

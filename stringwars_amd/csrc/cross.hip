@@ -174,8 +174,7 @@ __global__ __launch_bounds__(kCrossWaves * 64) void k_cross_short(CrossArgs args
                     const uint32_t mask = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u);
                     const uint32_t d = n + __popc(pv & mask) - __popc(mv & mask);
                     char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
-                    if (job.out_elem64) *(uint64_t *)dst = d;
-                    else *(uint32_t *)dst = d;
+                    store_out(dst, job.out_elem64 != 0, (int64_t)d);
                 }
             }
             lds_program_order();   // every lane has read table q

@@ -540,7 +540,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
 #pragma unroll
             for (int k = 0; k < kShortPer; ++k) {
                 const uint32_t q = (uint32_t)k * kShortThreads + threadIdx.x;
-                if (q < len) dst[q] = lds.staged[q];
+                if (q < len) store_out((char *)(dst + q), false, (int64_t)lds.staged[q]);
             }
         } else {
             char *chunk_out = job.out + base * job.out_stride;
@@ -550,8 +550,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
                 if (q < len) {
                     char *dst = chunk_out + (uint64_t)q * job.out_stride;
                     const uint32_t v = lds.staged[q];
-                    if (job.out_elem64) *(int64_t *)dst = (int64_t)v;
-                    else *(uint32_t *)dst = v;
+                    store_out(dst, job.out_elem64 != 0, (int64_t)v);
                 }
             }
         }

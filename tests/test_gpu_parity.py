@@ -717,6 +717,58 @@ def test_tape_widths_residency_and_strides(sw, orc, scope):
     N.lib.swh_unified_free(scope.handle, pointer)
 
 
+def test_results_are_out_when_a_synchronous_call_returns(sw, orc):
+    """A synchronous call with its results in device memory returns when the kernel's summary has landed in host-mapped memory,
+    not when the stream reports the kernel complete (api.hip: wait_for_summary); the results are written through and acknowledged
+    before that word goes out (common.hpp: store_out, report_call_summary). So they must be readable by ANYBODY on return: here by
+    a copy on another stream (torch's; the scope's own stream is non-blocking, nothing orders the two), call after call with
+    fresh inputs and a poisoned output -- words (k_direct_short / k_short_tiled), tokens (the tiled kernel), a cross-product of
+    words, alignment scores of words."""
+    import torch
+    rng = np.random.default_rng(77)
+    scope = sw.DeviceScope(gpu_device=0)
+    lev = sw.LevenshteinDistances(capabilities=scope)
+    byte_to_class, class_costs = sw.unary_class_costs(2, -1)
+    matrix = class_costs[byte_to_class][:, byte_to_class].astype(np.int8)
+    nw = sw.NeedlemanWunschScores(byte_to_class, class_costs, open=-2, extend=-2, capabilities=scope)
+    copier = torch.cuda.Stream()
+
+    def strs(count, lo, hi):
+        lens = rng.integers(lo, hi + 1, count)
+        offsets = np.zeros(count + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:])
+        return sw.Strs(data=rng.integers(97, 101, int(offsets[-1]), dtype=np.uint8), offsets=offsets)
+
+    for round_no in range(30):
+        count = int(rng.integers(300, 70000)) if round_no % 3 else int(rng.integers(300, 3000))
+        lo, hi = ((1, 16) if round_no % 2 else (20, 90)) if round_no % 3 else (1, 12)
+        a, b = strs(count, lo, hi), strs(count, lo, hi)
+        da, db = a.to_device(scope), b.to_device(scope)
+        if round_no % 3:
+            out = torch.full((count,), -7, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            (nw if round_no % 6 == 1 and hi <= 16 else lev).pairs(da, db, scope, out=out)
+            with torch.cuda.stream(copier):
+                got = out.to("cpu", non_blocking=False).numpy()
+            if round_no % 6 == 1 and hi <= 16:
+                want = orc.nw_pairs(a, b, matrix, -2, -2)
+            else:
+                want = orc.levenshtein_pairs(a, b, algo="hyyro")
+            assert (got == want).all(), (round_no, count, np.nonzero(got != want)[0][:5])
+        else:
+            side = int(count ** 0.5)
+            q, c = a.subview(0, side).to_device(scope), b.subview(0, side).to_device(scope)
+            out = torch.full((side, side), -7, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            lev(q, c, scope, out=out)
+            with torch.cuda.stream(copier):
+                got = out.to("cpu", non_blocking=False).numpy()
+            want = np.array([[orc.levenshtein(a[i], b[j]) for j in range(side)] for i in range(side)])
+            assert (got == want).all(), (round_no, side)
+            q.free(); c.free()
+        da.free(); db.free()
+
+
 def test_pipelined_scope_lanes(sw, orc):
     """Pipelined mode alternates calls between two internal lanes; results must be complete after synchronize()
     (or, on the scope's own stream, after join()) and identical to the synchronous path."""

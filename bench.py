@@ -941,7 +941,10 @@ def main():
             "value_steady": steady["value"] if steady else None, "value_pipelined": head["pipelined_rate"],
             "config": {"workload": cfg["text"].format(pairs=head["total_pairs"] if strong else pairs) + ", tapes prepared and resident in HBM",
                        "value_is": "rate of the K timed steps; a step is one synchronous call (results visible on return; the reference's "
-                                   "compute_into metric, utils.rs:721-799)" + (" followed by the gather of the distances to rank 0, which overlaps the next step's call" if world > 1 else ""),
+                                   "compute_into metric, utils.rs:721-799); a call returns when every result has been written through and "
+                                   "acknowledged (the kernel's summary in host-mapped memory), "
+                                   + ("as built" if os.environ.get("STRINGWARS_AMD_EARLY_RETURN", "1") != "0" else "switched off: it waits for the stream")
+                                   + " (DESIGN.md 3)" + (" followed by the gather of the distances to rank 0, which overlaps the next step's call" if world > 1 else ""),
                        "value_steady_is": f"the same steps over >= {args.steady_seconds} s: {steady}" if steady else None,
                        "value_pipelined_is": "K steps enqueued asynchronously on two internal lanes" + (f", {round(head['pipelined_ms'], 4)} ms per step" if head["pipelined_ms"] else ""),
                        "pairs_per_gpu": pairs, "pairs_total": head["total_pairs"], "cells_per_gpu": cells, "algorithm": args.algorithm,

@@ -110,12 +110,12 @@ struct BpWave {
 // memory wait next to every prefetch.
 // Lane `lane` serves block `lane % G` of the pair in slot `lane / G`; `have` says whether that slot holds a pair
 // (p, a0, la, b0, lb). G may exceed the blocks a pair needs (lanes past the pattern idle).
-// `staged` (optional): an LDS array the caller drains later -- the distance of pair p goes to staged[p - staged_base]
+// `staged` (optional): an LDS array of 16-bit slots the caller drains later -- the distance of pair p goes to staged[p - staged_base]
 // instead of straight to the output (tiled.hip writes a tile's results as one coalesced sweep).
 template <typename Sym, bool kWide>
 __device__ __forceinline__ void bp_item(const KernelArgs &args, BpWave<Sym> &wv, const uint32_t G, const bool have, const uint64_t p,
                                         const uint64_t a0, const uint32_t la, const uint64_t b0, const uint32_t lb,
-                                        uint32_t *staged = nullptr, const uint64_t staged_base = 0) {
+                                        uint16_t *staged = nullptr, const uint64_t staged_base = 0) {
     constexpr bool kBytes = sizeof(Sym) == 1;
     constexpr bool wide_tapes = kWide;
     const int lane = wv.lane;
@@ -286,7 +286,7 @@ __device__ __forceinline__ void bp_item(const KernelArgs &args, BpWave<Sym> &wv,
     if (have && first_blk) {
         uint32_t d = n + acc[lane];
         const uint32_t bounded = clamp_bound(d, args.job.bound);
-        if (staged) staged[p - staged_base] = bounded;
+        if (staged && bounded < 0xFFFFu) staged[p - staged_base] = (uint16_t)bounded;   // (0xFFFF: "no distance here")
         else store_result(args.job, p, (int64_t)bounded);
     }
     // ---- clear my table column ---------------------------------------------------------------

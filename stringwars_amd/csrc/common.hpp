@@ -461,7 +461,7 @@ struct KernelArgs {
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs);
 // tiled.hip: bit-parallel Levenshtein with per-workgroup planning (no pre-pass, no host round trip)
 struct TilePlan { uint32_t tile, tiles, blocks, shift; };
-TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text);
+TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text, uint32_t tile_max);
 void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text);
 // cross.hip: dense queries x candidates for word-sized strings, the query's match table shared by a wave
 void launch_cross_short(Scope *scope, const Job &job, uint32_t off64);

@@ -24,7 +24,11 @@
 
 namespace swh {
 
-constexpr int kTileMax = 1024;     // pairs per tile: 10 bits of an index-list entry (then 5 + 5 bits: common prefix / suffix)
+// Pairs per tile: 2048, and 4096 for the sixteen-wave workgroup that has a compute unit to itself (kIndexBits of an index-list
+// entry, then 6 + 6 bits: common prefix / suffix). ONE tile per workgroup is what the sizes are for: a second round of tiles cost
+// C2 12 % (tiles of 652 pairs in three rounds against 977 in two: 25.2 against 28.7 TCUPS), one round of 1954 gave 29.6.
+constexpr int tile_index_bits(int waves) { return waves >= 16 ? 12 : 11; }
+constexpr int tile_max(int waves) { return 1 << tile_index_bits(waves); }
 constexpr uint32_t kAffixCap = 16; // symbols cut off at either end: what one 16-byte window shows
 constexpr int kTileBuckets = 32;   // text-length buckets per class
 constexpr int kTileClasses = 64;
@@ -35,10 +39,13 @@ constexpr int kTileBins = kTileClasses * kTileBuckets;
 // half rate on its own (C2: the four workgroups of a CU finish at 105 / 150 / 190 / 235 us of a 260 us profiled launch,
 // tools/tile_spans.py). Eight-wave workgroups (two per CU, two tiles each) leave two waves per SIMD in that tail: -6 % for
 // a launch on its own (C2 synchronous: 22.95 -> 24.1-24.6 TCUPS); overlapping launches of two pipeline lanes, where the
-// other launch fills the tail anyway, measure the same with either (27.7-28.2 TCUPS).
+// other launch fills the tail anyway, measure the same with either (27.7-28.2 TCUPS). Round 4 took the step after that: ONE
+// sixteen-wave workgroup per compute unit with one tile of up to 4096 pairs (160 KB of LDS: sixteen 8.25 KB tables, the tile's
+// 16 KB index list, 8 KB of counters / staged distances) -- sixteen waves on one ticket finish together: 29.6 -> 31.1 TCUPS.
+template <int kTileMax>
 struct TileLds {
-    uint32_t sorted[kTileMax];            // tile-local pair indices (| prefix << 10 | suffix << 16), sorted by (class, text-length bucket)
-    uint32_t bins[kTileBins / 2];         // two u16 counters per word: counts, then exclusive prefixes
+    uint32_t sorted[kTileMax];            // tile-local pair indices (| prefix << kIndexBits | suffix << (kIndexBits + 6)), sorted by (class, text-length bucket)
+    uint32_t bins[kTileBins / 2 > kTileMax / 2 ? kTileBins / 2 : kTileMax / 2];   // two u16 counters per word: counts, then exclusive prefixes; later a tile's distances, 16 bits each
     uint32_t class_count[kTileClasses];   // pairs per natural class; after step C: per final class
     uint16_t class_thr[kTileClasses];     // ranks >= thr move up to class_tgt
     uint16_t class_tgt[kTileClasses];
@@ -54,7 +61,7 @@ struct TileTail {   // after the last tile the counters' space serves the call s
 static_assert(sizeof(TileTail) <= sizeof(uint32_t) * kTileBins / 2, "the tail reuses TileLds::bins");
 
 template <typename Sym, int kWaves> constexpr size_t tiled_lds_bytes() {
-    return (size_t)kWaves * (bp_table_words<Sym>() + 64) * 4 + sizeof(TileLds);
+    return (size_t)kWaves * (bp_table_words<Sym>() + 64) * 4 + sizeof(TileLds<tile_max(kWaves)>);
 }
 
 #ifdef SWH_TILE_PROFILE
@@ -92,13 +99,14 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
     constexpr int kThreads = kWaves * 64, kTableWords = bp_table_words<Sym>();
     // pairs per thread and tile, rounded UP: ten-wave workgroups (code points) have 640 threads, and 1024 / 640 = 1 left the
     // pairs 640 .. 1023 of a full tile unclassified (every use below is guarded by idx < count)
+    constexpr int kTileMax = tile_max(kWaves), kTileIndexBits = tile_index_bits(kWaves);
     constexpr int kPer = (kTileMax + kThreads - 1) / kThreads;
     const KernelArgs &args = targs.k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     BpWave<Sym> wv;
     wv.init((uint32_t *)smem + (size_t)wave * kTableWords, (uint32_t *)smem + (size_t)kWaves * kTableWords + wave * 64, lane,
             a_total, b_total);
-    TileLds &tl = *(TileLds *)(smem + (size_t)kWaves * (kTableWords + 64) * 4);
+    TileLds<kTileMax> &tl = *(TileLds<kTileMax> *)(smem + (size_t)kWaves * (kTableWords + 64) * 4);
     unsigned long long cells = 0, syms = 0;
     uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
 #ifdef SWH_TILE_PROFILE
@@ -121,53 +129,60 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         // pair. What a pair shares at both ends is cut off before it is classified (the first thing rapidfuzz's Levenshtein
         // does, too): up to kAffixCap symbols each, kept in the upper bits of the pair's entry in the tile's index list.
         uint32_t cls[kPer], txt[kPer], rank[kPer], affix[kPer];
-        uint64_t a0s[kPer], b0s[kPer];
-        uint32_t las[kPer], lbs[kPer];
+        // (two pairs per thread at a time: a pair's four 16-byte windows are 16 registers while they are in flight)
+        constexpr int kBatch = kPer < 2 ? kPer : 2;
+        static_assert(kPer % kBatch == 0, "pairs per thread come in whole batches");
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
+        for (int kb = 0; kb < kPer; kb += kBatch) {
+        uint64_t a0s[kBatch], b0s[kBatch];
+        uint32_t las[kBatch], lbs[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int k = kb + j;
             const uint64_t p = base + (uint32_t)k * kThreads + threadIdx.x;
             const uint64_t pc = p < args.job.pairs ? p : args.job.pairs - 1;
-            if (args.off64) pair_extent<uint64_t>(args.job, pc, a0s[k], las[k], b0s[k], lbs[k]);
-            else pair_extent<uint32_t>(args.job, pc, a0s[k], las[k], b0s[k], lbs[k]);
+            if (args.off64) pair_extent<uint64_t>(args.job, pc, a0s[j], las[j], b0s[j], lbs[j]);
+            else pair_extent<uint32_t>(args.job, pc, a0s[j], las[j], b0s[j], lbs[j]);
             affix[k] = 0;
         }
         if constexpr (sizeof(Sym) == 1 && kWide) {
             if (targs.cut_affixes) {
-                uint4 ha[kPer], hb[kPer], ta[kPer], tb[kPer];
-                bool inside[kPer];
+                uint4 ha[kBatch], hb[kBatch], ta[kBatch], tb[kBatch];
+                bool inside[kBatch];
 #pragma unroll
-                for (int k = 0; k < kPer; ++k) {
+                for (int j = 0; j < kBatch; ++j) {
                     // windows that would leave the tapes (the first / last strings) are read at the tapes' start and not used
-                    const uint64_t ea = a0s[k] + las[k], eb = b0s[k] + lbs[k];
-                    inside[k] = a0s[k] + 16 <= a_total && b0s[k] + 16 <= b_total && ea >= 16 && eb >= 16;
+                    const uint64_t ea = a0s[j] + las[j], eb = b0s[j] + lbs[j];
+                    inside[j] = a0s[j] + 16 <= a_total && b0s[j] + 16 <= b_total && ea >= 16 && eb >= 16;
                     const uint8_t *ad = (const uint8_t *)args.job.a.data, *bd = (const uint8_t *)args.job.b.data;
-                    __builtin_memcpy(&ha[k], ad + (inside[k] ? a0s[k] : 0), 16);
-                    __builtin_memcpy(&hb[k], bd + (inside[k] ? b0s[k] : 0), 16);
-                    __builtin_memcpy(&ta[k], ad + (inside[k] ? ea - 16 : 0), 16);
-                    __builtin_memcpy(&tb[k], bd + (inside[k] ? eb - 16 : 0), 16);
+                    __builtin_memcpy(&ha[j], ad + (inside[j] ? a0s[j] : 0), 16);
+                    __builtin_memcpy(&hb[j], bd + (inside[j] ? b0s[j] : 0), 16);
+                    __builtin_memcpy(&ta[j], ad + (inside[j] ? ea - 16 : 0), 16);
+                    __builtin_memcpy(&tb[j], bd + (inside[j] ? eb - 16 : 0), 16);
                 }
 #pragma unroll
-                for (int k = 0; k < kPer; ++k) {
-                    const uint32_t mn = las[k] < lbs[k] ? las[k] : lbs[k];
-                    const unsigned long long h_lo = (unsigned long long)(ha[k].x ^ hb[k].x) | ((unsigned long long)(ha[k].y ^ hb[k].y) << 32);
-                    const unsigned long long h_hi = (unsigned long long)(ha[k].z ^ hb[k].z) | ((unsigned long long)(ha[k].w ^ hb[k].w) << 32);
-                    const unsigned long long t_lo = (unsigned long long)(ta[k].x ^ tb[k].x) | ((unsigned long long)(ta[k].y ^ tb[k].y) << 32);
-                    const unsigned long long t_hi = (unsigned long long)(ta[k].z ^ tb[k].z) | ((unsigned long long)(ta[k].w ^ tb[k].w) << 32);
+                for (int j = 0; j < kBatch; ++j) {
+                    const uint32_t mn = las[j] < lbs[j] ? las[j] : lbs[j];
+                    const unsigned long long h_lo = (unsigned long long)(ha[j].x ^ hb[j].x) | ((unsigned long long)(ha[j].y ^ hb[j].y) << 32);
+                    const unsigned long long h_hi = (unsigned long long)(ha[j].z ^ hb[j].z) | ((unsigned long long)(ha[j].w ^ hb[j].w) << 32);
+                    const unsigned long long t_lo = (unsigned long long)(ta[j].x ^ tb[j].x) | ((unsigned long long)(ta[j].y ^ tb[j].y) << 32);
+                    const unsigned long long t_hi = (unsigned long long)(ta[j].z ^ tb[j].z) | ((unsigned long long)(ta[j].w ^ tb[j].w) << 32);
                     uint32_t pre = h_lo ? (uint32_t)__builtin_ctzll(h_lo) >> 3 : (h_hi ? 8u + ((uint32_t)__builtin_ctzll(h_hi) >> 3) : kAffixCap);
                     pre = pre < mn ? pre : mn;
                     uint32_t suf = t_hi ? (uint32_t)__builtin_clzll(t_hi) >> 3 : (t_lo ? 8u + ((uint32_t)__builtin_clzll(t_lo) >> 3) : kAffixCap);
                     suf = suf < mn - pre ? suf : mn - pre;
-                    affix[k] = inside[k] ? pre | (suf << 6) : 0u;
+                    affix[kb + j] = inside[j] ? pre | (suf << 6) : 0u;
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
+        for (int j = 0; j < kBatch; ++j) {
+            const int k = kb + j;
             const uint32_t idx = (uint32_t)k * kThreads + threadIdx.x;
             cls[k] = 0xFFu; txt[k] = 0; rank[k] = 0;
             if (idx < count) {
                 const uint64_t p = base + idx;
-                uint32_t la = las[k], lb = lbs[k];
+                uint32_t la = las[j], lb = lbs[j];
                 cells += (unsigned long long)la * lb;
                 syms += (unsigned long long)la + lb;
                 maxa = la > maxa ? la : maxa;
@@ -193,6 +208,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                     }
                 }
             }
+        }
         }
         __syncthreads();
         // ---- C: left-overs move up; work items per class (wave 0) -------------------------------------------------
@@ -280,7 +296,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
             if (key[k] != 0xFFFFFFFFu) {
                 const uint32_t word = tl.bins[key[k] >> 1];
                 const uint32_t start = (key[k] & 1u) ? word >> 16 : word & 0xFFFFu;
-                tl.sorted[start + rank[k]] = ((uint32_t)k * kThreads + threadIdx.x) | (affix[k] << 10);   // index | prefix << 10 | suffix << 16
+                tl.sorted[start + rank[k]] = ((uint32_t)k * kThreads + threadIdx.x) | (affix[k] << kTileIndexBits);   // index | prefix << 11 | suffix << 17
             }
         }
         __syncthreads();
@@ -293,8 +309,9 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         // scattered over the tile's window (which reached HBM as one 32-byte sector each: 6x the result bytes).
         if (threadIdx.x < kTileClasses) tl.class_thr[threadIdx.x] = (uint16_t)(tl.bins[(threadIdx.x * kTileBuckets) >> 1] & 0xFFFFu);
         __syncthreads();
-        uint32_t *const staged = tl.bins;
-        for (int i = threadIdx.x; i < kTileBins / 2; i += kThreads) staged[i] = 0xFFFFFFFFu;   // "no distance here" (trivial pairs are stored directly)
+        static_assert(sizeof(tl.bins) >= (size_t)kTileMax * 2, "the key counters' space holds a tile's distances as 16-bit slots");
+        uint16_t *const staged = (uint16_t *)tl.bins;
+        for (int i = threadIdx.x; i < kTileMax / 2; i += kThreads) tl.bins[i] = 0xFFFFFFFFu;   // "no distance here" (trivial pairs are stored directly)
         __syncthreads();
         // ---- G: work items, heaviest first (high class, long text), dealt by an LDS ticket --------------------------------
         __builtin_amdgcn_s_setprio(0);
@@ -318,10 +335,10 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
                 uint32_t la = 0, lb = 0;
                 if (have) {
                     const uint32_t entry = tl.sorted[cstart + pidx];
-                    p = base + (entry & 1023u);
+                    p = base + (entry & (uint32_t)(kTileMax - 1));
                     if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
                     else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
-                    const uint32_t pre = (entry >> 10) & 63u, both = pre + (entry >> 16);   // what the pair shares at both ends (step B)
+                    const uint32_t pre = (entry >> kTileIndexBits) & 63u, both = pre + (entry >> (kTileIndexBits + 6));   // what the pair shares at both ends (step B)
                     a0 += pre; b0 += pre; la -= both; lb -= both;
                 }
                 bp_item<Sym, kWide>(args, wv, G, have, p, a0, la, b0, lb, staged, base);
@@ -338,7 +355,7 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
 #endif
         for (uint32_t i = threadIdx.x; i < count; i += kThreads) {
             const uint32_t d = staged[i];
-            if (d != 0xFFFFFFFFu) store_result(args.job, base + i, (int64_t)d);
+            if (d != 0xFFFFu) store_result(args.job, base + i, (int64_t)d);
         }
         __syncthreads();   // the next tile rewrites the lists
     }
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void 
 
 // Tile size: every workgroup slot should get the same number of tiles (1, 2, ...), tiles stay <= kTileMax pairs, and a
 // batch too small to give every slot a useful tile uses fewer workgroups instead of smaller tiles.
-TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text) {
+TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text, uint32_t kTileMax) {
     TilePlan tp{};
     constexpr uint32_t kTileMin = 256;
     const uint64_t rounds = (pairs + (uint64_t)slots * kTileMax - 1) / ((uint64_t)slots * kTileMax);
@@ -420,7 +437,7 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
     constexpr size_t lds = tiled_lds_bytes<Sym, kWaves>();
     uint32_t slots = (uint32_t)scope->compute_units * (uint32_t)((160 * 1024) / lds);
     if (slots > (uint32_t)kMaxPartials) slots = kMaxPartials;
-    const TilePlan tp = plan_tiles(pairs, slots, longest_text);
+    const TilePlan tp = plan_tiles(pairs, slots, longest_text, (uint32_t)tile_max(kWaves));
     TiledArgs t{};
     t.k = args;
     t.k.boundary = nullptr;
@@ -453,6 +470,13 @@ void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pai
         else launch_tiled_sym<uint32_t, 10>(scope, args, pairs, longest_text);
     }
     else if (forced == 4) launch_tiled_sym<uint8_t, 4>(scope, args, pairs, longest_text);
+    else if (forced == 8) launch_tiled_sym<uint8_t, 8>(scope, args, pairs, longest_text);
+    // a batch that fills the device: ONE sixteen-wave workgroup per compute unit, one tile of up to 4096 pairs each. Two eight-wave
+    // workgroups share a CU unevenly -- the arbiter favours the older one, it finishes at ~half time and the younger runs the rest
+    // of its tile at two waves per SIMD (tools/tile_spans.py) --; sixteen waves on one ticket finish together.
+    // (Not in asynchronous scopes: two pipelined launches share the device best as eight-wave workgroups side by side on a CU -- 32.8
+    // TCUPS over pipelined steps against 31.2 -- where a 160 KB workgroup keeps the other launch off its CU.)
+    else if (forced == 16 || (!forced && !scope->async && pairs >= (uint64_t)scope->compute_units * 2048)) launch_tiled_sym<uint8_t, 16>(scope, args, pairs, longest_text);
     else launch_tiled_sym<uint8_t, 8>(scope, args, pairs, longest_text);
 }
 

@@ -108,6 +108,17 @@ __device__ __forceinline__ void short_lds_order() {
     asm volatile("" ::: "memory");
 }
 
+#ifdef SWH_SHORT_WG_SPANS
+// Diagnostic build only (make EXTRA=-DSWH_SHORT_WG_SPANS): when every workgroup of k_short_tiled starts and ends (100 MHz clock)
+__device__ unsigned long long g_short_wg[4096][2];
+extern "C" void swh_debug_short_wg(unsigned long long *out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_short_wg), sizeof(unsigned long long) * 4096 * 2);
+}
+#define SHORT_WG_STAMP(which) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_short_wg[blockIdx.x][which] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SHORT_WG_STAMP(which) do { } while (0)
+#endif
 #ifdef SWH_SHORT_PROFILE
 // Diagnostic build only (make EXTRA=-DSWH_SHORT_PROFILE): wave cycles per phase of k_short_tiled, summed over waves.
 __device__ unsigned long long g_short_phase[10];
@@ -179,6 +190,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
     }
     if (threadIdx.x == 0) lds.mixed = 0;
     __syncthreads();
+    SHORT_WG_STAMP(0);
     uint32_t cells = 0, syms = 0, maxa = 0, maxb = 0, misfit = 0;
     const uint32_t bound = job.bound;
 #ifdef SWH_SHORT_PROFILE
@@ -569,6 +581,7 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         atomicAdd(&g_short_phase[8], items_done);
     }
 #endif
+    SHORT_WG_STAMP(1);
     // ---- the workgroup's work units -> the call summary (common.hpp) -------------------------------------------------------------
     if (threadIdx.x == 0) { lds.tail.cells = 0; lds.tail.syms = 0; lds.tail.maxa = 0; lds.tail.maxb = 0; lds.tail.misfit = 0; }
     __syncthreads();

@@ -130,7 +130,10 @@ __device__ __forceinline__ void tiled_run(const TiledArgs &targs, char *smem, co
         // does, too): up to kAffixCap symbols each, kept in the upper bits of the pair's entry in the tile's index list.
         uint32_t cls[kPer], txt[kPer], rank[kPer], affix[kPer];
         // (two pairs per thread at a time: a pair's four 16-byte windows are 16 registers while they are in flight)
-        constexpr int kBatch = kPer < 2 ? kPer : 2;
+#ifndef SWH_TILE_BATCH
+#define SWH_TILE_BATCH 2
+#endif
+        constexpr int kBatch = kPer < SWH_TILE_BATCH ? kPer : SWH_TILE_BATCH;
         static_assert(kPer % kBatch == 0, "pairs per thread come in whole batches");
 #pragma unroll
         for (int kb = 0; kb < kPer; kb += kBatch) {

@@ -1490,6 +1490,36 @@ def test_utf8_three_kernel_scan_path(orc, mode):
     assert done.returncode == 0 and "split-scan ok" in done.stdout, done.stderr[-2000:]
 
 
+@pytest.mark.parametrize("waves", ["4", "8", "16"])
+def test_tiled_kernel_workgroup_shapes(orc, waves):
+    """k_bitparallel_tiled runs byte strings as sixteen-wave workgroups with tiles of up to 4096 pairs when a batch fills the device, as
+    eight-wave workgroups with tiles of up to 2048 otherwise (STRINGWARS_AMD_TILED_WAVES forces one: read once per process, hence the
+    subprocess). Every shape on the same batches: tokens with shared affixes in full tiles (9000 pairs: tiles of ~4096 / 2048 and a
+    short last one), strings over every block count up to 64 blocks, empty strings, a bound."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, stringwars_amd as sw, oracle\n"
+        "scope = sw.DeviceScope(gpu_device=0)\n"
+        "engine = sw.LevenshteinDistances(capabilities=scope, algorithm='tiled')\n"
+        "a, b = sw.generate_pairs('tokens64', 9000, seed=11)\n"
+        "assert (engine.pairs(a, b, scope) == oracle.levenshtein_pairs(a, b, algo='hyyro')).all()\n"
+        "assert (engine.pairs(a, b, scope, bound=5) == oracle.levenshtein_pairs(a, b, algo='hyyro', bound=5)).all()\n"
+        "rng = np.random.default_rng(3)\n"
+        "xs = [bytes(rng.integers(97, 101, int(n), dtype=np.uint8)) for n in list(range(0, 2049, 37)) * 3]\n"
+        "ys = [bytes(rng.integers(97, 101, int(n), dtype=np.uint8)) for n in rng.integers(0, 2049, len(xs))]\n"
+        "sa, sb = sw.Strs(xs), sw.Strs(ys)\n"
+        "scope.set_profiling(True)\n"
+        "got = engine.pairs(sa, sb, scope)\n"
+        "name = scope.last_timing()['dominant_name']\n"
+        "assert name == 'bitparallel_tiled', name\n"
+        "assert (got == oracle.levenshtein_pairs(sa, sb, algo='hyyro')).all()\n"
+        "print('tiled shapes ok')\n")
+    env = dict(os.environ, STRINGWARS_AMD_TILED_WAVES=waves, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0 and "tiled shapes ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
+
+
 def test_edge_cases_and_errors(sw, orc, scope):
     engine = sw.LevenshteinDistances(capabilities=scope)
     assert engine.pairs([], [], scope).size == 0

@@ -782,6 +782,10 @@ __global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignS
     const uint64_t chunks = (nb + 63) / 64, qblocks = (na + queries_per_item - 1) / queries_per_item;
     const uint64_t items = chunks * qblocks;
     for (uint64_t item = wave_id; item < items; item += waves_total) {
+        // (a wave that is ahead steps back -- common.hpp: fair_priority --: ACGT-1 K NW linear 12.8 -> 13.5 TCUPS, affine 6.08 -> 6.47, SW
+        // 6.93 -> 7.31, ACGT-100 affine 5.25 -> 5.66. The same two lines cost the one-pass kernels: k_align_cross_wide 10.4 -> 6.4 on
+        // ACGT-100 NW linear, k_cross_short 2.39 -> 1.81 on words -- their items are too short for a priority to mean anything.)
+        fair_priority((item - wave_id) / waves_total, (items - wave_id + waves_total - 1) / waves_total);
         const uint64_t chunk = item / qblocks, qb = item - chunk * qblocks;
         const uint64_t q_first = qb * queries_per_item, q_last = q_first + queries_per_item < na ? q_first + queries_per_item : na;
         const uint32_t q_count = (uint32_t)(q_last - q_first);

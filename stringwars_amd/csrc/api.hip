@@ -368,9 +368,30 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         const bool dev_out = is_device_pointer(spec.out);
         uint64_t a_bytes = 0, b_bytes = 0;
         const bool need_sizes = !prepared && (!dev_a_data || !dev_b_data || utf8);
+        bool believed_sizes = false;
         if (need_sizes) {
-            a_bytes = read_offset(spec.a.offsets, spec.a.off64, spec.a.count, dev_a_off, stream);
-            b_bytes = same_tape ? a_bytes : read_offset(spec.b.offsets, spec.b.off64, spec.b.count, dev_b_off, stream);
+            // A UTF-8 call on raw device tapes needs the tapes' byte totals before its first launch (scratch, grids): two synchronous
+            // 4-byte copies, ~25 us of a 0.7 ms call. The same tapes as last time (pointers, count) are believed to hold the same
+            // totals if the allocations still cover them; k_utf8_finish compares with offsets[count] and the call is redone if not.
+            static const bool believe = [] { const char *e = getenv("STRINGWARS_AMD_SIZE_BELIEF"); return !e || atoi(e) != 0; }();
+            auto total_of = [&](const HostTape &t, bool dev_data, bool dev_off, Scope::SizeBelief &slot) -> uint64_t {
+                if (believe && utf8 && dev_data && dev_off && !spec.force_planned && slot.valid && slot.data == t.data && slot.offsets == t.offsets &&
+                    slot.count == t.count && slot.off64 == t.off64) {
+                    void *base = nullptr; size_t size = 0;
+                    const size_t ow_t = t.off64 ? 8 : 4;
+                    bool covered = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)t.data) == hipSuccess &&
+                                   (const char *)t.data + slot.bytes <= (const char *)base + size;
+                    covered = covered && hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)t.offsets) == hipSuccess &&
+                              (const char *)t.offsets + (t.count + 1) * ow_t <= (const char *)base + size;
+                    if (covered) { believed_sizes = true; return slot.bytes; }
+                    (void)hipGetLastError();
+                }
+                const uint64_t bytes = read_offset(t.offsets, t.off64, t.count, dev_off, stream);
+                slot.data = t.data; slot.offsets = t.offsets; slot.count = t.count; slot.off64 = t.off64; slot.bytes = bytes; slot.valid = dev_data && dev_off;
+                return bytes;
+            };
+            a_bytes = total_of(spec.a, dev_a_data, dev_a_off, scope->size_belief[0]);
+            b_bytes = same_tape ? a_bytes : total_of(spec.b, dev_b_data, dev_b_off, scope->size_belief[1]);
         }
         // device-resident outputs are written in place with the caller's strides; host outputs are produced
         // compactly in device staging and scattered into the caller's strides by a 2-D copy
@@ -629,6 +650,13 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         };
         auto invalid_utf8 = [&]() -> swh_status_t {
             SWH_HIP_CHECK(hipStreamSynchronize(stream));
+            if (*invalid_host == kUtf8SizesChanged && believed_sizes) {
+                // the tapes changed behind the belief: read their totals afresh and do the call again
+                scope->size_belief[0].valid = scope->size_belief[1].valid = false;
+                scope->summary_pending = false;
+                scope->stamps_pending = false;
+                return run_call_on(scope, engine, spec, error);
+            }
             snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in an input tape (marker %u)", *invalid_host - 1);
             if (error) *error = g_error_text;
             return swh_invalid_utf8_k;

@@ -1394,6 +1394,8 @@ __device__ __forceinline__ void utf8_string_offset(const Utf8Args &args, const u
     const uint8_t *data = (const uint8_t *)args.in.data;
     const int64_t total = (int64_t)args.total_bytes;
     const int64_t off = (int64_t)offs[i];
+    // (the host may have BELIEVED the tape's byte total from its previous call on the same tape: the thread that owns the tape's end checks)
+    if (i == args.in.count && off != total) atomicMax(args.invalid, kUtf8SizesChanged);
     if (off >= total) {  // the tape's end (also every trailing empty string)
         uint64_t tiles = ((uint64_t)total + kUtf8Tile - 1) / kUtf8Tile;
         args.offsets[i] = tile_prefix[tiles];

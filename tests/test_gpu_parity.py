@@ -769,6 +769,36 @@ def test_results_are_out_when_a_synchronous_call_returns(sw, orc):
         da.free(); db.free()
 
 
+def test_believed_tape_sizes_are_checked_on_the_device(sw, orc):
+    """A UTF-8 call on raw device tapes believes the byte totals it read for the same tapes (pointers, count) last time instead of
+    fetching offsets[count] again; k_utf8_finish compares and the call is redone with fresh totals when the tapes were rewritten
+    in place -- shorter, longer, and back -- between calls (api.hip: size_belief; STRINGWARS_AMD_SIZE_BELIEF=0 always fetches)."""
+    import torch
+    rng = np.random.default_rng(91)
+    scope = sw.DeviceScope(gpu_device=0)
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    count = 3000
+
+    def batch(lo, hi):
+        cps = [0x41, 0x62, 0xE9, 0x416, 0x4E2D, 0x1F600]
+        strings = ["".join(chr(cps[int(c)]) for c in rng.integers(0, len(cps), int(n))).encode() for n in rng.integers(lo, hi, count)]
+        return sw.Strs(strings)
+
+    versions = [(batch(20, 60), batch(20, 60)), (batch(5, 25), batch(30, 80)), (batch(40, 90), batch(1, 10)), (batch(20, 60), batch(20, 60))]
+    room = max(max(len(a.data), len(b.data)) for a, b in versions) + 64
+    data_a, data_b = torch.zeros(room, dtype=torch.uint8, device="cuda"), torch.zeros(room, dtype=torch.uint8, device="cuda")
+    offs_a, offs_b = torch.zeros(count + 1, dtype=torch.int64, device="cuda"), torch.zeros(count + 1, dtype=torch.int64, device="cuda")
+    ta, tb = sw.DeviceTape.from_torch(data_a, offs_a), sw.DeviceTape.from_torch(data_b, offs_b)
+    for a, b in versions:
+        data_a[:len(a.data)] = torch.from_numpy(a.data).cuda(); offs_a.copy_(torch.from_numpy(a.offsets.astype(np.int64)))
+        data_b[:len(b.data)] = torch.from_numpy(b.data).cuda(); offs_b.copy_(torch.from_numpy(b.offsets.astype(np.int64)))
+        torch.cuda.synchronize()
+        want = orc.levenshtein_pairs(a, b, utf8=True)
+        for _ in range(3):   # the first call on rewritten tapes meets the stale belief, the next ones the fresh one
+            assert (engine.pairs(ta, tb, scope) == want).all()
+        assert (engine.pairs(ta, tb, scope, bound=7) == np.minimum(want, 8)).all()
+
+
 def test_pipelined_scope_lanes(sw, orc):
     """Pipelined mode alternates calls between two internal lanes; results must be complete after synchronize()
     (or, on the scope's own stream, after join()) and identical to the synchronous path."""

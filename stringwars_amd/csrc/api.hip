@@ -169,7 +169,7 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
 
 // both tapes of a call up to this size (together) are staged by one launch pair; STRINGWARS_AMD_UTF8_MERGED_MB=n moves it
 static uint64_t utf8_merged_bytes() {
-    static const uint64_t bytes = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_MERGED_MB"); return (uint64_t)(e ? atol(e) : 48) << 20; }();
+    static const uint64_t bytes = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_MERGED_MB"); return e ? (uint64_t)atol(e) << 20 : ~0ull; }();
     return bytes;
 }
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
@@ -562,9 +562,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 db = da;
             } else if (utf8_one_pass() && a_bytes + b_bytes <= utf8_merged_bytes()) {
                 // both tapes in the same two launches (tile decode, then string offsets + balance): what a small call costs is
-                // its launches (10 K word pairs: 135 -> 107 us per call). Large tapes keep a launch pair and a stream each
-                // below: 2 x 100 MB are staged in 0.27 ms that way, in 0.33 by one launch over both. In between
-                // (tools/mid_utf8.py): 16 MB of tapes 280 -> 267 us per call merged, 31 MB 323 -> 311, 63 MB the same.
+                // its launches (10 K word pairs: 135 -> 107 us per call). Since the tile kernel draws from one ticket PER TAPE
+                // (round 4) this is the path for every size (tools/mid_utf8.py, us per call, one launch pair : a launch pair and
+                // a stream per tape -- 4 MB of tapes 186 : 205, 16 MB 216 : 240, 31 MB 256 : 283, 63 MB 330 : 352, 200 MB
+                // 684 : 685); with one ticket for both tapes 2 x 100 MB took 0.33 ms in one launch against 0.27 in two.
+                // STRINGWARS_AMD_UTF8_MERGED_MB=n sends tapes beyond n MB to the two-stream path below.
                 auto prepare = [&](const TapeRef &in, uint64_t bytes, Utf8Args &u) {
                     u.slot = decode_slot++;
                     u.in = in; u.off64 = off64; u.total_bytes = bytes;

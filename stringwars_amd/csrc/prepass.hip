@@ -1228,16 +1228,24 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(Utf8TileJob job_a, Utf
     // the kernel needs 92 registers and a workgroup lives four times as long. Taken out again.)
     const uint32_t drawn = blockIdx.x;
 #else
-    if (threadIdx.x == 0) my_tile = atomicAdd(ticket, 1u);
+    // Two tapes in one launch draw from TWO tickets, one per tape (words 32 apart: 128 bytes): a ticket is an atomic on one address,
+    // 3.6 ns each -- 25 K tiles on one word were 90 us of a 0.25 ms kernel, which is what made one launch over both tapes slower
+    // than a launch and a stream each. A workgroup asks its preferred tape first (blockIdx parity) and the other one when that tape
+    // has no tile left; every tile before a drawn one belongs to a workgroup that is running or done, per tape, as before.
+    if (threadIdx.x == 0) {
+        const bool two = job_b.tiles != 0;
+        uint32_t pick = two ? (blockIdx.x & 1u) : 0u;
+        uint32_t t = atomicAdd(ticket + 32 * pick, 1u);
+        if (two && t >= (pick ? job_b.tiles : job_a.tiles)) { pick ^= 1u; t = atomicAdd(ticket + 32 * pick, 1u); }
+        my_tile = t | (pick << 31);
+    }
     __syncthreads();
     const uint32_t drawn = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_tile);
 #endif
     {
-    // tickets alternate between the two tapes while both have tiles left (two windows of the address space in flight, as when
-    // each tape had a launch and a stream of its own), the longer tape's remaining tiles follow
-    const uint64_t paired = 2 * (job_a.tiles < job_b.tiles ? job_a.tiles : job_b.tiles);
-    const bool second = drawn < paired ? (drawn & 1u) != 0 : job_b.tiles > job_a.tiles;
-    const uint64_t tile_in_tape = drawn < paired ? drawn >> 1 : drawn - paired / 2;
+    const bool second = (drawn >> 31) != 0;
+    const uint64_t tile_in_tape = drawn & 0x7FFFFFFFu;
+    if (tile_in_tape >= (second ? job_b.tiles : job_a.tiles)) return;   // (cannot happen: the grid has as many workgroups as the tapes have tiles)
     const uint8_t *data = second ? job_b.data : job_a.data;
     const uint64_t total = second ? job_b.total : job_a.total, tiles = second ? job_b.tiles : job_a.tiles;
     unsigned long long *status = second ? job_b.status : job_a.status;

@@ -239,6 +239,27 @@ static uint64_t read_offset(const void *offs, int off64, size_t i, bool device, 
 
 static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSpec &spec, const char **error);
 
+// Does either tape hold a byte above 0x7F? Runs in front of the byte kernels when a UTF-8 call BELIEVES its raw tapes to be ASCII
+// (they were, the last time this scope staged them): sixteen bytes per thread and step, the flag in host-mapped memory.
+__global__ __launch_bounds__(256) void k_ascii_check(const uint8_t *a, uint64_t a_bytes, const uint8_t *b, uint64_t b_bytes, uint32_t *flag) {
+    uint32_t high = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 16;
+    for (int t = 0; t < 2; ++t) {
+        const uint8_t *data = t ? b : a;
+        const uint64_t bytes = t ? b_bytes : a_bytes;
+        for (uint64_t at = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; at < bytes; at += stride) {
+            if (at + 16 <= bytes) {
+                uint4 v;
+                __builtin_memcpy(&v, data + at, 16);
+                high |= v.x | v.y | v.z | v.w;
+            } else {
+                for (uint64_t i = at; i < bytes; ++i) high |= data[i];
+            }
+        }
+    }
+    if (__ballot((high & 0x80808080u) != 0) != 0 && (threadIdx.x & 63) == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static swh_status_t run_call(Scope *scope, const Engine *engine, const CallSpec &spec, const char **error) {
     if (!scope || !engine) return fail(error, swh_invalid_argument_k, "null scope or engine");
     if (!scope->pipelined) return run_call_on(scope, engine, spec, error);
@@ -366,6 +387,44 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             same_tape = spec.b.data == spec.a.data && spec.b.offsets == spec.a.offsets && spec.b.count == spec.a.count;
         }
         const bool dev_out = is_device_pointer(spec.out);
+        static const bool believe = [] { const char *e = getenv("STRINGWARS_AMD_SIZE_BELIEF"); return !e || atoi(e) != 0; }();
+        auto same_as_believed = [](const HostTape &t, const Scope::SizeBelief &slot) {
+            return slot.valid && slot.data == t.data && slot.offsets == t.offsets && slot.count == t.count && slot.off64 == t.off64;
+        };
+        // -- raw UTF-8 tapes that were pure ASCII the last time this scope staged them: code points of ASCII text are its bytes, so the
+        // call runs on the byte kernels -- no staging, the word-sized and cross-product kernels instead of the code-point ones -- behind
+        // a kernel that checks every byte of both tapes; if one is above 0x7F after all, the call is done again the long way.
+        // (Synchronous scopes only: an asynchronous call cannot be redone behind the caller's back.)
+        if (believe && utf8 && !prepared && !scope->async && !spec.force_planned && dev_a_data && dev_a_off && dev_b_data && dev_b_off &&
+            same_as_believed(spec.a, scope->size_belief[0]) && scope->size_belief[0].ascii &&
+            (same_tape || (same_as_believed(spec.b, scope->size_belief[1]) && scope->size_belief[1].ascii))) {
+            const Scope::SizeBelief &ba = scope->size_belief[0], &bb = same_tape ? scope->size_belief[0] : scope->size_belief[1];
+            void *base = nullptr; size_t size = 0;
+            const bool covered = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)spec.a.data) == hipSuccess &&
+                                 (const char *)spec.a.data + ba.bytes <= (const char *)base + size &&
+                                 hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)spec.b.data) == hipSuccess &&
+                                 (const char *)spec.b.data + bb.bytes <= (const char *)base + size;
+            if (covered) {
+                uint32_t *seen_host = (uint32_t *)((char *)scope->summary_host + 128), *seen_dev = (uint32_t *)((char *)scope->summary_dev + 128);
+                *seen_host = 0;
+                const uint64_t most = std::max<uint64_t>(ba.bytes, bb.bytes);
+                const uint32_t blocks = (uint32_t)std::min<uint64_t>((most + 4095) / 4096 + 1, (uint64_t)scope->compute_units * 8);
+                hipLaunchKernelGGL(k_ascii_check, dim3(blocks), dim3(256), 0, stream, (const uint8_t *)spec.a.data, ba.bytes,
+                                   (const uint8_t *)spec.b.data, same_tape ? 0 : bb.bytes, seen_dev);
+                SWH_HIP_CHECK(hipGetLastError());
+                CallSpec as_bytes = spec;
+                as_bytes.utf8 = false;
+                const swh_status_t status = run_call_on(scope, engine, as_bytes, error);
+                if (status != swh_success_k) return status;
+                // (the check ran in front of the byte kernels on the same stream: it is complete when their results are)
+                if (__atomic_load_n(seen_host, __ATOMIC_ACQUIRE) == 0) return swh_success_k;
+                scope->size_belief[0].ascii = scope->size_belief[1].ascii = false;
+                scope->summary_pending = false;
+                scope->stamps_pending = false;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         uint64_t a_bytes = 0, b_bytes = 0;
         const bool need_sizes = !prepared && (!dev_a_data || !dev_b_data || utf8);
         bool believed_sizes = false;
@@ -373,10 +432,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             // A UTF-8 call on raw device tapes needs the tapes' byte totals before its first launch (scratch, grids): two synchronous
             // 4-byte copies, ~25 us of a 0.7 ms call. The same tapes as last time (pointers, count) are believed to hold the same
             // totals if the allocations still cover them; k_utf8_finish compares with offsets[count] and the call is redone if not.
-            static const bool believe = [] { const char *e = getenv("STRINGWARS_AMD_SIZE_BELIEF"); return !e || atoi(e) != 0; }();
             auto total_of = [&](const HostTape &t, bool dev_data, bool dev_off, Scope::SizeBelief &slot) -> uint64_t {
-                if (believe && utf8 && dev_data && dev_off && !spec.force_planned && slot.valid && slot.data == t.data && slot.offsets == t.offsets &&
-                    slot.count == t.count && slot.off64 == t.off64) {
+                if (believe && utf8 && dev_data && dev_off && !spec.force_planned && same_as_believed(t, slot)) {
                     void *base = nullptr; size_t size = 0;
                     const size_t ow_t = t.off64 ? 8 : 4;
                     bool covered = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)t.data) == hipSuccess &&
@@ -388,6 +445,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 }
                 const uint64_t bytes = read_offset(t.offsets, t.off64, t.count, dev_off, stream);
                 slot.data = t.data; slot.offsets = t.offsets; slot.count = t.count; slot.off64 = t.off64; slot.bytes = bytes; slot.valid = dev_data && dev_off;
+                slot.ascii = false;
                 return bytes;
             };
             a_bytes = total_of(spec.a, dev_a_data, dev_a_off, scope->size_belief[0]);
@@ -650,6 +708,12 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                                                hipMemcpyDeviceToHost, stream));
             }
         };
+        // what the staging saw of the tapes' bytes (one-pass kernel only): the next call on the same tapes may believe it
+        auto learn_ascii = [&]() {
+            if (!invalid_dev || !utf8_one_pass()) return;
+            if (same_as_believed(spec.a, scope->size_belief[0])) scope->size_belief[0].ascii = invalid_host[kUtf8AsciiWord] == 0;
+            if (!same_tape && same_as_believed(spec.b, scope->size_belief[1])) scope->size_belief[1].ascii = invalid_host[kUtf8AsciiWord + 1] == 0;
+        };
         auto invalid_utf8 = [&]() -> swh_status_t {
             SWH_HIP_CHECK(hipStreamSynchronize(stream));
             if (*invalid_host == kUtf8SizesChanged && believed_sizes) {
@@ -693,7 +757,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 launch_align_long(scope, k, longest);
             }
             else launch_bitparallel_tiled(scope, k, pairs, longest);
-            if (invalid_dev) SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, stream));
+            if (invalid_dev) SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4 * (kUtf8AsciiWord + 2), hipMemcpyDeviceToHost, stream));
             copy_results_back();
             scope->summary_sym_bytes = need_sizes ? 0 : sym_bytes;
             scope->summary_pairs = pairs; scope->summary_ow = ow; scope->summary_elem = elem;
@@ -704,6 +768,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 if (early) wait_for_summary(scope, stream);
                 else SWH_HIP_CHECK(hipStreamSynchronize(stream));
                 if (*invalid_host) return invalid_utf8();
+                learn_ascii();
                 if (scope->summary_host[0].violation) {
                     // the belief about the lengths was wrong (it came from an earlier batch): redo on the planned path
                     scope->hint_lengths = false;
@@ -734,7 +799,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         SWH_HIP_CHECK(hipStreamWaitEvent(scope->side_stream, scope->plan_ready, 0));
         SWH_HIP_CHECK(hipMemcpyAsync(&plan, plan_dev, sizeof(Plan), hipMemcpyDeviceToHost, scope->side_stream));
         if (invalid_dev)
-            SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4, hipMemcpyDeviceToHost, scope->side_stream));
+            SWH_HIP_CHECK(hipMemcpyAsync(invalid_host, invalid_dev, 4 * (kUtf8AsciiWord + 2), hipMemcpyDeviceToHost, scope->side_stream));
         SWH_HIP_CHECK(hipStreamSynchronize(scope->side_stream));
         if (plan.fused_failed) {
             // the one-launch planner could not gather its grid (a device shared with long-running foreign kernels): the DP
@@ -749,6 +814,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         scope->hint_lengths = true;
         scope->hint_max_la = plan.max_la; scope->hint_max_lb = plan.max_lb;
         if (*invalid_host) return invalid_utf8();
+        learn_ascii();
 
         if (bitpar_deferred) {
             bool any_bp = false;

@@ -376,7 +376,9 @@ struct Scope {
     // What the last call READ as the byte totals of two raw device tapes (offsets[count]): a UTF-8 call on the same tapes believes
     // them instead of fetching them again -- two synchronous round trips before its first launch -- and k_utf8_finish checks
     // the belief on the device (marker kUtf8SizesChanged; the host then reads them afresh and redoes the call).
-    struct SizeBelief { const void *data = nullptr, *offsets = nullptr; size_t count = 0; int off64 = 0; uint64_t bytes = 0; bool valid = false; } size_belief[2];
+    // `ascii`: the last staging of that tape met no byte above 0x7F (the one-pass kernel's flag words, kUtf8AsciiWord): the next UTF-8 call on
+    // the same tapes runs on their BYTES (code points of ASCII text are its bytes) next to a kernel that checks exactly that (api.hip).
+    struct SizeBelief { const void *data = nullptr, *offsets = nullptr; size_t count = 0; int off64 = 0; uint64_t bytes = 0; bool valid = false, ascii = false; } size_belief[2];
     bool align_wide_off = false;   // k_align_cross_wide met candidates with more than eight symbol classes (or longer strings): not tried again
     uint32_t hint_max_la = 0, hint_max_lb = 0;
     uint32_t hint_mean_x16 = 0;   // mean string length of the previous call, x16 (both tapes together)
@@ -515,6 +517,7 @@ void launch_align_long(Scope *scope, const KernelArgs &args, uint32_t longest_ro
 constexpr int kUtf8Pass = 1024, kUtf8Passes = 8;     // a block walks its tile in passes of 256 threads x one dword
 constexpr int kUtf8Tile = kUtf8Pass * kUtf8Passes;   // bytes per block
 constexpr int kUtf8Subs = kUtf8Tile / 256;           // 256-byte sub-tiles per tile
+constexpr int kUtf8AsciiWord = 3;   // flag words [3], [4]: the tape staged by slot 0 / 1 (or the first / second tape of one launch) held a byte above 0x7F
 constexpr uint32_t kUtf8SizesChanged = 0xFFFFFFFEu;   // `invalid` marker: a tape's offsets[count] is not the byte total the call believed
 constexpr int kUtf8FlagWords = 96;   // the tickets of two concurrent launches sit 128 bytes apart and away from the flag: on one
                                      // cache line their atomics took turns (2 x 100 MB staged in 0.32 ms instead of 0.28)

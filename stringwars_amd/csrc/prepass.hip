@@ -1281,6 +1281,15 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(Utf8TileJob job_a, Utf
         }
         if (threadIdx.x == 0) after = load_tape_dword(data, (int64_t)((tile + 1) * kUtf8Tile), tot);
     }
+    {   // a byte above 0x7F anywhere in the tile: the tape is not pure ASCII (a plain store, every such wave writes the same 1)
+        uint32_t high = 0;
+#pragma unroll
+        for (int q = 0; q < kUtf8Passes; ++q) high |= curs[q];
+        if (__ballot((high & 0x80808080u) != 0) != 0 && lane == 0) {
+            const uint32_t tape_no = (uint32_t)((ticket - invalid) / 32 - 1) + (second ? 1u : 0u);   // the launch's slot, + 1 for its second tape
+            invalid[kUtf8AsciiWord + (tape_no & 1u)] = 1u;
+        }
+    }
     uint32_t incls[kUtf8Passes];
 #pragma unroll
     for (int q = 0; q < kUtf8Passes; ++q) {

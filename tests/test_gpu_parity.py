@@ -799,6 +799,53 @@ def test_believed_tape_sizes_are_checked_on_the_device(sw, orc):
         assert (engine.pairs(ta, tb, scope, bound=7) == np.minimum(want, 8)).all()
 
 
+def test_ascii_tapes_through_the_utf8_engine_run_on_their_bytes(sw, orc):
+    """Raw UTF-8 device tapes that held only ASCII the last time a scope staged them are scored on their bytes the next time (code
+    points of ASCII text are its bytes: the word-sized and cross-product byte kernels instead of staging + code-point kernels), behind
+    a kernel that checks every byte; a tape rewritten in place with text beyond ASCII is caught by that check and the call is done
+    again the long way (api.hip: k_ascii_check). Pairs and cross-products, words and longer strings."""
+    import torch
+    rng = np.random.default_rng(123)
+    scope = sw.DeviceScope(gpu_device=0)
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    count = 2000
+
+    def batch(lo, hi, cps):
+        strings = ["".join(chr(cps[int(c)]) for c in rng.integers(0, len(cps), int(n))).encode() for n in rng.integers(lo, hi, count)]
+        return sw.Strs(strings)
+
+    ascii_cps, mixed_cps = list(range(97, 123)), [0x41, 0x62, 0xE9, 0x416, 0x4E2D, 0x1F600]
+    for lo, hi in ((1, 12), (30, 90)):
+        versions = [(batch(lo, hi, ascii_cps), batch(lo, hi, ascii_cps)), (batch(lo, hi, ascii_cps), batch(lo, hi, mixed_cps)),
+                    (batch(lo, hi, ascii_cps), batch(lo, hi, ascii_cps))]
+        room = max(max(len(a.data), len(b.data)) for a, b in versions) + 64
+        data_a, data_b = torch.zeros(room, dtype=torch.uint8, device="cuda"), torch.zeros(room, dtype=torch.uint8, device="cuda")
+        offs_a, offs_b = torch.zeros(count + 1, dtype=torch.int64, device="cuda"), torch.zeros(count + 1, dtype=torch.int64, device="cuda")
+        ta, tb = sw.DeviceTape.from_torch(data_a, offs_a), sw.DeviceTape.from_torch(data_b, offs_b)
+        names = []
+        for a, b in versions:
+            data_a[:len(a.data)] = torch.from_numpy(a.data).cuda(); offs_a.copy_(torch.from_numpy(a.offsets.astype(np.int64)))
+            data_b[:len(b.data)] = torch.from_numpy(b.data).cuda(); offs_b.copy_(torch.from_numpy(b.offsets.astype(np.int64)))
+            torch.cuda.synchronize()
+            want = orc.levenshtein_pairs(a, b, utf8=True)
+            for _ in range(3):
+                scope.set_profiling(True)
+                got = engine.pairs(ta, tb, scope)
+                names.append(scope.last_timing()["dominant_name"])
+                scope.set_profiling(False)
+                assert (got == want).all(), names
+            side = 40
+            cross = np.array([[orc.levenshtein_utf8(a[i], b[j]) for j in range(side)] for i in range(side)])
+            for _ in range(2):
+                assert (engine(ta.subview(0, side) if hasattr(ta, "subview") else ta, tb.subview(0, side) if hasattr(tb, "subview") else tb, scope)[:side, :side] == cross).all()
+        # token-sized strings name their kernels by symbol width -- ASCII version: staged once (code points), then on the byte kernel;
+        # mixed version: code points throughout (the first call meets the stale belief and is redone); ASCII again: back on bytes
+        if lo >= 30:
+            assert names[0] == "bitparallel_tiled_u32" and names[1] == names[2] == "bitparallel_tiled", names
+            assert names[3] == names[4] == names[5] == "bitparallel_tiled_u32", names
+            assert names[6] == "bitparallel_tiled_u32" and names[7] == names[8] == "bitparallel_tiled", names
+
+
 def test_pipelined_scope_lanes(sw, orc):
     """Pipelined mode alternates calls between two internal lanes; results must be complete after synchronize()
     (or, on the scope's own stream, after join()) and identical to the synchronous path."""

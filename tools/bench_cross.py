@@ -48,6 +48,7 @@ def main():
         N.check(N.lib.swh_device_alloc(scope.handle, side * side * 8, C.byref(out_ptr), C.byref(err)), err)
         engines = {
             "uniform/LevenshteinDistances": sw.LevenshteinDistances(capabilities=scope),
+            "uniform/LevenshteinDistancesUtf8": sw.LevenshteinDistancesUTF8(capabilities=scope),
             "linear/NeedlemanWunschScores": sw.NeedlemanWunschScores(classes, costs, open=-2, extend=-2, capabilities=scope),
             "affine/NeedlemanWunschScores": sw.NeedlemanWunschScores(classes, costs, open=-5, extend=-1, capabilities=scope),
             "linear/SmithWatermanScores": sw.SmithWatermanScores(classes, costs, open=-2, extend=-2, capabilities=scope),

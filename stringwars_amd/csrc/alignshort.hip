@@ -317,7 +317,7 @@ __device__ __forceinline__ int align_trivial(uint32_t la, uint32_t lb, bool loca
 
 struct AlignWaveLds {
     uint32_t qlen[kAlignQueries];
-    uint32_t qcls[kAlignQueries][8];     // the item's queries as class bytes (<= 32 per query)
+    uint32_t qcls[kAlignQueries][16];    // the item's queries as class bytes (<= 64 per query)
 };
 
 template <int W, int PQ, bool kAffine, bool kLocal>
@@ -395,15 +395,19 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
             uint64_t b0 = 0;
             uint32_t lb = 0;
             if (have) align_extent(job.b.offsets, args.off64, cand, b0, lb);
-            // queries: lane l stages bytes 8 (l % 4) .. + 7 of query l / 4 as classes (16 queries x 32 bytes = 64 lanes x 8 bytes)
+            // queries: lane l stages bytes kLaneBytes (l % 4) .. of query l / 4 as classes (16 queries x 32 bytes = 64 lanes x 8 bytes; rows of
+            // 64 cells: 64 bytes per query, 16 per lane)
+            constexpr int kLaneBytes = W > 32 ? 16 : 8, kLaneWords = kLaneBytes / 4;
             const uint32_t ql = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
             uint64_t qa0 = 0;
             uint32_t qm = 0;
             if (ql < q_count) align_extent(job.a.offsets, args.off64, q_first + ql, qa0, qm);
-            uint32_t staged[2] = {0, 0};
+            uint32_t staged[kLaneWords];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const uint32_t at = part * 8 + (uint32_t)t;
+            for (int t = 0; t < kLaneWords; ++t) staged[t] = 0;
+#pragma unroll
+            for (int t = 0; t < kLaneBytes; ++t) {
+                const uint32_t at = part * kLaneBytes + (uint32_t)t;
                 const uint32_t byte = (at < qm && qm <= (uint32_t)W) ? a_data[qa0 + at] : 0u;
                 staged[t >> 2] |= byte << (8 * (t & 3));
             }
@@ -417,11 +421,11 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
             align_classes<W / 4>(lclass_of, bw, n_max, bcls);
             align_selectors<W, PQ, kLocal>(bcls, n, sel);
             {
-                uint32_t scls[2];
-                align_classes<2>(lclass_of, staged, 8, scls);
+                uint32_t scls[kLaneWords];
+                align_classes<kLaneWords>(lclass_of, staged, kLaneBytes, scls);
                 wave_lds_fence();                              // the previous item's readers are done with the staging area
-                wl.qcls[ql][part * 2] = scls[0];
-                wl.qcls[ql][part * 2 + 1] = scls[1];
+#pragma unroll
+                for (int t = 0; t < kLaneWords; ++t) wl.qcls[ql][part * kLaneWords + t] = scls[t];
                 if (part == 0) wl.qlen[ql] = ql < q_count ? qm : 0u;
                 wave_lds_fence();
             }
@@ -977,10 +981,10 @@ void launch_align_long(Scope *scope, const KernelArgs &k, uint32_t longest_rows)
 template <int W, int PQ>
 static void launch_align_short_model(Scope *scope, const AlignShortArgs &args, bool affine, bool local, uint32_t blocks, const char *&name) {
     const dim3 grid(blocks), block(kAlignWaves * 64);
-    if (!affine && !local) { name = W == 16 ? "align_short_w16" : "align_short_w32"; }
-    else if (affine && !local) { name = W == 16 ? "align_short_affine_w16" : "align_short_affine_w32"; }
-    else if (!affine) { name = W == 16 ? "align_short_local_w16" : "align_short_local_w32"; }
-    else { name = W == 16 ? "align_short_affine_local_w16" : "align_short_affine_local_w32"; }
+    if (!affine && !local) { name = W == 16 ? "align_short_w16" : (W == 32 ? "align_short_w32" : "align_short_w64"); }
+    else if (affine && !local) { name = W == 16 ? "align_short_affine_w16" : (W == 32 ? "align_short_affine_w32" : "align_short_affine_w64"); }
+    else if (!affine) { name = W == 16 ? "align_short_local_w16" : (W == 32 ? "align_short_local_w32" : "align_short_local_w64"); }
+    else { name = W == 16 ? "align_short_affine_local_w16" : (W == 32 ? "align_short_affine_local_w32" : "align_short_affine_local_w64"); }
     StampGuard guard(scope, name);
     if (!affine && !local) hipLaunchKernelGGL((k_align_short<W, PQ, false, false>), grid, block, 0, scope->stream, args);
     else if (affine && !local) hipLaunchKernelGGL((k_align_short<W, PQ, true, false>), grid, block, 0, scope->stream, args);
@@ -989,7 +993,7 @@ static void launch_align_short_model(Scope *scope, const AlignShortArgs &args, b
     SWH_HIP_CHECK(hipGetLastError());
 }
 
-void launch_align_short(Scope *scope, const KernelArgs &k, uint32_t longest) {
+void launch_align_short(Scope *scope, const KernelArgs &k, uint32_t longest, bool wide) {
     AlignShortArgs args{};
     args.job = k.job; args.off64 = k.off64;
     args.open = k.scoring.open; args.extend = k.scoring.extend;
@@ -1004,7 +1008,7 @@ void launch_align_short(Scope *scope, const KernelArgs &k, uint32_t longest) {
     const bool affine = k.affine != 0, local = k.local != 0;
     const bool few = k.scoring.classes && k.scoring.classes <= 8;   // every class in the first two dwords of a cost row
     const char *name = nullptr;
-    if (longest > 32) {   // (api.hip picks this only for cross-products with linear gaps)
+    if (wide) {   // (api.hip picks this only for cross-products with linear gaps)
         const dim3 grid(blocks), block(kAlignWaves * 64);
         name = longest <= 64 ? (local ? "align_wide_local_w64" : "align_wide_w64") : (local ? "align_wide_local_w128" : "align_wide_w128");
         StampGuard guard(scope, name);
@@ -1021,9 +1025,14 @@ void launch_align_short(Scope *scope, const KernelArgs &k, uint32_t longest) {
     if (longest <= 16) {
         if (few) launch_align_short_model<16, 1>(scope, args, affine, local, blocks, name);
         else launch_align_short_model<16, 4>(scope, args, affine, local, blocks, name);
-    } else {
+    } else if (longest <= 32) {
         if (few) launch_align_short_model<32, 1>(scope, args, affine, local, blocks, name);
         else launch_align_short_model<32, 4>(scope, args, affine, local, blocks, name);
+    } else {
+        // up to 64 bytes (a register row of 64 cells, 64 selector registers for 32 classes: two waves per SIMD, Gotoh one): the tail of
+        // multilingual word tokens, which used to send the whole batch to the planned path -- 2048 x 2048 such words 0.19 -> see DESIGN 4.2c
+        if (few) launch_align_short_model<64, 1>(scope, args, affine, local, blocks, name);
+        else launch_align_short_model<64, 4>(scope, args, affine, local, blocks, name);
     }
 }
 

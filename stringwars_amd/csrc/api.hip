@@ -538,13 +538,15 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 else if (!band_pays && longest <= tiled_longest_limit())
                     route = (longest <= 32 && !utf8 && short_route_choice() != 2)
                                 ? (spec.cross ? kRouteCrossShort : (longest <= 16 && pairs >= short_tiled_min_pairs() && short_route_choice() == 0 ? kRouteShortTiled : kRouteDirectShort))
-                                : kRouteTiled;
+                                : ((longest <= 32 && utf8 && spec.cross && short_route_choice() != 2) ? kRouteCrossShort   // word-sized code points: k_cross_short_cp
+                                                                                                          : kRouteTiled);
             }
         }
 
         // Alignment scores on a class table when both tapes hold word-sized strings only (the reference's default `words` token mode,
         // bench.rs:271): one pair per lane, no pre-pass (alignshort.hip). STRINGWARS_AMD_ALIGN_SHORT=0 keeps them on the planned path.
         static const bool align_short_on = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_SHORT"); return !e || atoi(e) != 0; }();
+        bool align_wide = false;   // kRouteAlignShort on k_align_cross_wide (its alphabet condition is checked by the kernel)
         if (engine->kind != 0 && engine->scoring.class_table && !utf8 && !spec.force_planned && align_short_on) {
             bool known = false;
             uint32_t la_max = 0, lb_max = 0;
@@ -559,6 +561,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             if (known && (guaranteed || can_verify) && (both <= 32 || wide)) {
                 route = kRouteAlignShort;
                 longest = both;
+                align_wide = both > 32;
             } else if (known && can_verify && spec.cross && !scope->align_wide_off &&
                        both <= std::min(align_long_limit(), align_long_pays(engine->kind == 2, engine->scoring.open != engine->scoring.extend))) {
                 // longer ones on the same small-alphabet condition: columns in passes of 128 (local or Gotoh: 64, both: 32), the boundary
@@ -566,6 +569,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 // column-profile kernel (align_long_pays)
                 route = kRouteAlignLong;
                 longest = la_max;
+            } else if (known && (guaranteed || can_verify) && both <= 64) {
+                // tokens of up to 64 bytes over any alphabet (multilingual words: ~5 code points are ~11 bytes, their tail reaches past 32):
+                // the lane-per-pair kernel with a register row of 64 cells
+                route = kRouteAlignShort;
+                longest = both;
             }
         }
 
@@ -746,8 +754,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 }
                 launch_short_tiled(scope, job, off64, mean_x16);
             }
-            else if (route == kRouteCrossShort) launch_cross_short(scope, job, off64);
-            else if (route == kRouteAlignShort) launch_align_short(scope, k, longest);
+            else if (route == kRouteCrossShort) launch_cross_short(scope, job, off64, (uint32_t)sym_bytes);
+            else if (route == kRouteAlignShort) launch_align_short(scope, k, longest, align_wide);
             else if (route == kRouteAlignLong) {
                 const uint32_t per_item = align_long_queries(scope, spec.a.count, spec.b.count);
                 const uint64_t items = ((uint64_t)(spec.b.count + 63) / 64) * ((uint64_t)(spec.a.count + per_item - 1) / per_item);
@@ -772,11 +780,14 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 if (scope->summary_host[0].violation) {
                     // the belief about the lengths was wrong (it came from an earlier batch): redo on the planned path
                     scope->hint_lengths = false;
-                    if ((route == kRouteAlignShort && longest > 32) || route == kRouteAlignLong) scope->align_wide_off = true;   // (or: more than eight classes in an item)
+                    const bool compact_failed = (route == kRouteAlignShort && align_wide) || route == kRouteAlignLong;
+                    if (compact_failed) scope->align_wide_off = true;   // (or: more than eight classes in an item)
                     scope->summary_pending = false;
                     scope->stamps_pending = false;
                     CallSpec again = spec;
-                    again.force_planned = true;
+                    // (prepared tapes know their lengths: when only the small-alphabet kernels' condition failed, the redo may still take
+                    // the lane-per-pair kernel -- `align_wide_off` keeps it off the compacting ones)
+                    again.force_planned = !(compact_failed && prepared);
                     return run_call_on(scope, engine, again, error);
                 }
                 harvest_timing(scope, true);

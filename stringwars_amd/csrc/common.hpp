@@ -482,7 +482,7 @@ struct TilePlan { uint32_t tile, tiles, blocks, shift; };
 TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text, uint32_t tile_max);
 void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text);
 // cross.hip: dense queries x candidates for word-sized strings, the query's match table shared by a wave
-void launch_cross_short(Scope *scope, const Job &job, uint32_t off64);
+void launch_cross_short(Scope *scope, const Job &job, uint32_t off64, uint32_t sym_bytes);   // sym_bytes 4: code points (decoded tapes)
 // short.hip: pairwise batches of strings <= 16 bytes: chunks staged in LDS, affixes cut, sorted by what remains
 // `mean_bytes`: mean string length of the longer tape, x16 (0: unknown); sizes the chunks so that their segments fit the LDS arrays
 void launch_short_tiled(Scope *scope, const Job &job, uint32_t off64, uint32_t mean_bytes_x16);
@@ -505,7 +505,7 @@ uint32_t nwprofile_waves(const Scope *scope, uint32_t classes);   // waves of a 
 void launch_nwprofile(Scope *scope, KernelArgs args, uint32_t first, uint32_t count);
 int wavefront_strip_cap();
 // alignshort.hip: NW / SW scores on a class table, both strings <= 32 bytes (`longest`: of both tapes), one pair per lane; plan-free
-void launch_align_short(Scope *scope, const KernelArgs &args, uint32_t longest);
+void launch_align_short(Scope *scope, const KernelArgs &args, uint32_t longest, bool wide);   // wide: k_align_cross_wide (33 .. 128 symbols, <= 8 classes per item)
 // the same for queries x candidates of any length over a small alphabet (<= 8 classes per work item): columns in passes of 128
 // (Gotoh: 64), the boundary column between passes in args.boundary -- align_long_waves() areas of (longest_rows + 8) x 64 ints
 // (x 2 for Gotoh's E); queries of up to 4096 symbols

@@ -217,7 +217,155 @@ __global__ __launch_bounds__(kCrossWaves * 64) void k_cross_short(CrossArgs args
     report_call_summary(PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, lmisfit}, args.partials, args.done_counter, args.summary, summary_lds);
 }
 
-void launch_cross_short(Scope *scope, const Job &job, uint32_t off64) {
+// ---- the same for CODE POINTS (decoded UTF-8 tapes: 32-bit symbols, 64-bit offsets): `LevenshteinDistancesUtf8` on word-sized tokens,
+// the reference's XLSum words column (similarities/README.md:38-63). The query's match table is the code-point model of bp_item.hpp --
+// seven groups of three bits, eight entries each, Eq(c) = the AND of the seven entries c's groups select -- 56 dwords per query, shared
+// by the wave like the byte kernel's 32; a lane keeps its candidate's up to 32 symbols in registers.
+struct CrossCpWaveLds {
+    uint32_t table[2][56];
+    uint32_t qlen[kCrossQueries];
+    uint32_t qsyms[kCrossQueries][kCrossMax];
+};
+
+__global__ __launch_bounds__(kCrossWaves * 64) void k_cross_short_cp(CrossArgs args) {
+    __shared__ CrossCpWaveLds wave_lds[kCrossWaves];
+    __shared__ SummaryLds summary_lds;
+    __shared__ unsigned long long lcells, lsyms;
+    __shared__ uint32_t lmaxa, lmaxb, lshorts, lmisfit;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    CrossCpWaveLds &wl = wave_lds[wave];
+    if (lane < 56) { wl.table[0][lane] = 0; wl.table[1][lane] = 0; }
+    if (threadIdx.x == 0) { lcells = 0; lsyms = 0; lmaxa = 0; lmaxb = 0; lshorts = 0; lmisfit = 0; }
+    __syncthreads();
+    const Job &job = args.job;
+    const uint64_t na = job.a.count, nb = job.b.count;
+    const uint32_t *a_data = (const uint32_t *)job.a.data, *b_data = (const uint32_t *)job.b.data;
+    const uint64_t chunks = (nb + 63) / 64, qblocks = (na + kCrossQueries - 1) / kCrossQueries;
+    const uint64_t items = chunks * qblocks;
+    const uint64_t waves_total = (uint64_t)gridDim.x * kCrossWaves, wave_id = (uint64_t)blockIdx.x * kCrossWaves + wave;
+    unsigned long long cells = 0, syms = 0;
+    uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
+    const size_t elem = job.out_elem64 ? 8 : 4;
+    for (uint64_t item = wave_id; item < items; item += waves_total) {
+        const uint64_t chunk = item / qblocks, qb = item - chunk * qblocks;
+        const uint64_t q_first = qb * kCrossQueries, q_last = q_first + kCrossQueries < na ? q_first + kCrossQueries : na;
+        const uint32_t q_count = (uint32_t)(q_last - q_first);
+        const uint64_t slot = chunk * 64 + (uint64_t)lane;
+        const bool have = slot < nb;
+        uint64_t cand = 0, b0 = 0;
+        uint32_t n = 0;
+        if (have) {
+            cand = slot;
+            tape_extent<uint64_t>(job.b.offsets, cand, b0, n);
+        }
+        // queries: lane l stages symbols 8 (l % 4) .. 8 (l % 4) + 7 of query l / 4
+        const uint32_t ql = (uint32_t)lane >> 2, part = (uint32_t)lane & 3u;
+        uint64_t qa0 = 0;
+        uint32_t qm = 0;
+        if (ql < q_count) tape_extent<uint64_t>(job.a.offsets, q_first + ql, qa0, qm);
+        uint32_t staged[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t at = part * 8 + (uint32_t)t;
+            staged[t] = (at < qm && qm <= kCrossMax) ? a_data[qa0 + at] : 0u;
+        }
+        const bool fits = have && n <= kCrossMax;
+        if (have && !fits) misfit = 1;
+        uint32_t tw[kCrossMax];
+#pragma unroll
+        for (int t = 0; t < (int)kCrossMax; ++t) tw[t] = (fits && (uint32_t)t < n) ? b_data[b0 + (uint32_t)t] : 0u;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) wl.qsyms[ql][part * 8 + t] = staged[t];
+        if (part == 0) wl.qlen[ql] = ql < q_count ? qm : 0u;
+        lds_program_order();
+        const uint32_t n_live = fits ? n : 0;
+        const uint32_t n_max = wave_max_u32(n_live);
+        unsigned long long sum_m = 0;
+        uint32_t item_maxa = 0;
+        auto build = [&](uint32_t q, uint32_t *table) -> uint32_t {
+            const uint32_t m = q < q_count ? wl.qlen[q] : 0u;
+            if ((uint32_t)lane < m && m <= kCrossMax) {
+                const uint32_t c = wl.qsyms[q][lane];
+#pragma unroll
+                for (int g = 0; g < 7; ++g) atomicOr(&table[g * 8 + ((c >> (3 * g)) & 7u)], 1u << lane);
+            }
+            return m;
+        };
+        uint32_t m_next = build(0, wl.table[0]);
+        for (uint32_t q = 0; q < q_count; ++q) {
+            uint32_t *table = wl.table[q & 1];
+            const uint32_t m = m_next;
+            lds_program_order();
+            m_next = build(q + 1, wl.table[(q + 1) & 1]);
+            sum_m += m;
+            item_maxa = m > item_maxa ? m : item_maxa;
+            if (m > kCrossMax) misfit = 1;
+            uint32_t pv = 0xFFFFFFFFu, mv = 0;
+            if (m <= kCrossMax) {
+#pragma unroll
+                for (int t = 0; t < (int)kCrossMax; ++t) {
+                    if ((uint32_t)t >= n_max) break;
+                    const uint32_t c = tw[t];
+                    uint32_t eq = table[c & 7u] & table[8 + ((c >> 3) & 7u)] & table[16 + ((c >> 6) & 7u)];
+                    eq &= table[24 + ((c >> 9) & 7u)] & table[32 + ((c >> 12) & 7u)];
+                    eq &= table[40 + ((c >> 15) & 7u)] & table[48 + ((c >> 18) & 7u)];
+                    if ((uint32_t)t < n_live) {
+                        const uint32_t xv = eq | mv;
+                        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                        uint32_t ph = mv | ~(xh | pv);
+                        const uint32_t mh = pv & xh;
+                        ph = (ph << 1) | 1u;
+                        pv = (mh << 1) | ~(xv | ph);
+                        mv = ph & xv;
+                    }
+                }
+                if (fits) {
+                    const uint32_t mask = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u);
+                    const uint32_t d = n + __popc(pv & mask) - __popc(mv & mask);
+                    char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
+                    store_out(dst, job.out_elem64 != 0, (int64_t)d);
+                }
+            }
+            lds_program_order();
+            if (lane < 56) table[lane] = 0;
+        }
+        lds_program_order();
+        if (lane < 56) wl.table[q_count & 1][lane] = 0;
+        lds_program_order();
+        if (have) {
+            cells += sum_m * (unsigned long long)n;
+            maxb = n > maxb ? n : maxb;
+            if (qb == 0) syms += n;
+            if (fits) shorts += q_count;
+        }
+        if (lane == 0) {
+            maxa = item_maxa > maxa ? item_maxa : maxa;
+            if (chunk == 0) syms += sum_m;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cells += __shfl_xor(cells, off);
+        syms += __shfl_xor(syms, off);
+        shorts += __shfl_xor(shorts, off);
+        misfit |= __shfl_xor(misfit, off);
+        const uint32_t oa = __shfl_xor(maxa, off), ob = __shfl_xor(maxb, off);
+        maxa = oa > maxa ? oa : maxa;
+        maxb = ob > maxb ? ob : maxb;
+    }
+    if (lane == 0) {
+        atomicAdd(&lcells, cells);
+        atomicAdd(&lsyms, syms);
+        atomicAdd(&lshorts, shorts);
+        atomicMax(&lmaxa, maxa);
+        atomicMax(&lmaxb, maxb);
+        atomicOr(&lmisfit, misfit);
+    }
+    __syncthreads();
+    report_call_summary(PlanPartial{lcells, lsyms, lmaxa, lmaxb, lshorts, lmisfit}, args.partials, args.done_counter, args.summary, summary_lds);
+}
+
+void launch_cross_short(Scope *scope, const Job &job, uint32_t off64, uint32_t sym_bytes) {
     CrossArgs args{};
     args.job = job; args.off64 = off64;
     args.partials = scope->plan_partials; args.done_counter = scope->done_counter; args.summary = scope->summary_target();
@@ -226,8 +374,9 @@ void launch_cross_short(Scope *scope, const Job &job, uint32_t off64) {
     uint32_t max_blocks = (uint32_t)scope->compute_units * 8;
     if (max_blocks > (uint32_t)kMaxPartials) max_blocks = kMaxPartials;
     const uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)(blocks64 ? blocks64 : 1);
-    StampGuard guard(scope, "cross_short");
-    if (off64) hipLaunchKernelGGL(k_cross_short<uint64_t>, dim3(blocks), dim3(kCrossWaves * 64), 0, scope->stream, args);
+    StampGuard guard(scope, sym_bytes == 4 ? "cross_short_u32" : "cross_short");
+    if (sym_bytes == 4) hipLaunchKernelGGL(k_cross_short_cp, dim3(blocks), dim3(kCrossWaves * 64), 0, scope->stream, args);   // (decoded tapes: 64-bit offsets)
+    else if (off64) hipLaunchKernelGGL(k_cross_short<uint64_t>, dim3(blocks), dim3(kCrossWaves * 64), 0, scope->stream, args);
     else hipLaunchKernelGGL(k_cross_short<uint32_t>, dim3(blocks), dim3(kCrossWaves * 64), 0, scope->stream, args);
     SWH_HIP_CHECK(hipGetLastError());
 }

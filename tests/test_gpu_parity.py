@@ -846,6 +846,83 @@ def test_ascii_tapes_through_the_utf8_engine_run_on_their_bytes(sw, orc):
             assert names[6] == "bitparallel_tiled_u32" and names[7] == names[8] == "bitparallel_tiled", names
 
 
+@pytest.mark.parametrize("local", [False, True])
+@pytest.mark.parametrize("gaps", [(-2, -2), (-5, -1)])
+def test_alignment_of_tokens_up_to_64_bytes(sw, orc, local, gaps):
+    """k_align_short with a register row of 64 cells: tokens of up to 64 bytes over ANY alphabet (multilingual words: a few of them reach
+    past 32 bytes) stay on the lane-per-pair kernel instead of sending the whole batch to the planned path -- pairwise and cross-product,
+    prepared tapes (lengths known) and raw ones (second call), lengths around 32 / 33 / 63 / 64, a 65-byte token falls back."""
+    rng = np.random.default_rng(64 + local)
+    scope = sw.DeviceScope(gpu_device=0)
+    Engine = sw.SmithWatermanScores if local else sw.NeedlemanWunschScores
+    byte_to_class, costs = sw.unary_class_costs(2, -1)
+    full = np.array([[costs[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+    engine = Engine(byte_to_class, costs, open=gaps[0], extend=gaps[1], capabilities=scope)
+
+    def token(n):
+        return bytes(rng.integers(0, 256, int(n), dtype=np.uint8))
+
+    lens = [0, 1, 31, 32, 33, 63, 64] + list(rng.integers(1, 65, 300))
+    xs, ys = [token(n) for n in lens], [token(n) for n in rng.permutation(lens)]
+    ys[10] = xs[10][:40] + token(5)
+    want = np.array([orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for x, y in zip(xs, ys)])
+    pa, pb = sw.PreparedTape(scope, sw.Strs(xs)), sw.PreparedTape(scope, sw.Strs(ys))
+    scope.set_profiling(True)
+    got = engine.pairs(pa, pb, scope)
+    name = scope.last_timing()["dominant_name"]
+    scope.set_profiling(False)
+    assert name.startswith("align_short") and name.endswith("w64"), name
+    assert (got == want).all(), np.nonzero(got != want)[0][:5]
+    a, b = sw.Strs(xs), sw.Strs(ys)
+    for _ in range(2):
+        assert (engine.pairs(a, b, scope) == want).all()
+    qs, cs = xs[:40], ys[:90]
+    cross = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in cs] for x in qs])
+    pq, pc = sw.PreparedTape(scope, sw.Strs(qs)), sw.PreparedTape(scope, sw.Strs(cs))
+    for _ in range(2):   # (the first call may try the small-alphabet kernels: their condition fails on 256 byte values, the redo lands here)
+        scope.set_profiling(True)
+        got = engine(pq, pc, scope)
+        name = scope.last_timing()["dominant_name"]
+        scope.set_profiling(False)
+        assert (got == cross).all()
+    assert name.startswith("align_short") and name.endswith("w64"), name
+    xs2, ys2 = xs + [token(3)], ys + [token(65)]
+    want2 = np.array([orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for x, y in zip(xs2, ys2)])
+    assert (engine.pairs(sw.PreparedTape(scope, sw.Strs(xs2)), sw.PreparedTape(scope, sw.Strs(ys2)), scope) == want2).all()
+
+
+def test_cross_product_of_word_sized_code_points(sw, orc, scope):
+    """k_cross_short_cp (cross.hip): queries x candidates of up to 32 CODE POINTS each -- `LevenshteinDistancesUtf8` on word-sized tokens of
+    several scripts (1 .. 4-byte sequences, symbols that collide in single groups of their three-bit group tables), empty strings,
+    lengths up to exactly 32 -- against the oracle; the second call on the same scope (lengths known from the first) must run on
+    `cross_short_u32`, a candidate of 33 code points takes the general path and scores the same."""
+    rng = np.random.default_rng(55)
+    cps = [0x61, 0x69, 0x71, 0xE9, 0xE1, 0x430, 0x438, 0x4E2D, 0x4E25, 0x1F600, 0x1F608, 0x10FFFF, 0x7F, 0x80, 0x7FF, 0x800, 0xFFFF, 0x10000]
+
+    def word(n):
+        return "".join(chr(cps[int(c)]) for c in rng.integers(0, len(cps), int(n))).encode()
+
+    queries = [word(n) for n in [0, 1, 2, 31, 32] + list(rng.integers(1, 12, 95))]
+    candidates = [word(n) for n in [0, 1, 32, 32, 5] + list(rng.integers(1, 14, 200))]
+    candidates[7] = queries[9] + word(2)
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    want = np.array([[orc.levenshtein_utf8(x, y) for y in candidates] for x in queries])
+    q, c = sw.Strs(queries).to_device(scope), sw.Strs(candidates).to_device(scope)
+    assert (engine(q, c, scope) == want).all()
+    scope.set_profiling(True)
+    got = engine(q, c, scope)
+    name = scope.last_timing()["dominant_name"]
+    scope.set_profiling(False)
+    assert name == "cross_short_u32", name
+    assert (got == want).all(), np.argwhere(got != want)[:5]
+    longer = candidates + [word(33)]
+    want2 = np.array([[orc.levenshtein_utf8(x, y) for y in longer] for x in queries])
+    c2 = sw.Strs(longer).to_device(scope)
+    for _ in range(2):
+        assert (engine(q, c2, scope) == want2).all()
+    q.free(); c.free(); c2.free()
+
+
 def test_pipelined_scope_lanes(sw, orc):
     """Pipelined mode alternates calls between two internal lanes; results must be complete after synchronize()
     (or, on the scope's own stream, after join()) and identical to the synchronous path."""

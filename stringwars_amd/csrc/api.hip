@@ -129,6 +129,7 @@ static void harvest_timing(Scope *scope, bool complete) {
             scope->hint_lengths = true;
             scope->hint_max_la = sm.max_la; scope->hint_max_lb = sm.max_lb;
             scope->hint_mean_x16 = scope->summary_pairs ? (uint32_t)std::min<uint64_t>(sm.symbols * 8 / scope->summary_pairs, 0xFFFFFFu) : 0u;
+            scope->hint_mean_string_x16 = scope->summary_strings ? (uint32_t)std::min<uint64_t>(sm.symbols * 16 / scope->summary_strings, 0xFFFFFFu) : 0u;
             scope->hint_short = (uint64_t)sm.short_pairs * 4 >= scope->summary_pairs;
         } else if (scope->async) {
             // An asynchronous plan-free call cannot be redone behind the caller's back (synchronous calls are: run_call_on).
@@ -223,6 +224,7 @@ struct CallSpec {
     const Prepared *pa = nullptr, *pb = nullptr;   // prepared tapes (both or neither); a.count / b.count = the views' counts
     size_t a_first = 0, b_first = 0;
     bool force_planned = false;                    // redo of a call whose plan-free kernel met a pair it could not score
+    uint32_t skip_upto = 0;                        // ... where that kernel HAS scored every pair of two strings of at most this many symbols
 };
 
 static uint64_t read_offset(const void *offs, int off64, size_t i, bool device, hipStream_t stream) {
@@ -574,6 +576,21 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 // the lane-per-pair kernel with a register row of 64 cells
                 route = kRouteAlignShort;
                 longest = both;
+            } else if (known && can_verify && !scope->async) {
+                // word tokens with a FEW long ones among them (a URL, a sentence of a script that writes no spaces): the lane kernel scores
+                // every pair of two strings that fit its 64 cells, reports that some did not, and the redo plans only the pairs with a
+                // longer string (`skip_upto`) -- instead of 4 M word pairs on kernels built for long strings (2048 x 2048 multilingual
+                // words with one token of 70 bytes: 2.2 ms per call, NW linear). Taken when the mean string is word-sized.
+                uint64_t mean_x16 = scope->hint_mean_string_x16;
+                if (prepared) {
+                    const uint64_t ma = spec.pa->bytes.count ? spec.pa->total_bytes * 16 / spec.pa->bytes.count : 0;
+                    const uint64_t mb = spec.pb->bytes.count ? spec.pb->total_bytes * 16 / spec.pb->bytes.count : 0;
+                    mean_x16 = std::max(ma, mb);
+                }
+                if (mean_x16 && mean_x16 <= 24 * 16) {
+                    route = kRouteAlignShort;
+                    longest = 64;
+                }
             }
         }
 
@@ -692,6 +709,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         pre.unit_costs = engine->kind == 0 && engine->unit_costs ? 1 : 0;
         pre.local = engine->kind == 2 ? 1 : 0;
         pre.direct_short = bitpar_ok && sym_bytes == 1 && engine->algorithm == swh_algorithm_auto_k && scope->hint_short ? 1 : 0;
+        pre.skip_upto = spec.skip_upto;
         pre.banded = pre.unit_costs && spec.bound <= band_max_bound() && engine->algorithm == swh_algorithm_auto_k ? 1 : 0;
         pre.perm = perm; pre.keys = plan_keys; pre.hist = scope->plan_hist; pre.cursor = scope->plan_cursor;
         pre.partials = scope->plan_partials; pre.leftover = scope->plan_leftover; pre.plan = plan_dev;
@@ -769,6 +787,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             copy_results_back();
             scope->summary_sym_bytes = need_sizes ? 0 : sym_bytes;
             scope->summary_pairs = pairs; scope->summary_ow = ow; scope->summary_elem = elem;
+            scope->summary_strings = spec.cross ? (uint64_t)spec.a.count + spec.b.count : 2 * (uint64_t)pairs;
             scope->summary_extra_bytes = need_sizes ? a_bytes + b_bytes : 0;
             scope->summary_pending = true;
             scope->stamps_pending = scope->profiling;
@@ -788,6 +807,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                     // (prepared tapes know their lengths: when only the small-alphabet kernels' condition failed, the redo may still take
                     // the lane-per-pair kernel -- `align_wide_off` keeps it off the compacting ones)
                     again.force_planned = !(compact_failed && prepared);
+                    // the lane-per-pair kernel has scored every pair whose two strings fit its register row: the redo plans the others
+                    if (route == kRouteAlignShort && !align_wide) again.skip_upto = longest <= 16 ? 16u : (longest <= 32 ? 32u : 64u);
                     return run_call_on(scope, engine, again, error);
                 }
                 harvest_timing(scope, true);
@@ -824,6 +845,10 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         scope->hint_short = (uint64_t)plan.short_pairs * 4 >= pairs;
         scope->hint_lengths = true;
         scope->hint_max_la = plan.max_la; scope->hint_max_lb = plan.max_lb;
+        {
+            const uint64_t strings = 2 * (uint64_t)pairs;   // (the planner sums la + lb over PAIRS, also for a cross-product)
+            scope->hint_mean_string_x16 = strings ? (uint32_t)std::min<uint64_t>(plan.symbols * 16 / strings, 0xFFFFFFu) : 0u;
+        }
         if (*invalid_host) return invalid_utf8();
         learn_ascii();
 

@@ -382,6 +382,8 @@ struct Scope {
     bool align_wide_off = false;   // k_align_cross_wide met candidates with more than eight symbol classes (or longer strings): not tried again
     uint32_t hint_max_la = 0, hint_max_lb = 0;
     uint32_t hint_mean_x16 = 0;   // mean string length of the previous call, x16 (both tapes together)
+    uint32_t hint_mean_string_x16 = 0;   // symbols per STRING of the previous call, x16 (a cross-product counts every string once)
+    uint64_t summary_strings = 0;        // strings of the call whose summary is pending
     CallSummary *summary_host = nullptr;   // pinned, mapped: written by kernels, read by the host after a synchronisation
     CallSummary *summary_dev = nullptr;    // the same memory as the device sees it
     uint32_t summary_slot = 0;             // which of the block's two summaries the call in flight reports into (1: asynchronous)
@@ -448,6 +450,8 @@ struct PrepassArgs {
     uint32_t banded;        // bound <= 63 with unit costs: pairs may take the banded kernel
     uint32_t local;         // local alignment: pairs with an empty side score 0
     uint32_t direct_short;  // unit-cost byte pairs with both sides <= 32 symbols are scored by k_direct_short
+    uint32_t skip_upto;     // pairs with both sides <= this many symbols have been scored already (by k_align_short: the redo of a batch
+                            // whose few longer strings did not fit its register row plans only the pairs with such a string); 0: none
     uint32_t *perm;         // out: pair ids sorted by key
     uint16_t *keys;         // scratch: every pair's plan key, written by k_plan_hist, read back by k_plan_scatter
     uint32_t *hist;         // scratch: kKeys counters

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_hist(PrepassArgs args) {
             // the cutoff applies to every distance, whatever the costs (same as store_score in wavefront.hip)
             if (args.job.negate) v = (int64_t)clamp_bound((uint32_t)(-v), args.job.bound);
             store_result(args.job, p, v);
-        } else if (is_short && args.direct_short) {
-            key = kClassTrivial * kBuckets;   // scored by k_direct_short
+        } else if ((is_short && args.direct_short) || (info.la <= args.skip_upto && info.lb <= args.skip_upto)) {
+            key = kClassTrivial * kBuckets;   // scored by k_direct_short (or, skip_upto, by the lane-per-pair alignment kernel)
         } else {
             key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
         }
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_fused(PrepassArgs args, F
                     int64_t v = info.trivial_value;
                     if (args.job.negate) v = (int64_t)clamp_bound((uint32_t)(-v), args.job.bound);
                     if (!args.direct_short) store_result(args.job, p, v);   // (k_direct_short has stored it already)
-                } else if (is_short && args.direct_short) {
-                    key = kClassTrivial * kBuckets;   // scored by k_direct_short
+                } else if ((is_short && args.direct_short) || (info.la <= args.skip_upto && info.lb <= args.skip_upto)) {
+                    key = kClassTrivial * kBuckets;   // scored by k_direct_short (or, skip_upto, by the lane-per-pair alignment kernel)
                 } else {
                     key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
                 }

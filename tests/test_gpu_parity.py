@@ -891,6 +891,40 @@ def test_alignment_of_tokens_up_to_64_bytes(sw, orc, local, gaps):
     assert (engine.pairs(sw.PreparedTape(scope, sw.Strs(xs2)), sw.PreparedTape(scope, sw.Strs(ys2)), scope) == want2).all()
 
 
+@pytest.mark.parametrize("local", [False, True])
+def test_word_batches_with_a_few_long_tokens(sw, orc, local):
+    """Word tokens with a few long ones among them (a URL, a sentence of a script that writes no spaces): k_align_short scores every pair
+    of two strings that fit its 64 cells and reports that some did not; the redo plans ONLY the pairs with a longer string
+    (PrepassArgs::skip_upto) and must leave the others' scores alone. Cross-product and pairs, prepared and raw tapes (second call: the
+    first one's statistics), every score against the oracle; the second call's dominant kernel is the lane kernel's."""
+    rng = np.random.default_rng(72 + local)
+    scope = sw.DeviceScope(gpu_device=0)
+    Engine = sw.SmithWatermanScores if local else sw.NeedlemanWunschScores
+    byte_to_class, costs = sw.unary_class_costs(2, -1)
+    full = np.array([[costs[i % 32, j % 32] for j in range(256)] for i in range(256)], dtype=np.int8)
+    engine = Engine(byte_to_class, costs, open=-5, extend=-1, capabilities=scope)
+
+    def token(n):
+        return bytes(rng.integers(0, 256, int(n), dtype=np.uint8))
+
+    qs = [token(n) for n in list(rng.integers(1, 20, 60)) + [70, 130]]
+    cs = [token(n) for n in list(rng.integers(1, 24, 150)) + [65, 300, 64]]
+    want = np.array([[orc.nw_score(x, y, full, -5, -1, local=local) for y in cs] for x in qs])
+    pq, pc = sw.PreparedTape(scope, sw.Strs(qs)), sw.PreparedTape(scope, sw.Strs(cs))
+    for _ in range(2):
+        out = engine(pq, pc, scope)
+        assert (out == want).all(), np.argwhere(out != want)[:5]
+    raw_q, raw_c = sw.Strs(qs), sw.Strs(cs)
+    for _ in range(3):
+        assert (engine(raw_q, raw_c, scope) == want).all()
+    xs = [token(n) for n in list(rng.integers(1, 20, 500)) + [90]]
+    ys = [token(n) for n in list(rng.integers(1, 20, 500)) + [5]]
+    want_pairs = np.array([orc.nw_score(x, y, full, -5, -1, local=local) for x, y in zip(xs, ys)])
+    pa, pb = sw.PreparedTape(scope, sw.Strs(xs)), sw.PreparedTape(scope, sw.Strs(ys))
+    for _ in range(2):
+        assert (engine.pairs(pa, pb, scope) == want_pairs).all()
+
+
 def test_cross_product_of_word_sized_code_points(sw, orc, scope):
     """k_cross_short_cp (cross.hip): queries x candidates of up to 32 CODE POINTS each -- `LevenshteinDistancesUtf8` on word-sized tokens of
     several scripts (1 .. 4-byte sequences, symbols that collide in single groups of their three-bit group tables), empty strings,

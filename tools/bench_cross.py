@@ -17,13 +17,19 @@ def tokens(kind, count, rng):
         lens = np.full(count, 1000)
     elif kind.startswith("acgt"):   # acgt<N>: any other fixed length, for route experiments
         lens = np.full(count, int(kind[4:]))
-    elif kind in ("words", "uwords"):
+    elif kind.startswith("text"):   # text<N>: 26 letters, lengths around N (the mid-length shapes between words and lines)
+        lens = np.clip(rng.normal(int(kind[4:]), int(kind[4:]) / 5, count).astype(int), 1, None)
+    elif kind in ("words", "uwords", "twords"):
         lens = np.clip(rng.poisson(4.0, count) + 1, 1, 24)
     elif kind == "lines":
         lens = np.clip(rng.normal(3200, 1200, count).astype(int), 200, 9000)
-    if kind == "uwords":   # multilingual word-sized tokens (what XLSum words look like to the UTF-8 engine): ~5 code points of four scripts
+    if kind in ("uwords", "twords"):   # multilingual word-sized tokens (what XLSum words look like to the UTF-8 engine): ~5 code points of four scripts
         cps = np.array([0x61, 0x65, 0x6F, 0x74, 0xE9, 0xFC, 0x430, 0x435, 0x43E, 0x442, 0x4E2D, 0x6587, 0x65E5, 0x672C], dtype=np.uint32)
         lens = np.clip(rng.poisson(4.0, count) + 1, 1, 24)
+        if kind == "uwords":
+            lens = np.minimum(lens, 12)            # (~11 bytes on average, no token beyond 36: the lane kernels' own range)
+        else:
+            lens[rng.integers(0, count, 6)] = 60   # "twords": six tokens of ~130 bytes among them (URLs, unsegmented sentences)
         return sw.Strs(["".join(chr(int(c)) for c in cps[rng.integers(0, len(cps), int(n))]).encode() for n in lens])
     alphabet = np.frombuffer(b"ACGT" if kind.startswith("acgt") else bytes(range(97, 123)), dtype=np.uint8)
     offsets = np.zeros(count + 1, dtype=np.uint64)

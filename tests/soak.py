@@ -112,6 +112,20 @@ def main():
                 got = sharded_engine.pairs_sharded(batch, multi, bound=bound)
                 assert (got == want).all(), ("sharded", bound)
                 batch.free()
+            if rounds % 2 == 1:   # raw DEVICE tapes, three calls: the second and third believe what the first one learnt about them
+                                  # (byte totals; pure ASCII -> the byte kernels behind k_ascii_check), then the tapes change in place
+                da, db = a.to_device(scope), b.to_device(scope)
+                for _ in range(3):
+                    assert (engine.pairs(da, db, scope, bound=bound) == want).all(), ("device tapes", kind, algorithm, bound)
+                if utf8 and len(a) > 1:   # words of either script as a cross-product on device tapes (k_cross_short_cp / its byte twin), twice
+                    uq = [bytes(x).decode("utf-8", "ignore")[:int(rng.integers(0, 33))].encode() for x in (a[i] for i in range(min(len(a), 30)))]
+                    uc = [bytes(x).decode("utf-8", "ignore")[:int(rng.integers(0, 33))].encode() for x in (b[i] for i in range(min(len(b), 70)))]
+                    flat = np.array([[oracle.levenshtein_utf8(x, y) for y in uc] for x in uq])
+                    dq, dc = sw.Strs(uq).to_device(scope), sw.Strs(uc).to_device(scope)
+                    for _ in range(2):
+                        assert (engine(dq, dc, scope) == flat).all(), "cross-product of word-sized code points"
+                    dq.free(); dc.free()
+                da.free(); db.free()
             if rounds % 5 == 0:   # a word-sized cross-product (k_cross_short) against the same oracle, pair by pair
                 words_q = [bytes(x) for x in (a[i][:int(rng.integers(0, 33))] for i in range(min(len(a), 40)))]
                 words_c = [bytes(x) for x in (b[i][:int(rng.integers(0, 33))] for i in range(min(len(b), 90)))]
@@ -172,6 +186,13 @@ def main():
             assert (engine.pairs(a, b, scope) == want).all(), ("second call", kind, classes, gaps, lo, hi)
             pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
             assert (engine.pairs(pa, pb, scope) == want).all(), ("prepared", kind, classes, gaps, lo, hi)
+            if rounds % 2 == 0:   # word tokens with a few long ones among them: the lane kernel + a redo that plans only the pairs it left
+                wq = [x[:int(rng.integers(0, 20))] for x in items_a[:40]] + [x[:int(n)] for x, n in zip(items_a[40:43], (70, 150, 65))]
+                wc = [x[:int(rng.integers(0, 24))] for x in items_b[:120]] + [x[:int(n)] for x, n in zip(items_b[120:123], (66, 400, 64))]
+                wflat = np.array([[oracle.nw_score(x, y, matrix, gaps[0], gaps[1], local=(kind == "sw")) for y in wc] for x in wq])
+                pwq, pwc = sw.PreparedTape(scope, sw.Strs(wq)), sw.PreparedTape(scope, sw.Strs(wc))
+                for _ in range(2):
+                    assert (engine(pwq, pwc, scope) == wflat).all(), ("words with a few long tokens", kind, classes, gaps)
             cut = int(rng.choice([16, 32, 64, 128, 200, 384, 1000, 2048, 4096]))   # (beyond 128: columns in passes, k_align_cross_long)
             few = cut > 384   # (the oracle's share: 7 x 70 strings of up to 4 K symbols are ~10^9 cells)
             qs, cs = [x[:cut] for x in items_a[:7 if few else 23]], [x[:cut] for x in items_b[:70 if few else 150]]

@@ -36,7 +36,41 @@ def tape_digest(a, b) -> str:
     return h.hexdigest()
 
 
+def multilingual_words():
+    """tests/golden/uwords.npz: word-sized tokens of four scripts (1 .. 3-byte sequences, ~5 code points each) with a few long ones among
+    them -- 24 queries x 40 candidates -- and what the reference's engines would report for their cross-product: Levenshtein over bytes and
+    over code points (`LevenshteinDistances` / `LevenshteinDistancesUtf8`, bench.rs:382-399), NW / SW with `unary_class_costs(2, -1)`, linear
+    -2 / -2 and affine -5 / -1 (bench.rs:640, :655, :966). The shapes this round's routes were built for: code-point cross-products of
+    words, tokens of up to 64 bytes, a batch whose few longer tokens are scored apart."""
+    rng = np.random.default_rng(4242)
+    cps = np.array([0x61, 0x65, 0x6F, 0x74, 0xE9, 0xFC, 0x430, 0x435, 0x43E, 0x442, 0x4E2D, 0x6587, 0x65E5, 0x672C], dtype=np.uint32)
+
+    def token(n):
+        return "".join(chr(int(c)) for c in cps[rng.integers(0, len(cps), int(n))]).encode()
+
+    queries = [token(n) for n in list(np.clip(rng.poisson(4.0, 21) + 1, 1, 14)) + [0, 28, 61]]
+    candidates = [token(n) for n in list(np.clip(rng.poisson(4.0, 36) + 1, 1, 14)) + [0, 22, 30, 140]]
+    candidates[5] = queries[3] + token(2)
+    q, c = sw.Strs(queries), sw.Strs(candidates)
+    out = {"q_data": q.data, "q_offsets": q.offsets, "c_data": c.data, "c_offsets": c.offsets}
+    out["lev_bytes"] = np.array([[oracle.levenshtein(x, y) for y in candidates] for x in queries], dtype=np.int64)
+    assert (out["lev_bytes"] == np.array([[oracle.levenshtein(x, y, algo="hyyro") for y in candidates] for x in queries])).all()
+    out["lev_utf8"] = np.array([[oracle.levenshtein_utf8(x, y) for y in candidates] for x in queries], dtype=np.int64)
+    byte_to_class, class_costs = sw.unary_class_costs(2, -1)
+    unary = class_costs[byte_to_class][:, byte_to_class].astype(np.int8)
+    for tag, (open_, extend) in {"linear_m2": (-2, -2), "affine_m5_m1": (-5, -1)}.items():
+        for kind, local in (("nw", False), ("sw", True)):
+            scores = np.array([[oracle.nw_score(x, y, unary, open_, extend, local=local) for y in candidates] for x in queries], dtype=np.int64)
+            for i in range(0, 24, 5):   # the cubic second implementation on a few rows
+                for j in range(0, 40, 7):
+                    assert scores[i, j] == oracle.align_score_general(queries[i], candidates[j], unary, open_, extend, local=local)
+            out[f"{kind}_unary_{tag}"] = scores
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "uwords.npz"), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
 def main():
+    multilingual_words()
     out = {}
     for name, verbatim in VERBATIM.items():
         a, b = sw.generate_pairs(name, FULL, seed=42)

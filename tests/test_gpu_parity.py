@@ -2337,6 +2337,34 @@ def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps)
         assert (engine2(sw.PreparedTape(fresh2, sw.Strs(text[:10])), sw.PreparedTape(fresh2, sw.Strs(text[10:])), fresh2) == want).all()
 
 
+def test_golden_multilingual_words(sw, scope):
+    """tests/golden/uwords.npz (made by tests/golden/make_fixtures.py::multilingual_words): 24 x 40 word tokens of four scripts with a few long
+    ones among them -- the committed oracle matrices for Levenshtein over bytes and over code points and for NW / SW with the reference's
+    unary class costs, against the cross-product routes on prepared tapes, raw host tapes and raw device tapes, each twice (the second
+    call acts on what the first one learnt)."""
+    z = np.load(os.path.join(GOLDEN, "uwords.npz"))
+    q = sw.Strs(data=z["q_data"], offsets=z["q_offsets"])
+    c = sw.Strs(data=z["c_data"], offsets=z["c_offsets"])
+    byte_to_class, class_costs = sw.unary_class_costs(2, -1)
+    engines = {"lev_bytes": sw.LevenshteinDistances(capabilities=scope), "lev_utf8": sw.LevenshteinDistancesUTF8(capabilities=scope)}
+    for tag, gaps in (("linear_m2", (-2, -2)), ("affine_m5_m1", (-5, -1))):
+        engines[f"nw_unary_{tag}"] = sw.NeedlemanWunschScores(byte_to_class, class_costs, open=gaps[0], extend=gaps[1], capabilities=scope)
+        engines[f"sw_unary_{tag}"] = sw.SmithWatermanScores(byte_to_class, class_costs, open=gaps[0], extend=gaps[1], capabilities=scope)
+    for name, engine in engines.items():
+        want = z[name]
+        utf8 = name == "lev_utf8"
+        tapes = [(sw.PreparedTape(scope, q, utf8=utf8), sw.PreparedTape(scope, c, utf8=utf8)), (q, c), (q.to_device(scope), c.to_device(scope))]
+        for tq, tc in tapes:
+            for _ in range(2):
+                got = engine(tq, tc, scope)
+                assert (got == want).all(), (name, type(tq).__name__, np.argwhere(got != want)[:5])
+        # the word-sized part alone (no long tokens): the lane / wave-shared kernels' own range
+        short_q, short_c = q.subview(0, 21), c.subview(0, 36)
+        for _ in range(2):
+            assert (engine(short_q, short_c, scope) == want[:21, :36]).all(), (name, "words only")
+        tapes[2][0].free(); tapes[2][1].free()
+
+
 def test_golden_words_alignment_rows(sw, scope):
     """tests/golden/slices.npz: the reference's alignment rows on word-sized tokens -- `unary_class_costs(2, -1)`, linear -2 / -2 and
     affine -5 / -1 (bench.rs:640, :655, :966), NW and SW -- for the first 256 `words16` pairs (pairwise, prepared and raw tapes) and the

@@ -237,6 +237,26 @@ def test_golden_slices_reproducible(orc, sw):
     assert orc.nw_score(a[0], b[0], z["protein4k.matrix"], -11, -1, local=True) == z["protein4k.n256.sw_affine_m11_m1"][0]
 
 
+def test_golden_multilingual_words_reproducible(orc, sw):
+    """tests/golden/uwords.npz against the oracle: every matrix of the committed fixture recomputed from its committed inputs (Levenshtein
+    over bytes by both CPU routines and over code points; NW / SW with the reference's unary class costs, linear and affine; a few
+    entries also by the cubic general-gap table)."""
+    z = np.load(os.path.join(GOLDEN, "uwords.npz"))
+    q = sw.Strs(data=z["q_data"], offsets=z["q_offsets"])
+    c = sw.Strs(data=z["c_data"], offsets=z["c_offsets"])
+    queries, candidates = [q[i] for i in range(len(q))], [c[j] for j in range(len(c))]
+    assert any(len(x) > 64 for x in queries + candidates) and any(b > 0x7F for x in queries for b in x)   # long tokens, several scripts
+    assert [[orc.levenshtein(x, y) for y in candidates] for x in queries] == z["lev_bytes"].tolist()
+    assert [[orc.levenshtein(x, y, algo="hyyro") for y in candidates] for x in queries] == z["lev_bytes"].tolist()
+    assert [[orc.levenshtein_utf8(x, y) for y in candidates] for x in queries] == z["lev_utf8"].tolist()
+    byte_to_class, class_costs = sw.unary_class_costs(2, -1)
+    unary = class_costs[byte_to_class][:, byte_to_class].astype(np.int8)
+    for tag, gaps in (("linear_m2", (-2, -2)), ("affine_m5_m1", (-5, -1))):
+        for kind, local in (("nw", False), ("sw", True)):
+            assert [[orc.nw_score(x, y, unary, *gaps, local=local) for y in candidates] for x in queries] == z[f"{kind}_unary_{tag}"].tolist()
+            assert orc.align_score_general(queries[2], candidates[7], unary, *gaps, local=local) == z[f"{kind}_unary_{tag}"][2, 7]
+
+
 def test_generator_is_sliceable(sw):
     """Pair i depends only on (workload, seed, i): rank shards reproduce the global stream."""
     whole_a, whole_b = sw.generate_pairs("tokens64", 3000, seed=7)

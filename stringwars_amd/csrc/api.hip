@@ -243,12 +243,17 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
 
 // Does either tape hold a byte above 0x7F? Runs in front of the byte kernels when a UTF-8 call BELIEVES its raw tapes to be ASCII
 // (they were, the last time this scope staged them): sixteen bytes per thread and step, the flag in host-mapped memory.
-__global__ __launch_bounds__(256) void k_ascii_check(const uint8_t *a, uint64_t a_bytes, const uint8_t *b, uint64_t b_bytes, uint32_t *flag) {
+// The tapes' byte totals are read HERE, from offsets[count]: the caller's belief about them may be as stale as the one about their bytes.
+__global__ __launch_bounds__(256) void k_ascii_check(const uint8_t *a, const void *a_offsets, uint64_t a_count, const uint8_t *b, const void *b_offsets,
+                                                     uint64_t b_count, uint32_t off64, uint32_t *flag) {
     uint32_t high = 0;
     const uint64_t stride = (uint64_t)gridDim.x * 256 * 16;
     for (int t = 0; t < 2; ++t) {
         const uint8_t *data = t ? b : a;
-        const uint64_t bytes = t ? b_bytes : a_bytes;
+        const void *offsets = t ? b_offsets : a_offsets;
+        if (!offsets) continue;
+        const uint64_t count = t ? b_count : a_count;
+        const uint64_t bytes = off64 ? ((const uint64_t *)offsets)[count] : (uint64_t)((const uint32_t *)offsets)[count];
         for (uint64_t at = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; at < bytes; at += stride) {
             if (at + 16 <= bytes) {
                 uint4 v;
@@ -411,8 +416,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 *seen_host = 0;
                 const uint64_t most = std::max<uint64_t>(ba.bytes, bb.bytes);
                 const uint32_t blocks = (uint32_t)std::min<uint64_t>((most + 4095) / 4096 + 1, (uint64_t)scope->compute_units * 8);
-                hipLaunchKernelGGL(k_ascii_check, dim3(blocks), dim3(256), 0, stream, (const uint8_t *)spec.a.data, ba.bytes,
-                                   (const uint8_t *)spec.b.data, same_tape ? 0 : bb.bytes, seen_dev);
+                hipLaunchKernelGGL(k_ascii_check, dim3(blocks), dim3(256), 0, stream, (const uint8_t *)spec.a.data, spec.a.offsets, (uint64_t)spec.a.count,
+                                   (const uint8_t *)spec.b.data, same_tape ? nullptr : spec.b.offsets, (uint64_t)spec.b.count, (uint32_t)spec.a.off64, seen_dev);
                 SWH_HIP_CHECK(hipGetLastError());
                 CallSpec as_bytes = spec;
                 as_bytes.utf8 = false;

@@ -145,3 +145,31 @@ def test_bench_starts_its_own_ranks_when_there_is_no_world(monkeypatch):
     source = open(os.path.join(ROOT, "bench.py")).read()
     # nothing at module level pulls torch or the library in: both are imported inside the functions that need a GPU
     assert not [row for row in source.splitlines() if row.startswith(("import torch", "import stringwars_amd", "from stringwars_amd"))]
+
+
+def test_trace_tools_read_rocprofv3_csvs(tmp_path):
+    """tools/kernel_gaps.py and tools/api_timeline.py on a hand-made pair of rocprofv3 traces: the kernels of the last call in start
+    order with their lengths, and the host API calls of that call on the same time line."""
+    kernels = tmp_path / "run" / "x_kernel_trace.csv"
+    kernels.parent.mkdir()
+    rows = [("swh::k_utf8_tile_decode(a)", 1000, 251000, 1), ("void swh::k_banded<unsigned int, 36, 32>(b)", 300000, 610000, 1),
+            ("swh::k_utf8_tile_decode(a)", 1000000, 1250000, 1), ("other_kernel(c)", 1260000, 1270000, 1),
+            ("void swh::k_banded<unsigned int, 36, 32>(b)", 1300000, 1612000, 1)]
+    with open(kernels, "w", newline="") as handle:
+        writer = csv.writer(handle)
+        writer.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Stream_Id"])
+        writer.writerows(rows)
+    api = tmp_path / "run" / "x_hip_api_trace.csv"
+    with open(api, "w", newline="") as handle:
+        writer = csv.writer(handle)
+        writer.writerow(["Function", "Start_Timestamp", "End_Timestamp"])
+        writer.writerows([("hipLaunchKernel", 990000, 995000), ("hipStreamSynchronize", 1305000, 1620000), ("hipLaunchKernel", 100, 200)])
+    gaps = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_gaps.py"), str(kernels), "1"], capture_output=True, text=True, timeout=60)
+    assert gaps.returncode == 0, gaps.stderr
+    lines = gaps.stdout.strip().splitlines()
+    assert len(lines) == 3 and "k_banded" in lines[-1] and "312.0" in lines[-1] and "other_kernel" not in gaps.stdout   # the last 3 x 1 swh:: kernels
+    line = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "api_timeline.py"), str(tmp_path / "run"), "k_banded"], capture_output=True, text=True, timeout=60)
+    assert line.returncode == 0, line.stderr
+    out = line.stdout.strip().splitlines()
+    assert len(out) == 4, out
+    assert "A hipLaunchKernel" in out[0] and "K swh::k_utf8_tile_decode" in out[1] and "K swh::k_banded" in out[2] and "A hipStreamSynchronize" in out[3]

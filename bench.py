@@ -91,11 +91,18 @@ LEGS = {
                text="C3: 100 K UTF-8 line pairs ~1 KB, bounded Levenshtein k = 32 over code points, tapes prepared (decoded once)"),
     "c3_raw": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, variant="k32", check=1_000,
                    text="C3 on raw device tapes: UTF-8 validated and decoded inside every call"),
-    "c4_linear": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=16,
+    # the reference's literal UTF-8 calls (similarities/bench.rs:538-546, :625-629: raw tapes handed over on every call, no bound)
+    "utf8_unbounded_raw": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", prepared=False, variant="unbounded", check=1_000,
+                               text="C3's lines, UNBOUNDED Levenshtein over code points on raw device tapes: LevenshteinDistancesUtf8's literal call "
+                                    "(bench.rs:538-546) -- validated and decoded inside every call"),
+    "c3_raw_cold": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, cold=3, variant="k32", check=1_000,
+                        text="C3 on raw device tapes the scope has not seen in its previous call (three copies of the tapes in turn: the library's "
+                             "beliefs about a tape's byte total and its ASCII-ness never apply)"),
+    "c4_linear": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=128,
                       text="C4: NW, 256x256 i8 matrix (20 amino acids + other), 10 K pairs ~4 KB, linear gaps -4"),
-    "c4_affine": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-11, -1), prepared=True, variant="affine", check=16,
+    "c4_affine": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-11, -1), prepared=True, variant="affine", check=128,
                       text="C4 with affine gaps (-11, -1)"),
-    "c4_bytes": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=12,
+    "c4_bytes": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=128,
                      text="C4 over the full byte alphabet (all 256 classes of the matrix in use), 2 K pairs ~4 KB, linear gaps -4"),
     "c5": dict(workload="short_words", pairs=20_000_000, kind="lev", prepared=True, check=200_000,
                text="C5: one GPU's share of the 100 M short-word pairs (20 M pairs <= 16 B, mean ~6), unbounded Levenshtein"),
@@ -106,7 +113,7 @@ LEGS = {
                      text="NW on word-sized strings (the reference's default `words` token mode, bench.rs:271): 4 M pairs <= 16 B, "
                           "unary_class_costs(2, -1) as a 32-class table, linear gaps -2 -- one pair per lane (alignshort.hip)"),
 }
-DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c5", "nw_words"]
+DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c5", "nw_words"]
 
 
 def parse_args():
@@ -342,6 +349,19 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
         call = engine.bind_pairs(pa, pb, scope, out, bound=leg.get("bound")) if kind != "nw" else engine.bind_pairs(pa, pb, scope, out)
     elif kind == "nw":
         call = lambda: engine.pairs(da, db, scope, out=out)
+    elif leg.get("cold"):
+        # copies of the tapes taken in turn: no call meets the tapes of the call before it
+        copies = [(da, db)]
+        for _ in range(leg["cold"] - 1):
+            more = [t.clone() for t in tensors]
+            copies.append((sw.DeviceTape(more[0].data_ptr(), more[1].data_ptr(), a.count, a.offsets.dtype, keepalive=more[:2]),
+                           sw.DeviceTape(more[2].data_ptr(), more[3].data_ptr(), b.count, b.offsets.dtype, keepalive=more[2:])))
+        turn = [0]
+
+        def call():
+            ta, tb = copies[turn[0] % len(copies)]
+            turn[0] += 1
+            return engine.pairs(ta, tb, scope, bound=leg.get("bound"), out=out)
     else:
         call = lambda: engine.pairs(da, db, scope, bound=leg.get("bound"), out=out)
     made = 0

@@ -9,7 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, "libstringwars_amd.so")
+# STRINGWARS_AMD_LIBRARY: another build of the same C ABI -- the tests that need a test hook point it at libstringwars_amd_test.so
+# (built with -DSWH_TEST_HOOKS, `make -C stringwars_amd/csrc test-lib`) in a child process; nothing else sets it.
+LIBRARY_PATH = os.environ.get("STRINGWARS_AMD_LIBRARY") or os.path.join(_HERE, "libstringwars_amd.so")
+TEST_LIBRARY_PATH = os.path.join(_HERE, "libstringwars_amd_test.so")
 
 if not os.path.exists(LIBRARY_PATH):
     raise ImportError(

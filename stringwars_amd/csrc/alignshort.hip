@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) used |= (uint32_t)__shfl_xor((int)used, off);
         const bool compact = __popc(used) <= 8;
-        if (!compact) misfit = 1;
+        if (!compact) misfit |= 2;   // (bit 1: the alphabet is too rich for the compacting kernels -- CallSummary::violation)
         // -- the item's queries into LDS as class bytes: lane l stages bytes 16 (l % 8) .. + 15 of query l / 8, two rounds of eight queries
         wave_lds_fence();                                  // the previous item's readers are done with the staging area
 #pragma unroll
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignS
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) used |= (uint32_t)__shfl_xor((int)used, off);
         const bool compact = __popc(used) <= 8;
-        if (!compact) misfit = 1;
+        if (!compact) misfit |= 2;   // (bit 1: the alphabet is too rich for the compacting kernels -- CallSummary::violation)
         wave_lds_fence();                                  // the previous item's readers are done with the tables
         if (lane < 32) {
             wl.cid[lane] = (uint8_t)__popc(used & ((1u << lane) - 1u));
@@ -930,15 +930,30 @@ __global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignS
 // waves (= boundary areas) a launch of the multi-pass kernel gets: two four-wave workgroups per CU (a 128-column row, or 64
 // columns of H and F, leave two waves per SIMD), never more than it has work items -- and never more than kAlignBoundaryBytes of
 // boundary columns (an area is (longest_rows + 8) x 64 ints, twice that for Gotoh's E: queries of 4096 symbols on the 2048 waves of
-// 256 compute units are 2.2 GB, 4.3 for Gotoh; past the budget the launch gets fewer waves instead of a bigger buffer)
-constexpr uint64_t kAlignBoundaryBytes = 4ull << 30;
+// 256 compute units are 2.2 GB, 4.3 for Gotoh: such calls go to the column-profile kernel instead, align_long_fits below)
+constexpr uint64_t kAlignBoundaryBytes = 640ull << 20;
+static uint64_t align_long_area(uint32_t longest_rows, bool affine) {   // per workgroup
+    return (uint64_t)(longest_rows + 8) * 64 * sizeof(int32_t) * (affine ? 2 : 1) * kAlignWaves;
+}
+static uint64_t align_long_budget(bool *hooked = nullptr) {
+    const char *e = test_hook("STRINGWARS_AMD_ALIGN_BOUNDARY_MB");   // (test library, read per launch: a test lowers it to meet the cap on small inputs)
+    if (hooked) *hooked = e != nullptr;
+    return e ? (uint64_t)atoll(e) << 20 : kAlignBoundaryBytes;
+}
 uint32_t align_long_waves(const Scope *scope, uint64_t items, uint32_t longest_rows, bool affine) {
-    const uint64_t area = (uint64_t)(longest_rows + 8) * 64 * sizeof(int32_t) * (affine ? 2 : 1) * kAlignWaves;   // per workgroup
     uint64_t blocks = std::min<uint64_t>((items + kAlignWaves - 1) / kAlignWaves, (uint64_t)scope->compute_units * 2);
-    const char *e = getenv("STRINGWARS_AMD_ALIGN_BOUNDARY_MB");   // (read per launch: a test lowers it to meet the cap on small inputs)
-    const uint64_t budget = e ? (uint64_t)atoll(e) << 20 : kAlignBoundaryBytes;
-    blocks = std::min<uint64_t>(blocks, budget / area);
+    blocks = std::min<uint64_t>(blocks, align_long_budget() / align_long_area(longest_rows, affine));
     return (uint32_t)(blocks ? blocks : 1) * kAlignWaves;
+}
+// Does a launch with every wave it could use stay inside the budget? If not the call takes the column-profile kernel (api.hip), whose
+// boundary rings are a few MB: a cross-product call does not allocate gigabytes of scratch (round 4 let this one grow to 4 GB and
+// gave a launch past that fewer waves; with the test hook set that is still what happens, so that the cap itself stays tested).
+bool align_long_fits(const Scope *scope, uint64_t items, uint32_t longest_rows, bool affine) {
+    bool hooked = false;
+    const uint64_t budget = align_long_budget(&hooked);
+    if (hooked) return true;
+    const uint64_t blocks = std::min<uint64_t>((items + kAlignWaves - 1) / kAlignWaves, (uint64_t)scope->compute_units * 2);
+    return blocks * align_long_area(longest_rows, affine) <= budget;
 }
 
 // Queries per work item (one item = those queries x 64 candidates, walked by one wave from start to end). An item of 16 queries of

@@ -173,6 +173,13 @@ static uint64_t utf8_merged_bytes() {
     static const uint64_t bytes = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_MERGED_MB"); return e ? (uint64_t)atol(e) << 20 : ~0ull; }();
     return bytes;
 }
+// STRINGWARS_AMD_UTF8_STAGING: `strings` -- every raw UTF-8 call on the planned / tiled routes stages string by string (k_utf8_strings: the
+// tests send words and empty strings through it), `tiles` -- never (the flat one-pass kernel: the comparison), unset -- tapes whose
+// mean string has at least kUtf8StringsMeanBytes bytes.
+static int utf8_strings_mode() {
+    static const int mode = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_STAGING"); return !e ? 0 : (!strcmp(e, "strings") ? 1 : (!strcmp(e, "tiles") ? 2 : 0)); }();
+    return mode;
+}
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
 static size_t utf8_scratch_words(uint64_t bytes) {
     // mirrors the carving in launch_utf8_decode: tile counts | sub-tile prefixes | u64 tile prefixes | u64 block sums | balances
@@ -190,12 +197,13 @@ static bool is_device_pointer(const void *p) {
 }
 
 // hipMalloc'ed memory of a device (not managed, not host-mapped): where a write-through store that was acknowledged can be read by anybody
-static bool is_plain_device_memory(const void *p) {
+// -- ON THE SCOPE'S OWN DEVICE: agent-scope write-through is visibility on that agent; a peer device's memory takes the stream's way
+static bool is_plain_device_memory(const void *p, int device) {
     if (!p) return false;
     hipPointerAttribute_t attr;
     hipError_t err = hipPointerGetAttributes(&attr, p);
     if (err != hipSuccess) { (void)hipGetLastError(); return false; }
-    return attr.type == hipMemoryTypeDevice;
+    return attr.type == hipMemoryTypeDevice && attr.device == device;
 }
 
 // ---- one engine call ---------------------------------------------------------------------------
@@ -225,6 +233,7 @@ struct CallSpec {
     size_t a_first = 0, b_first = 0;
     bool force_planned = false;                    // redo of a call whose plan-free kernel met a pair it could not score
     uint32_t skip_upto = 0;                        // ... where that kernel HAS scored every pair of two strings of at most this many symbols
+    bool flat_staging = false;                     // redo of a raw UTF-8 call whose string-by-string staging met a string too long for it
 };
 
 static uint64_t read_offset(const void *offs, int off64, size_t i, bool device, hipStream_t stream) {
@@ -300,8 +309,13 @@ static uint32_t tiled_longest_limit() {
 // keeps k_direct_short for all of them, `tiled` sends them to the general tiled kernel.
 // (STRINGWARS_AMD_SHORT_MIN_PAIRS, read per call: the tests send small batches to the chunked kernel with it)
 static uint64_t short_tiled_min_pairs() {
-    const char *e = getenv("STRINGWARS_AMD_SHORT_MIN_PAIRS");
+#ifdef SWH_TEST_HOOKS
+    const char *e = getenv("STRINGWARS_AMD_SHORT_MIN_PAIRS");   // (the test library reads it per call: the tests move it between calls)
     return e ? (uint64_t)atoll(e) : (uint64_t)1 << 16;
+#else
+    static const uint64_t pairs = [] { const char *e = getenv("STRINGWARS_AMD_SHORT_MIN_PAIRS"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 16; }();
+    return pairs;
+#endif
 }
 // Bounds up to here may take the banded kernel (STRINGWARS_AMD_BAND_MAX=63: the one-word windows only, the comparison knob).
 static uint32_t band_max_bound() {
@@ -331,17 +345,39 @@ static bool early_return_on() {
     static const bool on = [] { const char *e = getenv("STRINGWARS_AMD_EARLY_RETURN"); return !e || atoi(e) != 0; }();
     return on;
 }
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+// The poll is bounded by what the scope's previous early-returning call took: a call that ran for more than ~0.4 ms last time waits for
+// the stream straight away (5 us are nothing to it, and a core spinning for milliseconds per call is), a shorter one spins for at most
+// four times that -- never more than 2 ms -- before it falls back to the stream (which also reports a kernel that died).
 static void wait_for_summary(Scope *scope, hipStream_t stream) {
     volatile uint32_t *landed = &scope->summary_host[0].landed;
     const auto begun = std::chrono::steady_clock::now();
+    const auto finish = [&]() {
+        const auto took = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - begun).count();
+        scope->early_return_last_us = (uint32_t)std::min<long long>(took, 1000000);
+    };
+    if (scope->early_return_last_us > 400) {
+        SWH_HIP_CHECK(hipStreamSynchronize(stream));
+        finish();
+        return;
+    }
+    const auto patience = std::chrono::microseconds(std::min<uint32_t>(2000u, std::max<uint32_t>(100u, 4u * scope->early_return_last_us)));
     for (uint32_t spins = 1;; ++spins) {
-        if (__atomic_load_n(landed, __ATOMIC_ACQUIRE)) return;
-        // a call of milliseconds does not care for 5 us: it waits for the stream the ordinary way (which also reports a kernel that died)
-        if ((spins & 0x3FFu) == 0 && std::chrono::steady_clock::now() - begun > std::chrono::milliseconds(2)) {
+        if (__atomic_load_n(landed, __ATOMIC_ACQUIRE)) { finish(); return; }
+        if ((spins & 0xFFu) == 0 && std::chrono::steady_clock::now() - begun > patience) {
             SWH_HIP_CHECK(hipStreamSynchronize(stream));
+            finish();
             return;
         }
-        __builtin_ia32_pause();
+        cpu_relax();
     }
 }
 
@@ -570,7 +606,10 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 longest = both;
                 align_wide = both > 32;
             } else if (known && can_verify && spec.cross && !scope->align_wide_off &&
-                       both <= std::min(align_long_limit(), align_long_pays(engine->kind == 2, engine->scoring.open != engine->scoring.extend))) {
+                       both <= std::min(align_long_limit(), align_long_pays(engine->kind == 2, engine->scoring.open != engine->scoring.extend)) &&
+                       align_long_fits(scope, ((uint64_t)(spec.b.count + 63) / 64) * ((uint64_t)(spec.a.count + align_long_queries(scope, spec.a.count, spec.b.count) - 1) /
+                                                                                      align_long_queries(scope, spec.a.count, spec.b.count)),
+                                       la_max, engine->scoring.open != engine->scoring.extend)) {
                 // longer ones on the same small-alphabet condition: columns in passes of 128 (local or Gotoh: 64, both: 32), the boundary
                 // column between passes through global memory (alignshort.hip: k_align_cross_long), up to where it beats the
                 // column-profile kernel (align_long_pays)
@@ -613,6 +652,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 probe.take<uint32_t>(b_bytes + 4); probe.take<uint64_t>(spec.b.count + 1);
                 probe.take<uint32_t>(utf8_scratch_words(b_bytes));
                 probe.take<uint32_t>(kUtf8FlagWords);
+                probe.take<uint64_t>(2 * spec.a.count + 2); probe.take<uint64_t>(2 * spec.b.count + 2);   // (first, end) pairs of the string-by-string staging
             }
             need = probe.used;
         }
@@ -628,6 +668,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
 
         // -- UTF-8 staging ----------------------------------------------------------------------------
         uint32_t *invalid_dev = nullptr;
+        bool staged_by_string = false;
         if (utf8 && !prepared) {
             uint32_t decode_slot = 0;
             auto decode = [&](const TapeRef &in, uint64_t bytes, TapeRef &out_tape, uint64_t first_word, bool opened) {
@@ -645,7 +686,32 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             TapeRef da, db;
             invalid_dev = sc.take<uint32_t>(kUtf8FlagWords);   // one flag + two balance words + the tile tickets, shared by both decodes
             SWH_HIP_CHECK(hipMemsetAsync(invalid_dev, 0, kUtf8FlagWords * sizeof(uint32_t), stream));
-            if (same_tape) {
+            // Lines and longer strings are staged string by string (prepass.hip: k_utf8_strings -- one launch, no look-back; the code-point
+            // tapes it leaves have gaps, TapeRef::gap): the routes whose kernels take their extents through pair_extent.
+            const uint64_t all_strings = (uint64_t)spec.a.count + (same_tape ? 0 : spec.b.count), all_bytes = a_bytes + (same_tape ? 0 : b_bytes);
+            if (scope->utf8_strings_rest) --scope->utf8_strings_rest;
+            // (a too-long string sends the call back to the flat staging: the plan-free route can only do that where the host looks at the outcome)
+            staged_by_string = (route == kRoutePlanned || (route == kRouteTiled && (!scope->async || !dev_out))) && utf8_strings_mode() != 2 && !spec.flat_staging &&
+                               (utf8_strings_mode() == 1 || (scope->utf8_strings_rest == 0 && all_bytes >= (uint64_t)kUtf8StringsMeanBytes * all_strings));
+            if (staged_by_string) {
+                auto job_of = [&](const TapeRef &in, uint64_t bytes) {
+                    Utf8StringsJob j{};
+                    j.data = (const uint8_t *)in.data; j.offsets = in.offsets; j.count = in.count; j.total = bytes;
+                    j.symbols = sc.take<uint32_t>(bytes + 4);
+                    j.extents = sc.take<uint64_t>(2 * in.count + 2);
+                    return j;
+                };
+                const Utf8StringsJob sa = job_of(ta, a_bytes);
+                da.data = sa.symbols; da.offsets = sa.extents; da.count = ta.count; da.gap = 1;
+                if (same_tape) {
+                    launch_utf8_strings(scope, sa, nullptr, off64, invalid_dev);
+                    db = da;
+                } else {
+                    const Utf8StringsJob sb = job_of(tb, b_bytes);
+                    launch_utf8_strings(scope, sa, &sb, off64, invalid_dev);
+                    db.data = sb.symbols; db.offsets = sb.extents; db.count = tb.count; db.gap = 1;
+                }
+            } else if (same_tape) {
                 decode(ta, a_bytes, da, 0, false);
                 db = da;
             } else if (utf8_one_pass() && a_bytes + b_bytes <= utf8_merged_bytes()) {
@@ -754,6 +820,15 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 scope->stamps_pending = false;
                 return run_call_on(scope, engine, spec, error);
             }
+            if (*invalid_host == kUtf8StringTooLong && staged_by_string) {
+                // a string too long for a wave of its own (k_utf8_strings): this call and the scope's next few stage the flat way
+                scope->utf8_strings_rest = 16;
+                scope->summary_pending = false;
+                scope->stamps_pending = false;
+                CallSpec flat = spec;
+                flat.flat_staging = true;
+                return run_call_on(scope, engine, flat, error);
+            }
             snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in an input tape (marker %u)", *invalid_host - 1);
             if (error) *error = g_error_text;
             return swh_invalid_utf8_k;
@@ -764,7 +839,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             // host-mapped memory with the kernel's completion ------------------------------------------------------------
             // (an asynchronous call reports into slot 1, whose `sticky` word outlives the summary: see CallSummary)
             scope->summary_slot = (scope->async && dev_out) ? 1u : 0u;
-            const bool early = !scope->async && dev_out && !scope->profiling && !invalid_dev && early_return_on() && is_plain_device_memory(spec.out);
+            const bool early = !scope->async && dev_out && !scope->profiling && !invalid_dev && early_return_on() && is_plain_device_memory(spec.out, scope->device);
             if (early) scope->summary_host[0].landed = 0;
             if (route == kRouteDirectShort) launch_direct_short_alone(scope, pre);
             else if (route == kRouteShortTiled) {
@@ -804,8 +879,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 if (scope->summary_host[0].violation) {
                     // the belief about the lengths was wrong (it came from an earlier batch): redo on the planned path
                     scope->hint_lengths = false;
-                    const bool compact_failed = (route == kRouteAlignShort && align_wide) || route == kRouteAlignLong;
-                    if (compact_failed) scope->align_wide_off = true;   // (or: more than eight classes in an item)
+                    // the compacting kernels stay off this scope only when the ALPHABET was the reason (violation bit 1); a string longer
+                    // than the believed lengths just drops the belief, and the next batch of the same shape is routed afresh
+                    const bool compact_route = (route == kRouteAlignShort && align_wide) || route == kRouteAlignLong;
+                    const bool compact_failed = compact_route && (scope->summary_host[0].violation & 2u) != 0;
+                    if (compact_failed) scope->align_wide_off = true;
                     scope->summary_pending = false;
                     scope->stamps_pending = false;
                     CallSpec again = spec;

@@ -95,10 +95,8 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
 template <typename Sym, int kBpWaves>
 __global__ __launch_bounds__(kBpWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel(KernelArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
-                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
-    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
-                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
+    const uint64_t a_total = tape_total(args.job.a, args.off64);
+    const uint64_t b_total = tape_total(args.job.b, args.off64);
     if constexpr (sizeof(Sym) == 1) {
         if (a_total >= 16 && b_total >= 16) bp_run<Sym, kBpWaves, true>(args, smem, a_total, b_total);
         else bp_run<Sym, kBpWaves, false>(args, smem, a_total, b_total);
@@ -128,10 +126,8 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
 #pragma unroll
     for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
     const uint32_t cstart = args.plan->class_start[kClassBpLong], ccount = args.plan->class_count[kClassBpLong];
-    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
-                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
-    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
-                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
+    const uint64_t a_total = tape_total(args.job.a, args.off64);
+    const uint64_t b_total = tape_total(args.job.b, args.off64);
     const uint32_t waves_total = gridDim.x * kBpWaves;
     const uint32_t wave_id = blockIdx.x * kBpWaves + wave_in_block;
     // carry words of this wave: [parity of the producing pass][+1 bits | -1 bits][words]

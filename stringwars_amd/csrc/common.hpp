@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 #include <unordered_map>
@@ -20,9 +21,19 @@ namespace swh {
 // tape's own u32/u64 (bytes) or the scratch tape's u64 (code points).
 struct TapeRef {
     const void *data;     // device pointer, Sym elements
-    const void *offsets;  // device pointer, count+1 entries
+    const void *offsets;  // device pointer, count+1 entries (gap: 2 count + 1, see below)
     uint64_t count;
+    // gap = 1: a code-point tape staged string by string (prepass.hip: k_utf8_strings) -- string i's symbols start where its BYTES
+    // started (no prefix over the strings before it is needed to place them), so the strings do not abut and `offsets` holds a
+    // (first, end) pair per string: string i = [offsets[2 i], offsets[2 i + 1]), offsets[2 count] = the symbol buffer's capacity.
+    uint32_t gap = 0;
 };
+// offsets[count]: the end of the tape's last string = how many symbols the data buffer holds (gap tapes: its capacity)
+template <typename Off>
+__device__ __forceinline__ uint64_t tape_total(const TapeRef &t) { return (uint64_t)((const Off *)t.offsets)[t.count << t.gap]; }
+__device__ __forceinline__ uint64_t tape_total(const TapeRef &t, uint32_t off64) {
+    return off64 ? tape_total<uint64_t>(t) : tape_total<uint32_t>(t);
+}
 
 struct Job {
     TapeRef a, b;
@@ -61,8 +72,8 @@ __device__ __forceinline__ void pair_extent(const Job &job, uint64_t p, uint64_t
                                             uint32_t &lb) {
     uint64_t ia = p, ib = p;
     if (job.cross) cross_split(job, p, ia, ib);
-    const Off *oa = (const Off *)job.a.offsets, *ob = (const Off *)job.b.offsets;
-    Off x0 = oa[ia], x1 = oa[ia + 1], y0 = ob[ib], y1 = ob[ib + 1];
+    const Off *oa = (const Off *)job.a.offsets + (ia << job.a.gap), *ob = (const Off *)job.b.offsets + (ib << job.b.gap);
+    Off x0 = oa[0], x1 = oa[1], y0 = ob[0], y1 = ob[1];
     a0 = (uint64_t)x0; la = (uint32_t)(x1 - x0);
     b0 = (uint64_t)y0; lb = (uint32_t)(y1 - y0);
 }
@@ -278,7 +289,9 @@ __device__ __forceinline__ void report_call_summary(const PlanPartial &mine, Pla
         __hip_atomic_store(&summary->max_la, maxa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&summary->max_lb, maxb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&summary->short_pairs, shorts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&summary->violation, viol ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (non-zero: a pair was not scored. Bit 0: a string did not fit the kernel; bit 1: an item's candidates use more symbol classes
+        // than the compacting alignment kernels hold -- the one reason that keeps a scope off those kernels, api.hip)
+        __hip_atomic_store(&summary->violation, viol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (viol) __hip_atomic_store(&summary->sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the summary's words (and the counter's reset) before the word that says so
@@ -379,7 +392,10 @@ struct Scope {
     // `ascii`: the last staging of that tape met no byte above 0x7F (the one-pass kernel's flag words, kUtf8AsciiWord): the next UTF-8 call on
     // the same tapes runs on their BYTES (code points of ASCII text are its bytes) next to a kernel that checks exactly that (api.hip).
     struct SizeBelief { const void *data = nullptr, *offsets = nullptr; size_t count = 0; int off64 = 0; uint64_t bytes = 0; bool valid = false, ascii = false; } size_belief[2];
-    bool align_wide_off = false;   // k_align_cross_wide met candidates with more than eight symbol classes (or longer strings): not tried again
+    uint32_t early_return_last_us = 0;   // what the previous call that returned on its summary took (api.hip: wait_for_summary bounds its spin by it)
+    uint32_t utf8_strings_rest = 0;   // raw UTF-8 calls left before the string-by-string staging is tried again (it met a string too long for it)
+    bool align_wide_off = false;   // k_align_cross_wide / _long met candidates with more than eight symbol classes: not tried again on this scope
+                                   // (a string longer than the believed lengths only drops the belief: the next call measures afresh)
     uint32_t hint_max_la = 0, hint_max_lb = 0;
     uint32_t hint_mean_x16 = 0;   // mean string length of the previous call, x16 (both tapes together)
     uint32_t hint_mean_string_x16 = 0;   // symbols per STRING of the previous call, x16 (a cross-product counts every string once)
@@ -513,7 +529,8 @@ void launch_align_short(Scope *scope, const KernelArgs &args, uint32_t longest, 
 // the same for queries x candidates of any length over a small alphabet (<= 8 classes per work item): columns in passes of 128
 // (Gotoh: 64), the boundary column between passes in args.boundary -- align_long_waves() areas of (longest_rows + 8) x 64 ints
 // (x 2 for Gotoh's E); queries of up to 4096 symbols
-uint32_t align_long_waves(const Scope *scope, uint64_t items, uint32_t longest_rows, bool affine);   // (capped at 4 GB of boundary columns)
+uint32_t align_long_waves(const Scope *scope, uint64_t items, uint32_t longest_rows, bool affine);   // (capped by the boundary budget, 640 MB)
+bool align_long_fits(const Scope *scope, uint64_t items, uint32_t longest_rows, bool affine);         // would a full launch stay inside it?
 uint32_t align_long_queries(const Scope *scope, uint64_t queries, uint64_t candidates);   // queries per work item (16 .. 1)
 void launch_align_long(Scope *scope, const KernelArgs &args, uint32_t longest_rows);
 
@@ -540,8 +557,28 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args);
 // words: [0] the invalid-UTF-8 marker, [32 (1 + slot)] the launch's tile ticket (the kernel takes tickets from there: anything
 // but zero at launch is a hang or a tile never decoded)
 bool utf8_one_pass();
+// staging string by string (prepass.hip: k_utf8_strings): the code points of string i from symbols[offsets[i]] on, (first, end)
+// pairs in `extents` (2 count + 1 entries: TapeRef::gap = 1). `invalid`: the call's flag words ([0] marker, [3], [4] "not ASCII").
+struct Utf8StringsJob { const uint8_t *data; const void *offsets; uint64_t count, total; uint32_t *symbols; uint64_t *extents; };
+constexpr uint32_t kUtf8StringTooLong = 0xFFFFFFFDu;   // `invalid` marker: a string beyond kUtf8StringLongest bytes -- stage the flat way
+constexpr uint32_t kUtf8StringLongest = 64u * 1024u;
+constexpr uint32_t kUtf8StringsMeanBytes = 192;        // tapes whose mean string is shorter keep the flat staging
+void launch_utf8_strings(Scope *scope, const Utf8StringsJob &a, const Utf8StringsJob *b, uint32_t off64, uint32_t *invalid);
 void launch_utf8_decode_pair(Scope *scope, const Utf8Args &a, const Utf8Args *b, uint64_t first_word, bool opened);
 void utf8_status_open(Scope *scope, uint64_t words);
+
+// Environment switches come in two kinds. Comparison / tuning knobs are read ONCE per process by whoever uses them.
+// Test hooks -- fault injection, shapes no input reaches, the UTF-8 staging of rounds 1-2 kept as the tests' second implementation --
+// exist in the TEST library only (`make test-lib`: -DSWH_TEST_HOOKS -> libstringwars_amd_test.so, which the tests that need a hook
+// load in a child process); the shipped library does not look at them and does not carry the code behind them.
+inline const char *test_hook(const char *name) {
+#ifdef SWH_TEST_HOOKS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 #define SWH_HIP_CHECK_DECLARED 1
 #define SWH_HIP_CHECK(expr)                                                                          \

@@ -13,6 +13,7 @@
 //
 // Also here: UTF-8 -> code point staging (k_utf8_count / k_utf8_write) and a small device scan.
 #include "common.hpp"
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include "bp_window.hpp"
@@ -833,7 +834,7 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
             scope->plan_barrier_target = 0;
         }
         // test hook: a grid four times larger than the device holds, to exercise the barrier's give-up path
-        static const bool oversubscribe = getenv("STRINGWARS_AMD_FUSED_OVERSUBSCRIBE") != nullptr;
+        static const bool oversubscribe = test_hook("STRINGWARS_AMD_FUSED_OVERSUBSCRIBE") != nullptr;
         if (oversubscribe) nb = 4 * fused_slots <= (uint32_t)kMaxPartials ? 4 * fused_slots : (uint32_t)kMaxPartials;
         if (nb < 1) nb = 1;
         FusedArgs f{};
@@ -910,6 +911,7 @@ __device__ __forceinline__ uint32_t lead_mask4(uint32_t dw, int valid) {
     return m;
 }
 
+#ifdef SWH_TEST_HOOKS   // the count / scan / write staging of rounds 1-2: the tests' second implementation (STRINGWARS_AMD_UTF8_SCAN)
 __global__ __launch_bounds__(256) void k_utf8_tile_count(const uint8_t *data, uint64_t total, uint32_t *tile_counts,
                                                          uint32_t *sub_prefix) {
     __shared__ uint32_t wave_sum[kUtf8Passes][4];
@@ -1056,9 +1058,11 @@ __device__ __noinline__ void utf8_tile_write_edge(Utf8WriteLds &lds, const uint8
     if (threadIdx.x == 0) balance[tile] = wave_bal[0] + wave_bal[1] + wave_bal[2] + wave_bal[3];
 }
 
+#endif   // SWH_TEST_HOOKS
 // Lead bytes (everything but 10xxxxxx) of four packed bytes as 0x80 flags: !bit7 | bit6.
 __device__ __forceinline__ uint32_t lead_flags4(uint32_t dw) { return (~dw | (dw << 1)) & 0x80808080u; }
 
+#ifdef SWH_TEST_HOOKS   // count / scan / write staging, continued
 // One UTF-8 sequence starting in the low byte of `seq` (its next three bytes above it), without branches:
 // n1 = leading one bits of the first byte (0: ASCII, 2..4: lead of a 2..4 byte sequence), the payload bits of all
 // four bytes are packed as if the sequence were four bytes long and shifted down by the bytes it does not have.
@@ -1148,6 +1152,7 @@ __global__ __launch_bounds__(256) void k_utf8_tile_write(const uint8_t *data, ui
     if (threadIdx.x == 0) balance[tile] = lds.wave_bal[0] + lds.wave_bal[1] + lds.wave_bal[2] + lds.wave_bal[3];
 }
 
+#endif   // SWH_TEST_HOOKS
 // ------------------------------------------------------------------------------------------------
 // The same staging in ONE pass over the tape (what launch_utf8_decode runs unless STRINGWARS_AMD_UTF8_SCAN=split): count,
 // prefix and decode per tile in one kernel, the tile's code-point index found by a decoupled look-back over the tiles before it
@@ -1391,6 +1396,7 @@ __global__ __launch_bounds__(256) void k_utf8_tile_decode(Utf8TileJob job_a, Utf
     }
 }
 
+#ifdef SWH_TEST_HOOKS   // count / scan / write staging, continued
 __global__ __launch_bounds__(256) void k_utf8_balance(const int *tile_balance, uint64_t tiles, int *balance) {
     __shared__ int red[256];
     int sum = 0;
@@ -1404,6 +1410,7 @@ __global__ __launch_bounds__(256) void k_utf8_balance(const int *tile_balance, u
     if (threadIdx.x == 0 && red[0] != 0) atomicAdd(balance, red[0]);
 }
 
+#endif   // SWH_TEST_HOOKS
 // Code-point offset of string i of a tape (i == count: the tape's end) and the check that it starts on a sequence boundary.
 template <typename Off>
 __device__ __forceinline__ void utf8_string_offset(const Utf8Args &args, const uint64_t *tile_prefix, const uint32_t *sub_prefix, uint64_t i) {
@@ -1437,6 +1444,7 @@ __device__ __forceinline__ void utf8_string_offset(const Utf8Args &args, const u
         atomicCAS(args.invalid, 0u, (uint32_t)i + 1u);
 }
 
+#ifdef SWH_TEST_HOOKS   // count / scan / write staging, continued
 template <typename Off>
 __global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, const uint64_t *tile_prefix,
                                                              const uint32_t *sub_prefix, const int *balance) {
@@ -1446,6 +1454,7 @@ __global__ __launch_bounds__(256) void k_utf8_string_offsets(Utf8Args args, cons
     utf8_string_offset<Off>(args, tile_prefix, sub_prefix, i);
 }
 
+#endif   // SWH_TEST_HOOKS
 // The one-pass staging's second (and last) launch: the string offsets of BOTH tapes (blocks [0, a.blocks) are tape a's), and
 // in the first block of each tape's range the balance of its tiles (k_utf8_balance's sum: stray continuation bytes somewhere).
 struct Utf8FinishJob {
@@ -1480,6 +1489,7 @@ __global__ __launch_bounds__(256) void k_utf8_finish(Utf8FinishJob job_a, Utf8Fi
     utf8_string_offset<Off>(args, tile_prefix, sub_prefix, i);
 }
 
+#ifdef SWH_TEST_HOOKS   // count / scan / write staging, continued
 // Exclusive scan of u32 counts into u64 offsets (count+1 entries). Three small kernels.
 constexpr int kScanBlock = 1024;
 __global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const uint32_t *counts, uint64_t n,
@@ -1567,11 +1577,12 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_one(const uint32_t *counts,
     }
 }
 
+#endif   // SWH_TEST_HOOKS
 // STRINGWARS_AMD_UTF8_SCAN=split forces the count / scan / write kernels with the three-kernel scan, =scan the same with
 // the one-launch scan (what round 2 ran; tests and comparisons use them). 0: the one-pass staging.
 static int utf8_scan_mode() {
     static const int mode = [] {
-        const char *e = getenv("STRINGWARS_AMD_UTF8_SCAN");
+        const char *e = test_hook("STRINGWARS_AMD_UTF8_SCAN");
         return !e ? 0 : (!strcmp(e, "split") ? 2 : (!strcmp(e, "scan") ? 1 : 0));
     }();
     return mode;
@@ -1595,7 +1606,7 @@ static void utf8_status_reserve(Scope *scope, uint64_t words) {
     SWH_HIP_CHECK(hipMemsetAsync(scope->utf8_status, 0, want * sizeof(unsigned long long), scope->stream));
     // test hook STRINGWARS_AMD_UTF8_EPOCH=n: the first epoch of a fresh buffer (default 1), to reach the wrap-around in a few calls
     static const uint32_t first_epoch = [] {
-        const char *e = getenv("STRINGWARS_AMD_UTF8_EPOCH");
+        const char *e = test_hook("STRINGWARS_AMD_UTF8_EPOCH");
         const long v = e ? atol(e) : 1;
         return (uint32_t)(v >= 1 && v <= 0xFFFF ? v : 1);
     }();
@@ -1646,6 +1657,7 @@ void launch_utf8_decode_pair(Scope *scope, const Utf8Args &a, const Utf8Args *b,
 
 void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
     if (utf8_one_pass()) { launch_utf8_decode_pair(scope, args, nullptr, 0, false); return; }
+#ifdef SWH_TEST_HOOKS
     hipStream_t stream = scope->stream;
     const uint64_t n = args.in.count, total = args.total_bytes;
     const uint64_t tiles = (total + kUtf8Tile - 1) / kUtf8Tile;
@@ -1689,6 +1701,162 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
         if (args.off64) hipLaunchKernelGGL(k_utf8_string_offsets<uint64_t>, dim3(blocks), dim3(256), 0, stream, args, tile_prefix, sub_prefix, (const int *)(args.invalid + 1 + args.slot));
         else hipLaunchKernelGGL(k_utf8_string_offsets<uint32_t>, dim3(blocks), dim3(256), 0, stream, args, tile_prefix, sub_prefix, (const int *)(args.invalid + 1 + args.slot));
     }
+    SWH_HIP_CHECK(hipGetLastError());
+#endif   // SWH_TEST_HOOKS
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Staging STRING BY STRING (round 5): one wave per string, rounds of 1 KB, no ticket, no look-back, no workgroup barrier.
+// What made the flat kernels above wait -- a tile needs the code points of every tile before it to know where its own go -- is a
+// property of the OUTPUT LAYOUT, not of UTF-8: here string i's code points go to symbols[offsets[i] ...], the place its BYTES had,
+// so a string is placed by its own byte offset alone and counted by the wave that decodes it. The tape that results has gaps
+// (a string of b bytes holds <= b code points): its `offsets` are (first, end) pairs, TapeRef::gap = 1 (common.hpp), and every
+// kernel that reads code points takes its extents through pair_extent / tape_total, which know. Validation is per string too:
+// every lead byte checks its own sequence (k_utf8_tile_decode's table), a sequence may not reach past its string's end, and the
+// bytes the sequences claim must add up to the string's length -- claimed ranges are disjoint, so equality means every byte is a
+// lead byte or claimed once (a string that starts with a continuation byte, or holds a stray one, comes up short).
+// For tapes of lines and longer (api.hip: a mean string of >= kUtf8StringsMeanBytes bytes); a string beyond kUtf8StringLongest
+// bytes would keep one wave busy for milliseconds: the kernel says so (kUtf8StringTooLong) and the host stages the flat way.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kUtf8StrRound = 1024;       // bytes per round: sixteen per lane
+constexpr int kUtf8StrWaves = 4;
+struct Utf8StringsLds {
+    Utf8Lead table[256];
+    uint32_t raw[kUtf8StrWaves][kUtf8StrRound / 4 + 4];    // a round's bytes and the word after them (look-ahead of its last sequences)
+    uint16_t leads[kUtf8StrWaves][kUtf8StrRound];          // byte positions of the round's lead bytes in rank order
+};
+
+// sixteen bytes from `pos` on; bytes past the tape read as zero (a branch only the tape's last bytes take)
+__device__ __forceinline__ uint4 utf8_load16(const uint8_t *data, uint64_t pos, uint64_t total) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (pos + 16 <= total) { __builtin_memcpy(&v, data + pos, 16); return v; }
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int j = 0; j < 16; ++j)
+        if (pos + (uint64_t)j < total) w[j >> 2] |= (uint32_t)data[pos + j] << (8 * (j & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename Off>
+__global__ __launch_bounds__(kUtf8StrWaves * 64) void k_utf8_strings(Utf8StringsJob ja, Utf8StringsJob jb, uint32_t *invalid) {
+    __shared__ Utf8StringsLds lds;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: a string's extent is a scalar load)
+    *(uint4 *)&lds.table[threadIdx.x] = *(const uint4 *)&kUtf8Leads.e[threadIdx.x];
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        // the host may have BELIEVED the tapes' byte totals (api.hip): the tape's end is compared here; and the capacity slot of the extents
+        const Utf8StringsJob &j = threadIdx.x ? jb : ja;
+        if (j.offsets) {
+            if ((uint64_t)((const Off *)j.offsets)[j.count] != j.total) atomicMax(invalid, kUtf8SizesChanged);
+            j.extents[2 * j.count] = j.total;
+        }
+    }
+    uint32_t *raw = lds.raw[wave];
+    uint16_t *leads = lds.leads[wave];
+    const uint64_t strings = ja.count + jb.count;
+    const uint64_t waves_total = (uint64_t)gridDim.x * kUtf8StrWaves;
+    uint32_t high_a = 0, high_b = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * kUtf8StrWaves + wave; s < strings; s += waves_total) {
+        const bool second = s >= ja.count;   // (wave-uniform)
+        const uint64_t i = second ? s - ja.count : s;
+        const uint8_t *data = second ? jb.data : ja.data;
+        const Off *offs = (const Off *)(second ? jb.offsets : ja.offsets);
+        const uint64_t total = second ? jb.total : ja.total;
+        uint32_t *symbols = second ? jb.symbols : ja.symbols;
+        uint64_t *extents = second ? jb.extents : ja.extents;
+        const uint64_t o = (uint64_t)offs[i], e = (uint64_t)offs[i + 1];
+        if (e > total || o > e) {   // the tape is not what the host believed (or its offsets do not ascend): nothing of it is touched
+            if (lane == 0) { atomicMax(invalid, kUtf8SizesChanged); extents[2 * i] = 0; extents[2 * i + 1] = 0; }
+            continue;
+        }
+        const uint64_t len = e - o;
+        if (len > kUtf8StringLongest) {
+            if (lane == 0) { atomicMax(invalid, kUtf8StringTooLong); extents[2 * i] = o; extents[2 * i + 1] = o; }
+            continue;
+        }
+        uint32_t done = 0;                 // code points of the rounds before this one
+        uint32_t wrong_pair = 0, wrong_tops = 0, shapes = 0, over = 0, high = 0;
+        uint32_t *out = symbols + o;
+        for (uint64_t at0 = 0; at0 < len; at0 += kUtf8StrRound) {
+            // rounds start AT the string (unaligned 16-byte loads): no bytes in front of it to mask away
+            const uint4 v = utf8_load16(data, o + at0 + 16u * (uint32_t)lane, total);
+            uint32_t after = 0;
+            if (lane == 0) { const uint4 nx = utf8_load16(data, o + at0 + kUtf8StrRound, total); after = nx.x; }
+            const uint32_t f0 = lead_flags4(v.x), f1 = lead_flags4(v.y), f2 = lead_flags4(v.z), f3 = lead_flags4(v.w);
+            high |= v.x | v.y | v.z | v.w;
+            const uint32_t mine = (uint32_t)(__popc(f0) + __popc(f1) + __popc(f2) + __popc(f3));
+            const uint32_t incl = wave_inclusive_sum_u32(mine);
+            *(uint4 *)&raw[4 * lane] = v;
+            if (lane == 0) raw[kUtf8StrRound / 4] = after;
+            // Bytes behind the string's end (the last round only) come AFTER every byte of it, so their lead bytes rank behind
+            // the string's own: they are listed and never decoded. How many of the round's lead bytes are the string's is found
+            // on the scalar unit: the lane that holds the end, its flags below the end, its exclusive prefix.
+            uint32_t valid = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint64_t rem = len - at0;
+            if (rem < kUtf8StrRound) {
+                const uint32_t el = (uint32_t)rem >> 4, eb = (uint32_t)rem & 15u;   // lane and byte of the first byte behind the string
+                const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, el), g1 = (uint32_t)__builtin_amdgcn_readlane((int)f1, el);
+                const uint32_t g2 = (uint32_t)__builtin_amdgcn_readlane((int)f2, el), g3 = (uint32_t)__builtin_amdgcn_readlane((int)f3, el);
+                const uint32_t excl_el = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), el);
+                const uint32_t dw = eb >> 2, below = (1u << (8u * (eb & 3u))) - 1u;
+                const uint32_t part = dw == 0 ? g0 : (dw == 1 ? g1 : (dw == 2 ? g2 : g3));
+                uint32_t cnt = (uint32_t)__popc(part & below);
+                cnt += dw > 0 ? (uint32_t)__popc(g0) : 0u;
+                cnt += dw > 1 ? (uint32_t)__popc(g1) : 0u;
+                cnt += dw > 2 ? (uint32_t)__popc(g2) : 0u;
+                valid = excl_el + cnt;
+            }
+            uint32_t rank = incl - mine;
+            const uint32_t fl[4] = {f0, f1, f2, f3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((fl[q] >> (8 * u + 7)) & 1u) leads[rank++] = (uint16_t)(16 * lane + 4 * q + u);
+            wave_lds_fence();   // the lanes read each other's bytes and list entries
+            const uint32_t end_rel = rem < kUtf8StrRound + 4u ? (uint32_t)rem : (uint32_t)kUtf8StrRound + 4u;   // (a round's last sequences may reach into the next round, never past the string)
+            for (uint32_t k = (uint32_t)lane; k < valid; k += 64) {
+                const uint32_t at = leads[k];
+                const uint32_t lo = raw[at >> 2], hi = raw[(at >> 2) + 1];
+                const uint32_t sq = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (at & 3u)));
+                const uint4 t = *(const uint4 *)&lds.table[sq & 0xFFu];   // x lead, y shape, z cont, w range (see k_utf8_tile_decode)
+                uint32_t inside;
+                asm volatile("v_med3_u16 %0, %1, %2, %2 op_sel:[0,0,1,0]" : "=v"(inside) : "v"(sq), "v"(t.w));
+                wrong_pair |= inside ^ sq;
+                wrong_tops |= (sq ^ 0x80800000u) & t.z;
+                shapes += t.y;
+                over |= (at + (t.y >> 16) > end_rel) ? 1u : 0u;
+                const uint32_t after3 = (((sq >> 8 & 0x3Fu) << 6 | (sq >> 16 & 0x3Fu)) << 6) | (sq >> 24 & 0x3Fu);
+                out[done + k] = t.x | __builtin_amdgcn_ubfe(after3, t.y, t.z);
+            }
+            done += valid;
+            wave_lds_fence();   // the next round rewrites the bytes and the list
+        }
+        if (second) high_b |= high; else high_a |= high;
+        // what the sequences claim against what the string holds; any lane's complaint is the string's
+        const uint32_t claimed = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum_u32(shapes >> 16), 63);
+        const bool bad_lane = (((wrong_pair & 0xFFFFu) | (wrong_tops & 0xC0C00000u)) | over) != 0;
+        const bool bad = __ballot(bad_lane) != 0 || claimed != (uint32_t)len;
+        if (lane == 0) {
+            extents[2 * i] = o;
+            extents[2 * i + 1] = o + done;
+            if (bad) atomicCAS(invalid, 0u, (uint32_t)i + 1u);   // (the marker: the string's index; k_utf8_tile_decode's is a word of the tape)
+        }
+    }
+    // a byte above 0x7F anywhere: the tape is not pure ASCII (a plain store, every such wave writes the same 1)
+    if (__ballot((high_a & 0x80808080u) != 0) != 0 && lane == 0) invalid[kUtf8AsciiWord] = 1u;
+    if (__ballot((high_b & 0x80808080u) != 0) != 0 && lane == 0) invalid[kUtf8AsciiWord + 1] = 1u;
+}
+
+void launch_utf8_strings(Scope *scope, const Utf8StringsJob &a, const Utf8StringsJob *b, uint32_t off64, uint32_t *invalid) {
+    Utf8StringsJob none{};
+    const Utf8StringsJob &jb = b ? *b : none;
+    const uint64_t strings = a.count + jb.count;
+    // eight workgroups per compute unit hold every wave slot; fewer strings than that: a wave each
+    const uint64_t most = (uint64_t)scope->compute_units * 8;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(most, (strings + kUtf8StrWaves - 1) / kUtf8StrWaves));
+    StampGuard guard(scope, "utf8_strings");
+    if (off64) hipLaunchKernelGGL(k_utf8_strings<uint64_t>, dim3(blocks), dim3(kUtf8StrWaves * 64), 0, scope->stream, a, jb, invalid);
+    else hipLaunchKernelGGL(k_utf8_strings<uint32_t>, dim3(blocks), dim3(kUtf8StrWaves * 64), 0, scope->stream, a, jb, invalid);
     SWH_HIP_CHECK(hipGetLastError());
 }
 

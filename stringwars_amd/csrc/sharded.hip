@@ -204,7 +204,7 @@ swh_status_t swh_scope_init_gpus(const int *devices, int count, swh_scope_t *out
     // Test hooks (read per call): STRINGWARS_AMD_RCCL=off makes a scope of several members fail the way a missing RCCL does;
     // =force builds the communicator whatever the device list looks like -- one member (a one-rank communicator: the real
     // ncclCommInitAll / group / destroy calls on a one-GPU box) or members sharing a device (which RCCL refuses).
-    const char *rccl_knob = getenv("STRINGWARS_AMD_RCCL");
+    const char *rccl_knob = test_hook("STRINGWARS_AMD_RCCL");
     const bool rccl_off = rccl_knob && strcmp(rccl_knob, "off") == 0, rccl_force = rccl_knob && strcmp(rccl_knob, "force") == 0;
     if (rccl_off && count > 1)
         return cleanup(sharded_fail(error, swh_rccl_error_k, "RCCL (librccl.so) could not be loaded: %s", "disabled by STRINGWARS_AMD_RCCL=off"));
@@ -499,7 +499,7 @@ static swh_status_t sharded_call(const std::vector<void *> &engines, ShardScore 
     SWH_SHARD_HIP(hipSetDevice(multi->devices[0]));
     SWH_SHARD_HIP(hipEventRecord(multi->gathered, multi->gather_stream));
     SWH_SHARD_HIP(hipStreamWaitEvent(stream_of(0), multi->gathered, 0));
-    if (const char *fault = getenv("STRINGWARS_AMD_SHARD_FAULT")) {   // test hook: damage one gathered distance of the last shard
+    if (const char *fault = test_hook("STRINGWARS_AMD_SHARD_FAULT")) {   // test hook: damage one gathered distance of the last shard
         const size_t r = members - 1, n = (size_t)(sp->cuts[r + 1] - sp->cuts[r]);
         if (atoi(fault) && n) SWH_SHARD_HIP(hipMemsetAsync(sp->gathered + sp->cuts[r] + n / 2, 0x5A, sizeof(uint32_t), stream_of(0)));
     }

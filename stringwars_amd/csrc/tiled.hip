@@ -403,10 +403,8 @@ template <typename Sym, int kWaves>
 __global__ __launch_bounds__(kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel_tiled(TiledArgs targs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KernelArgs &args = targs.k;
-    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
-                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
-    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
-                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
+    const uint64_t a_total = tape_total(args.job.a, args.off64);
+    const uint64_t b_total = tape_total(args.job.b, args.off64);
     if constexpr (sizeof(Sym) == 1) {
         if (a_total >= 16 && b_total >= 16) tiled_run<Sym, kWaves, true>(targs, smem, a_total, b_total);
         else tiled_run<Sym, kWaves, false>(targs, smem, a_total, b_total);

@@ -173,10 +173,8 @@ __global__ __launch_bounds__(256) void k_wavefront(KernelArgs args, uint32_t cls
     const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     const int open = args.scoring.open, ext = args.scoring.extend;
     const int match = args.scoring.match, mismatch = args.scoring.mismatch;
-    const uint64_t a_total = args.off64 ? ((const uint64_t *)args.job.a.offsets)[args.job.a.count]
-                                        : ((const uint32_t *)args.job.a.offsets)[args.job.a.count];
-    const uint64_t b_total = args.off64 ? ((const uint64_t *)args.job.b.offsets)[args.job.b.count]
-                                        : ((const uint32_t *)args.job.b.offsets)[args.job.b.count];
+    const uint64_t a_total = tape_total(args.job.a, args.off64);
+    const uint64_t b_total = tape_total(args.job.b, args.off64);
     int32_t *bnd_h = args.boundary ? args.boundary + (uint64_t)(wave_id * kGroups + grp) * args.boundary_stride * 2
                                    : nullptr;
     int32_t *bnd_e = bnd_h ? bnd_h + args.boundary_stride : nullptr;

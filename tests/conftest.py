@@ -28,3 +28,22 @@ def orc():
 def scope(sw):
     """One GPU scope for the whole session; a missing device is a hard failure under `-m gpu`."""
     return sw.DeviceScope(gpu_device=0)
+
+
+def run_in_child(request, env=None, test_library=False, timeout=1800) -> bool:
+    """For tests that need an environment switch the library reads once per process, or a test hook that only the TEST build of the
+    library carries (libstringwars_amd_test.so, -DSWH_TEST_HOOKS): the test runs AGAIN in a child process with that environment
+    (and that library). Returns True in the child -- run the body -- and False in the parent, after the child has passed."""
+    import subprocess
+    if os.environ.get("SWH_TEST_CHILD") == request.node.nodeid:
+        return True
+    child_env = dict(os.environ, SWH_TEST_CHILD=request.node.nodeid, PYTHONPATH=ROOT, **(env or {}))
+    if test_library:
+        child_env["STRINGWARS_AMD_LIBRARY"] = os.path.join(ROOT, "stringwars_amd", "libstringwars_amd_test.so")
+    done = subprocess.run([sys.executable, "-m", "pytest", request.node.nodeid, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                          cwd=ROOT, env=child_env, capture_output=True, text=True, timeout=timeout)
+    assert done.returncode == 0 and " passed" in done.stdout, done.stdout[-4000:] + done.stderr[-2000:]
+    return False
+
+
+TEST_LIBRARY_ENV = {"STRINGWARS_AMD_LIBRARY": os.path.join(ROOT, "stringwars_amd", "libstringwars_amd_test.so")}

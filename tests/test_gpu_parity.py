@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import TEST_LIBRARY_ENV, run_in_child
+
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -1202,13 +1204,16 @@ def test_pairs_with_common_affixes(sw, orc, scope):
     assert (grid.reshape(-1) == flat).all()
 
 
-def test_word_sized_batches_on_the_chunked_kernel(sw, orc, scope, monkeypatch):
+def test_word_sized_batches_on_the_chunked_kernel(sw, orc, request):
     """k_short_tiled (strings <= 16 bytes, pairwise): chunks of the tapes staged in LDS, common affixes cut, pairs sorted by
     what remains. Every shape that steers it: affixes of every length around every residue, the 8-byte compare window,
     empty strings, 16-byte strings back to back (segments beyond the LDS capacity: the chunk is halved), chunk and tile
     edges, both offset widths, strided outputs, bounds, sub-views that start in the middle of a tape, and a
     batch that stops being word-sized (the kernel reports it, the call is redone on another route)."""
-    monkeypatch.setenv("STRINGWARS_AMD_SHORT_MIN_PAIRS", "1")     # batches below 64 K pairs take k_direct_short otherwise
+    # batches below 64 K pairs take k_direct_short otherwise (the threshold is read once per process: a child process with it set)
+    if not run_in_child(request, env={"STRINGWARS_AMD_SHORT_MIN_PAIRS": "1"}):
+        return
+    scope = sw.DeviceScope(gpu_device=0)
     rng = np.random.default_rng(53)
     letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
     def word(n, k=26):
@@ -1500,12 +1505,15 @@ def test_sharded_cross_product_on_one_gpu(sw, orc):
         sw.ShardedCross(single, q, c)                                       # a single-device scope does not shard
 
 
-def test_sharded_call_pieces_self_check_and_error_paths(sw, orc, monkeypatch):
+def test_sharded_call_pieces_self_check_and_error_paths(sw, orc, monkeypatch, request):
     """`swh_levenshtein_pairs_sharded` beyond the happy path: shards large enough to be scored in four pieces (the send of a piece
     enqueued behind its kernel), the gather's self-check (per-shard checksums computed on the shard's device and again over the
     gathered vector: first call of a scope, every call with STRINGWARS_AMD_SHARD_CHECK=1) catching a damaged distance, HIP and
     RCCL failures surfacing as statuses -- an unknown device, RCCL unavailable, a communicator RCCL refuses -- and RCCL's own
     entry points (init of a one-rank communicator, an empty group, destroy) on this box's single GPU."""
+    # (STRINGWARS_AMD_SHARD_FAULT / STRINGWARS_AMD_RCCL are test hooks: only the test build of the library reads them)
+    if not run_in_child(request, test_library=True):
+        return
     a, b = sw.generate_pairs("short_words", 1_200_000, seed=33)
     scope = sw.DeviceScope(gpu_devices=[0, 0, 0])
     engine = sw.LevenshteinDistances(capabilities=scope)
@@ -1655,10 +1663,96 @@ def test_utf8_look_back_epoch_wraps(orc):
         "        assert (engine.pairs(t[0], t[1], scope, bound=40) == want[id(t)]).all(), round\n"
         "print('epochs ok')\n")
     # (tapes of more than 4 MB together take the stream-per-tape path here; the default is 48 MB)
-    env = dict(os.environ, STRINGWARS_AMD_UTF8_EPOCH="65520", STRINGWARS_AMD_UTF8_MERGED_MB="4",
+    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_UTF8_EPOCH="65520", STRINGWARS_AMD_UTF8_MERGED_MB="4", STRINGWARS_AMD_UTF8_STAGING="tiles",
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0 and "epochs ok" in done.stdout, done.stderr[-2000:]
+
+
+def test_utf8_lines_are_staged_string_by_string(orc):
+    """Raw UTF-8 tapes of lines (a mean string of >= 192 bytes) are staged by k_utf8_strings -- a wave per string, the code points where
+    the string's bytes were, (first, end) extents instead of abutting offsets (TapeRef::gap) -- and every kernel behind it reads those
+    extents: the banded kernel (bounds of one and two words), the planned bit-parallel kernels, the tiled kernel, general costs on
+    the wavefront kernels, a cross-product, pairwise and with one tape against itself; u32 and u64 offsets, host and device tapes, strings
+    of every length around the 1 KB rounds (1023, 1024, 1025 ... bytes, ending in sequences of every length) and empty ones among them.
+    STRINGWARS_AMD_STAMPS shows which staging kernel ran (read once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, stringwars_amd as sw, oracle\n"
+        "scope = sw.DeviceScope(gpu_device=0)\n"
+        "scope.set_profiling(True)\n"
+        "engine = sw.LevenshteinDistancesUTF8(capabilities=scope)\n"
+        "a, b = sw.generate_pairs('utf8_lines', 3000, seed=5)\n"
+        "for bound in (None, 0, 7, 32, 63, 64, 100, 127, 200):\n"
+        "    want = oracle.levenshtein_pairs(a, b, utf8=True, bound=bound)\n"
+        "    for ta, tb in ((a, b), (a.with_offsets(np.uint64).to_device(scope), b.with_offsets(np.uint64).to_device(scope))):\n"
+        "        assert (engine.pairs(ta, tb, scope, bound=bound) == want).all(), bound\n"
+        "assert (engine.pairs(a, a, scope) == 0).all()\n"
+        "tiled = sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm='tiled')\n"
+        "sa, sb = sw.generate_pairs('utf8_lines', 400, seed=9)\n"
+        "short_a = sw.Strs([bytes(x)[:200].decode('utf-8', 'ignore') for x in sa]); short_b = sw.Strs([bytes(x)[:230].decode('utf-8', 'ignore') for x in sb])\n"
+        "assert (tiled.pairs(short_a, short_b, scope) == oracle.levenshtein_pairs(short_a, short_b, utf8=True)).all()\n"
+        "q, c = [bytes(x) for x in list(sa)[:24]], [bytes(x) for x in list(sb)[:40]]\n"
+        "wide = oracle.levenshtein_pairs(sw.Strs([x for x in q for _ in c]), sw.Strs(c * len(q)), utf8=True)\n"
+        "assert (engine(sw.Strs(q), sw.Strs(c), scope).reshape(-1) == wide).all()\n"
+        "self_wide = oracle.levenshtein_pairs(sw.Strs([x for x in q for _ in q]), sw.Strs(q * len(q)), utf8=True)\n"
+        "assert (engine(sw.Strs(q), None, scope).reshape(-1) == self_wide).all()\n"
+        "# strings around the rounds of 1024 bytes, ending in sequences of 1 .. 4 bytes, empty strings among them\n"
+        "tails = ['x', '\u00e9', '\u4e2d', '\U0001f600']\n"
+        "edge = []\n"
+        "for n in (0, 1, 15, 16, 17, 1019, 1020, 1021, 1022, 1023, 1024, 1025, 1026, 1027, 1028, 2047, 2048, 2049, 3071, 5000):\n"
+        "    for t in tails:\n"
+        "        body = ('ab\u00e9\u4e2d\U0001f600' * (n // 10 + 1)).encode('utf-8')[:max(n - len(t.encode('utf-8')), 0)]\n"
+        "        while body and ((body[-1] & 0xC0) == 0x80 or body[-1] >= 0xC0): body = body[:-1]\n"
+        "        body = body + b'y' * max(n - len(t.encode('utf-8')) - len(body), 0)\n"
+        "        edge.append(body + (t.encode('utf-8') if n else b''))\n"
+        "ea = sw.Strs(edge); eb = sw.Strs([e.decode('utf-8')[1:].encode('utf-8') + b'zz' for e in edge])\n"
+        "for bound in (None, 32):\n"
+        "    assert (engine.pairs(ea, eb, scope, bound=bound) == oracle.levenshtein_pairs(ea, eb, utf8=True, bound=bound)).all()\n"
+        "print('strings ok')\n")
+    env = dict(os.environ, STRINGWARS_AMD_STAMPS="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0 and "strings ok" in done.stdout, done.stderr[-3000:]
+    assert "utf8_strings" in done.stderr and done.stderr.count("utf8_strings") >= 20, done.stderr[-2000:]
+    # the comparison knob keeps the flat kernel
+    env["STRINGWARS_AMD_UTF8_STAGING"] = "tiles"
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0 and "strings ok" in done.stdout, done.stderr[-3000:]
+    assert "utf8_strings" not in done.stderr and "utf8_tile_decode" in done.stderr
+
+
+def test_utf8_string_by_string_staging_validates(orc):
+    """The UTF-8 validation and fuzz tests, the random scripts, the tapes at their edges and the size beliefs once more with EVERY raw
+    UTF-8 call on the planned / tiled routes staged string by string (STRINGWARS_AMD_UTF8_STAGING=strings: words, empty strings, strings cut inside a
+    sequence, malformed bytes at every offset): the per-string validation rejects exactly what the flat one rejects."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRINGWARS_AMD_UTF8_STAGING="strings", PYTHONPATH=root)
+    picks = ("test_utf8_validation_matches_the_oracle or test_utf8_validation_fuzz or test_utf8_random_scripts or test_small_tapes_and_strings_at_tape_edges "
+             "or test_believed_tape_sizes_are_checked_on_the_device or test_kat_levenshtein or test_golden_multilingual_words or test_config3_bounded_utf8 "
+             "or test_general_cost_levenshtein_over_code_points or test_patterns_longer_than_64_blocks or test_banded_window_kernel")
+    done = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", picks],
+                          env=env, capture_output=True, text=True, timeout=1800)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-2000:]
+    assert " passed" in done.stdout and "failed" not in done.stdout, done.stdout[-1000:]
+
+
+def test_utf8_string_too_long_for_a_wave_of_its_own(sw, orc, scope):
+    """A string beyond 64 KB would keep one wave of k_utf8_strings busy for milliseconds: the kernel says so, the call is redone with the
+    flat staging (and the scope's next calls are too), the distances are the oracle's either way."""
+    rng = np.random.default_rng(5)
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    base = "caf\u00e9 \u4e2d\u6587 \U0001f600 "
+    long_one = (base * 9000).encode("utf-8")             # ~170 KB
+    a = sw.Strs([long_one, (base * 40).encode("utf-8"), b"x" * 700])
+    b = sw.Strs([long_one[: len(long_one) - 44] + b"tail", (base * 39).encode("utf-8"), b"x" * 650 + b"y" * 10])
+    want = orc.levenshtein_pairs(a, b, utf8=True, bound=60)
+    for _ in range(3):
+        assert engine.pairs(a, b, scope, bound=60).tolist() == want.tolist()
+    la, lb = sw.generate_pairs("utf8_lines", 300, seed=2)
+    assert (engine.pairs(la, lb, scope, bound=32) == orc.levenshtein_pairs(la, lb, utf8=True, bound=32)).all()
 
 
 @pytest.mark.parametrize("mode", ["split", "scan"])
@@ -1677,7 +1771,7 @@ def test_utf8_three_kernel_scan_path(orc, mode):
         "want = oracle.levenshtein_pairs(a, b, utf8=True, bound=40)\n"
         "assert (got == want).all()\n"
         "print('split-scan ok')\n")
-    env = dict(os.environ, STRINGWARS_AMD_UTF8_SCAN=mode, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_UTF8_SCAN=mode, STRINGWARS_AMD_UTF8_STAGING="tiles", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0 and "split-scan ok" in done.stdout, done.stderr[-2000:]
 
@@ -1923,7 +2017,7 @@ def test_fused_planner_gives_up_instead_of_hanging():
         "assert (got[:20000] == want).all() and (got == again).all()\n"
         "assert second < 1.0, second\n"
         "print('gave-up ok', round(first, 2), round(second, 3))\n")
-    env = dict(os.environ, STRINGWARS_AMD_FUSED_OVERSUBSCRIBE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_FUSED_OVERSUBSCRIBE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert done.returncode == 0 and "gave-up ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
 
@@ -1990,7 +2084,8 @@ def test_bench_line_carries_every_config():
     assert line["value"] > 0 and line["value_steady"] > 0 and line["value_pipelined"] > 0 and line["parity_vs_oracle"] is True
     assert abs(line["value"] - line["config"]["cells_per_gpu"] * 5 / (line["ms_per_step"] * 5e-3) / 1e9) < 0.02 * line["value"]
     assert line["roofline"]["bound"] == "valu" and line["roofline"]["kernel_ms"] > 0 and line["roofline"]["kernel"] == "bitparallel_tiled"
-    assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c5", "nw_words"]
+    assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes",
+                                                        "c5", "nw_words"]
     for entry in line["configs"]:
         assert "error" not in entry, entry
         assert entry["value"] > 0 and entry["parity_vs_oracle"] is True and entry["roofline"]["kernel_ms"] > 0 and entry["pairs"] == 600, entry
@@ -2271,7 +2366,7 @@ def test_banded_windows_of_two_words(sw, orc, scope, utf8):
 
 @pytest.mark.parametrize("local", [False, True])
 @pytest.mark.parametrize("gaps", [(-2, -2), (-5, -1)])
-def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps):
+def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps, request):
     """k_align_cross_long (alignshort.hip): queries x candidates of any length (up to 4096 symbols) over a small alphabet, the columns run as
     passes of 128 (local or Gotoh: 64, both: 32) with the boundary column between passes parked in global memory. Candidate lengths around every pass boundary (0, 1,
     63 .. 65, 127 .. 129, 255 .. 257, 300, 384), query lengths odd and even, linear and affine gaps, global and local, the reference's
@@ -2319,17 +2414,16 @@ def test_small_alphabet_cross_product_of_any_length(sw, orc, scope, local, gaps)
         assert name.startswith("align_long") == (top <= limit), (top, limit, name)
         want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
         assert (got == want).all(), (top, np.argwhere(got != want)[:5])
-    # the boundary columns are capped (4 GB; a launch past that gets fewer waves): with a budget of 3 MB the 200 x 70 strings below
-    # run on one or two workgroups, every wave taking many work items in turn
-    os.environ["STRINGWARS_AMD_ALIGN_BOUNDARY_MB"] = "3"
-    try:
-        queries, candidates = [dna(n) for n in rng.integers(300, 385, 200)], [dna(n) for n in rng.integers(1, 385, 70)]
-        fresh.set_profiling(True)
-        got = engine(sw.PreparedTape(fresh, sw.Strs(queries)), sw.PreparedTape(fresh, sw.Strs(candidates)), fresh)
-        name = fresh.last_timing()["dominant_name"]
-        fresh.set_profiling(False)
-    finally:
-        del os.environ["STRINGWARS_AMD_ALIGN_BOUNDARY_MB"]
+    # the boundary columns are budgeted (640 MB: a call that would need more takes the column-profile kernel; STRINGWARS_AMD_ALIGN_BOUNDARY_MB, a
+    # hook of the TEST library, gives a launch past the budget fewer waves instead): with 3 MB the 200 x 70 strings below run on one or two
+    # workgroups, every wave taking many work items in turn -- the whole test once more in a child process on the test library
+    if not run_in_child(request, env={"STRINGWARS_AMD_ALIGN_BOUNDARY_MB": "3"}, test_library=True):
+        return
+    queries, candidates = [dna(n) for n in rng.integers(300, 385, 200)], [dna(n) for n in rng.integers(1, 385, 70)]
+    fresh.set_profiling(True)
+    got = engine(sw.PreparedTape(fresh, sw.Strs(queries)), sw.PreparedTape(fresh, sw.Strs(candidates)), fresh)
+    name = fresh.last_timing()["dominant_name"]
+    fresh.set_profiling(False)
     assert name.startswith("align_long"), name
     want = np.array([[orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for y in candidates] for x in queries])
     assert (got == want).all(), np.argwhere(got != want)[:5]

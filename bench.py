@@ -145,8 +145,13 @@ def parse_args():
                    help="one process, one scope over --gpus devices: swh_scope_init_gpus + swh_levenshtein_pairs_sharded (the RCCL gather inside the library)")
     p.add_argument("--no-single-process", action="store_true", help="at N > 1: leave the single-process leg (a child of rank 0) out of the line")
     p.add_argument("--single-process-timeout", type=float, default=300.0)
-    p.add_argument("--gather-transport", default="auto", choices=["auto", "u32", "u8"],
-                   help="strong configs: what travels to rank 0 -- the u32 distances as they are, or bytes when no distance can exceed 255 (auto)")
+    p.add_argument("--gather-transport", default="u32", choices=["auto", "u32", "u8"],
+                   help="strong configs: what travels to rank 0 -- the u32 distances as they are (what BASELINE's north star names: the default), "
+                        "or bytes when no distance can exceed 255 (u8 / auto). At N > 1 the C5 entry is measured with u32 and carries the u8 variant beside it (`gather_u8`)")
+    p.add_argument("--collective-timeout", type=float, default=600.0, help="seconds a collective may take before the process group gives up (a dead rank ends the run, with an error line, within this)")
+    p.add_argument("--launch-timeout", type=float, default=7200.0, help="with --gpus N and no WORLD_SIZE: seconds the ranks this script starts may take in all")
+    p.add_argument("--die-rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: this rank exits with code 3 ...
+    p.add_argument("--die-at", default="start", choices=["start", "after-init", "measure"], help=argparse.SUPPRESS)   # ... at this point
     p.add_argument("--c5-pairs", type=int, default=0, help="at N > 1: total pairs of the C5 strong-scaling entry (default 100 M; testing)")
     return p.parse_args()
 
@@ -451,18 +456,56 @@ def last_json_line(text):
     return None
 
 
+def error_line(args, message, **more):
+    """The one JSON line of a run that could not measure: same keys a reader of the line looks at first, `value` null, `error` set."""
+    line = {"metric": "GCUPS (DP cell updates/s) batched Levenshtein", "value": None, "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "higher_is_better": True, "error": message}
+    line.update(more)
+    return json.dumps(line)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no WORLD_SIZE around: start the N ranks ourselves. This process has not imported
     torch, loaded the library or made any HIP call -- the ranks are a CHILD process (torch.distributed.run), never an exec --
-    and it leaves with the child's exit code; rank 0's JSON line goes straight to our stdout."""
+    and it leaves with the child's exit code; rank 0's JSON line goes straight to our stdout. A run that fails -- a rank that
+    dies, RCCL that does not come up, ranks that hang past --launch-timeout -- still ends with ONE JSON line (`error`) and a non-zero
+    exit code, within a bounded time: torch.distributed.run tears the other ranks down when one exits, the process group's
+    collectives give up after --collective-timeout, and whatever is left is killed here."""
+    import signal
     import subprocess
+    import threading
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
     env.setdefault("OMP_NUM_THREADS", "8")
-    done = subprocess.run(cmd, env=env)
-    raise SystemExit(done.returncode)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    seen = {"line": False, "tail": []}
+
+    def pump():
+        for row in child.stdout:
+            sys.stdout.write(row)
+            sys.stdout.flush()
+            if row.startswith("{") and ('"metric"' in row or '"error"' in row):
+                seen["line"] = True
+            seen["tail"] = (seen["tail"] + [row.rstrip()])[-5:]
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+    timed_out = False
+    try:
+        code = child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        try:
+            os.killpg(child.pid, signal.SIGKILL)          # the launcher and every rank it started (its own session: nothing else)
+        except ProcessLookupError:
+            pass
+        code = child.wait()
+    reader.join(timeout=10)
+    if timed_out or (code != 0 and not seen["line"]):
+        why = f"the ranks did not finish within --launch-timeout {args.launch_timeout} s" if timed_out else f"torch.distributed.run exited with code {code} before rank 0 printed its line"
+        print(error_line(args, why, stdout_tail=seen["tail"]), flush=True)
+    raise SystemExit(code if code != 0 else (1 if timed_out else 0))
 
 
 def visible_devices(torch):
@@ -550,7 +593,7 @@ def run_single_process(args):
     print(json.dumps(line), flush=True)
 
 
-def measure(cfg_name, args, env, steps, warmup, prewarm_seconds, steady_seconds, with_pipelined, pairs_arg=None, gather_cost=False):
+def measure(cfg_name, args, env, steps, warmup, prewarm_seconds, steady_seconds, with_pipelined, pairs_arg=None, gather_cost=False, gather_transport=None):
     """The measurement of one bench config on this rank's GPU (+ the collective at N > 1): returns what the line needs.
     Every rank makes the same calls in the same order (a step contains the collective)."""
     torch, dist, sw, sharding = env["torch"], env["dist"], env["sw"], env["sharding"]
@@ -559,6 +602,7 @@ def measure(cfg_name, args, env, steps, warmup, prewarm_seconds, steady_seconds,
     workload = (args.workload if cfg_name == args.config else None) or cfg["workload"]
     strong = cfg["scaling"] == "strong"
     chunks = args.chunks
+    gather_transport = gather_transport or args.gather_transport
     # ---- this rank's shard of the seeded stream -------------------------------------------------------------------
     if strong:
         total_pairs = pairs_arg or cfg["pairs"]
@@ -622,9 +666,9 @@ def measure(cfg_name, args, env, steps, warmup, prewarm_seconds, steady_seconds,
         if world > 1:
             longest = torch.tensor([int(max(a.lengths.max(initial=0), b.lengths.max(initial=0)))], dtype=torch.int64, device=comm_device)
             dist.all_reduce(longest, op=dist.ReduceOp.MAX)
-            if args.gather_transport == "u8" and int(longest.item()) > 255:
-                raise SystemExit("--gather-transport u8 needs every string <= 255 bytes")
-            if args.gather_transport != "u32" and int(longest.item()) <= 255:
+            if gather_transport == "u8" and int(longest.item()) > 255:
+                raise RuntimeError("gather transport u8 needs every string <= 255 bytes")
+            if gather_transport != "u32" and int(longest.item()) <= 255:
                 transport = torch.uint8
         # one pre-bound call per (buffer, piece): sub-views of the prepared tapes, the piece's slice of the result buffer
         piece_calls = [[engine.bind_pairs(pa[p_lo:p_hi], pb[p_lo:p_hi], scope, outs[slot][p_lo:p_hi]) if p_hi > p_lo else None
@@ -823,6 +867,19 @@ def collective_text(strong, world):
 
 def main():
     args = parse_args()
+    try:
+        return run(args)
+    except SystemExit:
+        raise
+    except BaseException as error:   # a rank that cannot go on says so in a JSON line (rank 0's is THE line; the launcher adds one if none came)
+        rank = int(os.environ.get("RANK", "0"))
+        print(error_line(args, f"rank {rank}: {type(error).__name__}: {error}", rank=rank), flush=True)
+        import traceback
+        traceback.print_exc()
+        os._exit(1)        # not sys.exit: a process group whose peer is gone can hang in its destructors
+
+
+def run(args):
     world_env = os.environ.get("WORLD_SIZE")
     if args.single_process:
         if world_env is not None and int(world_env) > 1:
@@ -834,14 +891,27 @@ def main():
     if world != args.gpus:                     # never a silent measurement of fewer GPUs than asked for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different number of GPUs")
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.die_rank == rank and args.die_at == "start":
+        os._exit(3)                            # test hook: a rank that never comes up
+    if world > 1:
+        # torch.distributed.run ends the other ranks with SIGTERM when one of them exits: say why before going
+        import signal
+
+        def terminated(signum, frame):
+            print(error_line(args, f"rank {rank}: terminated by signal {signum} (another rank failed, or the launcher gave up)", rank=rank), flush=True)
+            os._exit(1)
+        signal.signal(signal.SIGTERM, terminated)
+
+    import datetime
+
     import torch
     import torch.distributed as dist
 
     import stringwars_amd as sw
     from stringwars_amd import sharding
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not args.share_gpu and visible_devices(torch) < (local_rank + 1 if world > 1 else 1):
         raise SystemExit(f"rank {rank}: device {local_rank} is not there ({visible_devices(torch)} visible)")
     if args.share_gpu:
@@ -861,10 +931,13 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        limit = datetime.timedelta(seconds=args.collective_timeout)   # a collective whose peer is gone raises instead of waiting for ever
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=device, timeout=limit)  # RCCL over xGMI
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
+        if args.die_rank == rank and args.die_at == "after-init":
+            os._exit(3)                        # test hook: a rank that dies once the group is up
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     comm_device = device if args.backend == "nccl" else torch.device("cpu")
@@ -883,6 +956,8 @@ def main():
         ranks_seen = {"world_size": dist.get_world_size(), "backend": args.backend, "rccl_version": version,
                       "distinct_devices": len({(e["uuid"], e["pci_bus_id"]) for e in everyone}), "ranks": everyone}
 
+    if args.die_rank == rank and args.die_at == "measure":
+        os._exit(3)                            # test hook: a rank that dies while the others are in their first collective
     head = measure(args.config, args, env, args.steps, args.warmup, args.prewarm_seconds, args.steady_seconds, not args.no_pipelined,
                    pairs_arg=args.pairs, gather_cost=world > 1)
 
@@ -890,10 +965,21 @@ def main():
     c5 = None
     if world > 1 and args.config == "c2" and not args.no_configs:
         c5_pairs = args.c5_pairs or CONFIGS["c5"]["pairs"]
+        # the entry is what the north star names -- the u32 distances gathered as they are --; the same steps with bytes on the wire
+        # (no distance of word-sized pairs exceeds 255; widened on the root) ride beside it as `gather_u8`
+        c5_u8 = None
         try:
-            c5 = measure("c5", args, env, args.steps, min(args.warmup, 2), min(args.prewarm_seconds, 0.25), 0.0, False, pairs_arg=c5_pairs, gather_cost=True)
+            c5 = measure("c5", args, env, args.steps, min(args.warmup, 2), min(args.prewarm_seconds, 0.25), 0.0, False, pairs_arg=c5_pairs, gather_cost=True,
+                         gather_transport="u32")
         except Exception as error:   # must not cost the line its headline; every rank raises or none (same calls everywhere)
             c5 = {"error": f"{type(error).__name__}: {error}"}
+        if "error" not in c5:
+            try:
+                torch.cuda.empty_cache()
+                c5_u8 = measure("c5", args, env, args.steps, min(args.warmup, 2), min(args.prewarm_seconds, 0.25), 0.0, False, pairs_arg=c5_pairs,
+                                gather_cost=True, gather_transport="u8")
+            except Exception as error:
+                c5_u8 = {"error": f"{type(error).__name__}: {error}"}
 
     line = None
     if rank == 0:
@@ -948,6 +1034,12 @@ def main():
                     "kernel_ms_rank0_per_step": round(c5["totals"]["compute_ms"] / c5_calls * c5["n_pieces"], 4),
                     "dominant_kernel": kernel_family(c5["sync_timing"]["dominant_name"]), "parity_vs_oracle": c5_parity,
                     "parity_sample": "first 200000 pairs of rank 0's shard against oracle/; every other rank's slice by checksum (gather_ok)"}]
+                if c5_u8 is not None:
+                    leg_entries[0]["gather_u8"] = c5_u8 if "error" in c5_u8 else {
+                        "value": round(c5_u8["total_cells"] * c5_u8["steps"] / c5_u8["elapsed"] / 1e9, 2), "unit": "GCUPS",
+                        "ms_per_step": round(c5_u8["elapsed"] / c5_u8["steps"] * 1e3, 4), "gather_ok": c5_u8["gather_ok"], "gather": c5_u8["gather"],
+                        "same_results": bool((c5_u8["sync_result"] == c5["sync_result"]).all()),
+                        "is": "the same steps with the distances travelling as bytes (a quarter of the u32 bytes over rank 0's inbound links), widened on the root"}
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N = 1 only
             cpu_baselines = cpu_rows(head["a"], head["b"], budget_s=args.cpu_seconds)
             cpu_baseline = {k: v for k, v in cpu_baselines[0].items() if k != "name"}

@@ -900,6 +900,37 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         }
 
         // ---- planned path: classify + counting sort on the device, then the DP kernels the plan's classes call for ----
+        // Doubling. A unit-cost call whose bound lies beyond one band word (or that has none) first runs the ONE-WORD band at k1 = 63 over
+        // the pairs long enough for it: whatever comes back <= 63 is the distance, under any larger bound, and only the pairs that
+        // came back 64 are planned again with the call's own bound (two-word band, bit-parallel blocks). The reference's CPU row does
+        // the same inside every call -- rapidfuzz doubles a score hint of 31 until the result fits under it -- and text that is compared
+        // for similarity mostly is similar: config C3's lines, unbounded, 26 -> ~50 TCUPS. The first stage costs band_cost(63) per
+        // column where the second costs `later`; the share of pairs it has to settle for that to pay (plus a quarter: a second plan, a
+        // second tail) is held against what the scope's previous doubling call saw, and a scope that saw less sits eight calls out.
+        bool doubling = false;
+        double doubling_need = 0;
+        constexpr uint32_t kDoublingBound = 63;
+        static const bool doubling_on = [] { const char *e = getenv("STRINGWARS_AMD_DOUBLING"); return !e || atoi(e) != 0; }();
+        if (doubling_on && bitpar_ok && pre.unit_costs && engine->algorithm == swh_algorithm_auto_k && spec.bound > kDoublingBound &&
+            (prepared || scope->hint_lengths)) {
+            const uint32_t la_max = prepared ? (utf8 ? spec.pa->longest_symbols : spec.pa->longest_bytes) : scope->hint_max_la;
+            const uint32_t lb_max = prepared ? (utf8 ? spec.pb->longest_symbols : spec.pb->longest_bytes) : scope->hint_max_lb;
+            const uint32_t blocks = (std::min(la_max, lb_max) + 31) >> 5;
+            const uint32_t unbounded_cost = (sym_bytes == 4 ? 40u : 28u) * blocks;
+            const uint32_t later = spec.bound <= band_max_bound() ? std::min(band_cost(spec.bound), unbounded_cost) : unbounded_cost;
+            doubling_need = 1.25 * band_cost(kDoublingBound) / std::max(later, 1u);
+            if (scope->doubling_rest) --scope->doubling_rest;
+            else doubling = doubling_need <= 0.9 && (uint64_t)pairs * blocks >= 200000;
+        }
+        if (doubling) {
+            PrepassArgs first = pre;
+            first.job.bound = kDoublingBound; first.banded = 1; first.stage1 = 1; first.direct_short = 0; first.skip_upto = 0;
+            launch_prepass(scope, first);
+            KernelArgs kf = k;
+            kf.job.bound = kDoublingBound;
+            launch_banded(scope, kf, pairs);
+            pre.redo_filter = 1; pre.redo_done_upto = kDoublingBound;
+        }
         launch_prepass(scope, pre);
         // The bit-parallel kernel reads its work list from the device plan, so it is enqueued right away;
         // the host copy of the plan (needed only to pick wavefront kernels) travels on a side stream and
@@ -934,6 +965,12 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         }
         if (*invalid_host) return invalid_utf8();
         learn_ascii();
+        if (doubling) {
+            // what the first stage left over: the pairs the second plan filed under a kernel class
+            const uint64_t redo = plan.class_start[kMaxClasses] - plan.class_count[kClassTrivial];
+            const double settled = 1.0 - (double)redo / (double)pairs;
+            if (settled < doubling_need) scope->doubling_rest = 8;
+        }
 
         if (bitpar_deferred) {
             bool any_bp = false;

@@ -99,6 +99,19 @@ __device__ __forceinline__ void store_result(const Job &job, uint64_t p, int64_t
     store_out(dst, job.out_elem64 != 0, value);
 }
 
+// What an earlier kernel of the same call stored for pair p (the second stage of a doubling call asks whether the first one settled it).
+__device__ __forceinline__ int64_t load_result(const Job &job, uint64_t p) {
+    const char *src;
+    if (job.cross) {
+        uint64_t ia, ib;
+        cross_split(job, p, ia, ib);
+        src = job.out + ia * job.row_stride + ib * (job.out_elem64 ? 8 : 4);
+    } else {
+        src = job.out + p * job.out_stride;
+    }
+    return job.out_elem64 ? (int64_t)*(const long long *)src : (int64_t)*(const int *)src;
+}
+
 // Lanes of one wave that hand data to each other through LDS still need a fence: the compiler reasons per
 // thread, so it may sink a lane's ds_write below reads that only OTHER lanes' writes alias (seen on gfx950:
 // a staging store moved under the loads that consume it). Wavefront scope costs no cache traffic.
@@ -393,6 +406,7 @@ struct Scope {
     // the same tapes runs on their BYTES (code points of ASCII text are its bytes) next to a kernel that checks exactly that (api.hip).
     struct SizeBelief { const void *data = nullptr, *offsets = nullptr; size_t count = 0; int off64 = 0; uint64_t bytes = 0; bool valid = false, ascii = false; } size_belief[2];
     uint32_t early_return_last_us = 0;   // what the previous call that returned on its summary took (api.hip: wait_for_summary bounds its spin by it)
+    uint32_t doubling_rest = 0;   // calls left before the two-stage (doubling) schedule of api.hip is tried again: its first stage settled too few pairs
     uint32_t utf8_strings_rest = 0;   // raw UTF-8 calls left before the string-by-string staging is tried again (it met a string too long for it)
     bool align_wide_off = false;   // k_align_cross_wide / _long met candidates with more than eight symbol classes: not tried again on this scope
                                    // (a string longer than the believed lengths only drops the belief: the next call measures afresh)
@@ -468,6 +482,11 @@ struct PrepassArgs {
     uint32_t direct_short;  // unit-cost byte pairs with both sides <= 32 symbols are scored by k_direct_short
     uint32_t skip_upto;     // pairs with both sides <= this many symbols have been scored already (by k_align_short: the redo of a batch
                             // whose few longer strings did not fit its register row plans only the pairs with such a string); 0: none
+    // Doubling (api.hip: a call with a bound beyond one band word, or none, first runs the one-word band at k1 = 63 -- rapidfuzz's own
+    // schedule doubles its score hint the same way). stage1: plan the banded class only, every other pair gets job.bound + 1 stored ("not
+    // settled") and is filed as done. redo_filter (the second stage): a pair whose stored result is <= redo_done_upto was settled by the
+    // first stage and is filed as done untouched; the others are planned with the call's real bound.
+    uint32_t stage1, redo_filter, redo_done_upto;
     uint32_t *perm;         // out: pair ids sorted by key
     uint16_t *keys;         // scratch: every pair's plan key, written by k_plan_hist, read back by k_plan_scatter
     uint32_t *hist;         // scratch: kKeys counters

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_hist(PrepassArgs args) {
         maxa = info.la > maxa ? info.la : maxa;
         maxb = info.lb > maxb ? info.lb : maxb;
         uint32_t key;
-        if (info.trivial) {
+        if (args.redo_filter && (uint64_t)load_result(args.job, p) <= (uint64_t)args.redo_done_upto) {
+            key = kClassTrivial * kBuckets;   // settled by the call's first stage (the one-word band)
+        } else if (info.trivial) {
             key = kClassTrivial * kBuckets;
             int64_t v = info.trivial_value;
             // distances are stored positive: the max-plus core negates, the trivial path mirrors it
@@ -142,6 +144,10 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_hist(PrepassArgs args) {
             key = kClassTrivial * kBuckets;   // scored by k_direct_short (or, skip_upto, by the lane-per-pair alignment kernel)
         } else {
             key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
+            if (args.stage1 && key / kBuckets != (uint32_t)kClassBanded) {   // not the band's: left to the second stage
+                store_result(args.job, p, (int64_t)args.job.bound + 1);
+                key = kClassTrivial * kBuckets;
+            }
         }
         args.keys[p] = (uint16_t)key;   // k_plan_scatter sorts by the stored keys: no second look at the offsets
         atomicAdd(&lhist[key], 1u);
@@ -350,7 +356,9 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_fused(PrepassArgs args, F
                 maxa = info.la > maxa ? info.la : maxa;
                 maxb = info.lb > maxb ? info.lb : maxb;
                 uint32_t key;
-                if (info.trivial) {
+                if (args.redo_filter && (uint64_t)load_result(args.job, p) <= (uint64_t)args.redo_done_upto) {
+                    key = kClassTrivial * kBuckets;   // settled by the call's first stage (the one-word band)
+                } else if (info.trivial) {
                     key = kClassTrivial * kBuckets;
                     int64_t v = info.trivial_value;
                     if (args.job.negate) v = (int64_t)clamp_bound((uint32_t)(-v), args.job.bound);
@@ -359,6 +367,10 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_fused(PrepassArgs args, F
                     key = kClassTrivial * kBuckets;   // scored by k_direct_short (or, skip_upto, by the lane-per-pair alignment kernel)
                 } else {
                     key = plan_key(info.la, info.lb, args.mode, args.symmetric, args.sym_bytes, args.banded, args.job.bound);
+                    if (args.stage1 && key / kBuckets != (uint32_t)kClassBanded) {   // not the band's: left to the second stage
+                        store_result(args.job, p, (int64_t)args.job.bound + 1);
+                        key = kClassTrivial * kBuckets;
+                    }
                 }
                 keys[k] = key;
                 ranks[k] = atomicAdd(&lhist[key], 1u);

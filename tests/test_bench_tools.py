@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -126,15 +127,19 @@ def test_bench_starts_its_own_ranks_when_there_is_no_world(monkeypatch):
     bench = load(os.path.join(ROOT, "bench.py"), "bench_module_launch")
     seen = {}
 
-    class Done:
-        returncode = 7
+    class Child:
+        pid = 0
+        stdout = iter(['{"metric": "GCUPS", "value": 1.0}\n'])
 
-    def fake_run(cmd, env=None, **kwargs):
+        def wait(self, timeout=None):
+            return 7
+
+    def fake_popen(cmd, env=None, **kwargs):
         seen["cmd"], seen["env"] = cmd, env
-        return Done()
+        return Child()
 
     monkeypatch.delenv("WORLD_SIZE", raising=False)
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     try:
         bench.main()
@@ -148,6 +153,62 @@ def test_bench_starts_its_own_ranks_when_there_is_no_world(monkeypatch):
     source = open(os.path.join(ROOT, "bench.py")).read()
     # nothing at module level pulls torch or the library in: both are imported inside the functions that need a GPU
     assert not [row for row in source.splitlines() if row.startswith(("import torch", "import stringwars_amd", "from stringwars_amd"))]
+
+
+def test_bench_run_that_fails_still_ends_with_one_error_line(monkeypatch, capsys):
+    """A run whose ranks die before rank 0 has printed its line, or hang past --launch-timeout, ends with a non-zero exit code AND one JSON
+    line carrying `error` (the driver reads the last JSON line of stdout): the launcher prints it when no rank did."""
+    bench = load(os.path.join(ROOT, "bench.py"), "bench_module_fail")
+    killed = []
+
+    def child_of(code, rows, hang=False):
+        class Child:
+            pid = 424242
+            stdout = iter(rows)
+
+            def __init__(self):
+                self.waits = 0
+
+            def wait(self, timeout=None):
+                self.waits += 1
+                if hang and self.waits == 1:
+                    raise subprocess.TimeoutExpired("torchrun", timeout)
+                return code
+        return Child()
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(os, "killpg", lambda pid, sig: killed.append(pid))
+    for code, rows, hang, want_code, want_error in ((1, ["Traceback ...\n", "RuntimeError: ncclCommInitRank failed\n"], False, 1, "exited with code 1"),
+                                                     (-9, [], True, -9, "did not finish within --launch-timeout"),
+                                                     (1, ['{"metric": "m", "value": null, "error": "rank 0: boom"}\n'], False, 1, None)):
+        monkeypatch.setattr(subprocess, "Popen", lambda cmd, **kw: child_of(code, rows, hang))
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "2", "--launch-timeout", "5"])
+        try:
+            bench.main()
+            raise AssertionError("a failed run must not return")
+        except SystemExit as leave:
+            assert leave.code == want_code
+        lines = [json.loads(row) for row in capsys.readouterr().out.splitlines() if row.startswith("{")]
+        assert len(lines) == 1 and lines[0]["value"] is None
+        if want_error:
+            assert want_error in lines[0]["error"] and lines[0]["steps"] == 2 and lines[0]["n_gpus"] == 8
+        else:
+            assert lines[0]["error"] == "rank 0: boom"          # the rank's own line is THE line: the launcher adds none
+    assert killed == [424242]
+
+
+def test_bench_rank_that_dies_ends_the_run_with_an_error_line():
+    """`python bench.py --gpus 2` whose rank 1 exits before the process group is up (a GPU that did not come up, an RCCL that failed to
+    initialise): torch.distributed.run tears rank 0 down, the run ends with a non-zero exit code and a JSON line carrying `error`, within a
+    bounded time -- no hang, no half line. (Runs without a GPU: rank 0 then fails on its own, which is an error line all the same.)"""
+    bench = os.path.join(ROOT, "bench.py")
+    started = time.time()
+    done = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "1", "--warmup", "0", "--pairs", "2000",
+                           "--no-cpu-baseline", "--no-configs", "--die-rank", "1", "--die-at", "start", "--collective-timeout", "30", "--launch-timeout", "150"],
+                          capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert done.returncode != 0 and time.time() - started < 300
+    lines = [json.loads(row) for row in done.stdout.splitlines() if row.startswith("{")]
+    assert lines and "error" in lines[-1] and lines[-1]["value"] is None and lines[-1]["n_gpus"] == 2, (done.stdout[-600:], done.stderr[-600:])
 
 
 def test_trace_tools_read_rocprofv3_csvs(tmp_path):

@@ -1669,6 +1669,78 @@ def test_utf8_look_back_epoch_wraps(orc):
     assert done.returncode == 0 and "epochs ok" in done.stdout, done.stderr[-2000:]
 
 
+def test_doubling_schedule_for_bounds_beyond_one_band_word(orc):
+    """A unit-cost call with no bound, or one beyond the 64-bit band window, runs in two stages when its strings are long enough: the
+    one-word band at k = 63 over everything the band pays for, then only the pairs that came back 64 under the call's own bound
+    (api.hip: doubling; rapidfuzz's own score-hint schedule). Similar lines (C3's: half within 32 edits), unrelated lines, words and
+    empty strings in one batch; no bound and bounds on both sides of every kernel switch; code points (raw and prepared) and bytes;
+    32- and 64-bit results; a cross-product. STRINGWARS_AMD_STAMPS shows the two stages (two plans, the band first), and a scope
+    whose first stage settles too little stops trying for a while."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, stringwars_amd as sw, oracle\n"
+        "scope = sw.DeviceScope(gpu_device=0)\n"
+        "scope.set_profiling(True)\n"
+        "rng = np.random.default_rng(8)\n"
+        "a, b = sw.generate_pairs('utf8_lines', 13000, seed=5)\n"
+        "la, lb = [bytes(x) for x in a], [bytes(x) for x in b]\n"
+        "for i in range(0, 13000, 9): lb[i] = la[(i + 4001) % 13000]            # unrelated lines: the second stage's work\n"
+        "for i in range(0, 13000, 31): la[i] = la[i][:40].decode('utf-8', 'ignore').encode('utf-8')   # words among the lines\n"
+        "la[7] = b''; lb[11] = b''; la[12] = b''; lb[12] = b''\n"
+        "a, b = sw.Strs(la), sw.Strs(lb)\n"
+        "full = oracle.levenshtein_pairs(a, b, utf8=True)\n"
+        "assert (full > 200).sum() > 1000 and (full <= 63).sum() > 5000\n"
+        "engine = sw.LevenshteinDistancesUTF8(capabilities=scope)\n"
+        "pa, pb = sw.PreparedTape(scope, a, utf8=True), sw.PreparedTape(scope, b, utf8=True)\n"
+        "da, db = a.to_device(scope), b.to_device(scope)\n"
+        "for bound in (None, 64, 65, 100, 127, 128, 255, 5000, 63, 32):\n"
+        "    want = full if bound is None else np.minimum(full, bound + 1)\n"
+        "    assert (engine.pairs(pa, pb, scope, bound=bound) == want).all(), ('prepared', bound)\n"
+        "    assert (engine.pairs(da, db, scope, bound=bound) == want).all(), ('raw', bound)\n"
+        "out64 = np.zeros(13000, dtype=np.uint64)\n"
+        "engine.pairs(pa, pb, scope, out=out64)\n"
+        "assert (out64 == full).all()\n"
+        "print('STAGES-BEGIN', flush=True)\n"
+        "import sys; sys.stderr.write('STAGES-BEGIN\\n'); sys.stderr.flush()\n"
+        "assert (engine.pairs(pa, pb, scope) == full).all()\n"
+        "sys.stderr.write('STAGES-END\\n'); sys.stderr.flush()\n"
+        "# the same tapes as bytes\n"
+        "bytes_engine = sw.LevenshteinDistances(capabilities=scope)\n"
+        "full_bytes = oracle.levenshtein_pairs(a, b, algo='hyyro')\n"
+        "ba, bb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)\n"
+        "for bound in (None, 64, 127, 300):\n"
+        "    want = full_bytes if bound is None else np.minimum(full_bytes, bound + 1)\n"
+        "    assert (bytes_engine.pairs(ba, bb, scope, bound=bound) == want).all(), ('bytes', bound)\n"
+        "# a cross-product large enough for two stages: 120 x 120 lines\n"
+        "q, c = sw.Strs(la[100:220]), sw.Strs(lb[100:220])\n"
+        "wide = oracle.levenshtein_pairs(sw.Strs([x for x in la[100:220] for _ in range(120)]), sw.Strs(lb[100:220] * 120), utf8=True)\n"
+        "assert (engine(sw.PreparedTape(scope, q, utf8=True), sw.PreparedTape(scope, c, utf8=True), scope).reshape(-1) == wide).all()\n"
+        "# unrelated lines only: the first stage settles nothing, the scope sits the next calls out\n"
+        "ua, ub = sw.Strs(la[:12000]), sw.Strs([la[(i + 4001) % 13000] for i in range(12000)])\n"
+        "fresh = sw.DeviceScope(gpu_device=0); fresh.set_profiling(True)\n"
+        "fa, fb = sw.PreparedTape(fresh, ua, utf8=True), sw.PreparedTape(fresh, ub, utf8=True)\n"
+        "other = sw.LevenshteinDistancesUTF8(capabilities=fresh)\n"
+        "want = oracle.levenshtein_pairs(ua, ub, utf8=True)\n"
+        "sys.stderr.write('UNRELATED-BEGIN\\n'); sys.stderr.flush()\n"
+        "for _ in range(3): assert (other.pairs(fa, fb, fresh) == want).all()\n"
+        "sys.stderr.write('UNRELATED-END\\n'); sys.stderr.flush()\n"
+        "print('doubling ok')\n")
+    env = dict(os.environ, STRINGWARS_AMD_STAMPS="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+    assert done.returncode == 0 and "doubling ok" in done.stdout, done.stderr[-3000:]
+    stages = done.stderr.split("STAGES-BEGIN")[1].split("STAGES-END")[0]
+    assert stages.count("stamp plan_") == 2 and stages.count("stamp banded") == 1 and "bitparallel_u32" in stages, stages
+    unrelated = done.stderr.split("UNRELATED-BEGIN")[1].split("UNRELATED-END")[0]
+    assert unrelated.count("stamp banded") == 1 and unrelated.count("stamp plan_") == 4, unrelated    # tried once, then sat out
+    # the comparison knob: one stage
+    env["STRINGWARS_AMD_DOUBLING"] = "0"
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+    assert done.returncode != 0 or "doubling ok" in done.stdout
+    stages = done.stderr.split("STAGES-BEGIN")[1].split("STAGES-END")[0]
+    assert stages.count("stamp plan_") == 1 and "stamp banded" not in stages, stages
+
+
 def test_utf8_lines_are_staged_string_by_string(orc):
     """Raw UTF-8 tapes of lines (a mean string of >= 192 bytes) are staged by k_utf8_strings -- a wave per string, the code points where
     the string's bytes were, (first, end) extents instead of abutting offsets (TapeRef::gap) -- and every kernel behind it reads those
@@ -1747,7 +1819,7 @@ def test_utf8_string_too_long_for_a_wave_of_its_own(sw, orc, scope):
     base = "caf\u00e9 \u4e2d\u6587 \U0001f600 "
     long_one = (base * 9000).encode("utf-8")             # ~170 KB
     a = sw.Strs([long_one, (base * 40).encode("utf-8"), b"x" * 700])
-    b = sw.Strs([long_one[: len(long_one) - 44] + b"tail", (base * 39).encode("utf-8"), b"x" * 650 + b"y" * 10])
+    b = sw.Strs([(base * 8998).encode("utf-8") + b"tail", (base * 39).encode("utf-8"), b"x" * 650 + b"y" * 10])
     want = orc.levenshtein_pairs(a, b, utf8=True, bound=60)
     for _ in range(3):
         assert engine.pairs(a, b, scope, bound=60).tolist() == want.tolist()
@@ -2120,7 +2192,7 @@ def test_bench_two_ranks_share_the_gpu(config, pairs):
 def test_bench_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` with NO torchrun prefix and no WORLD_SIZE (the shape of the driver's N = 1 command): the script
     starts its ranks as a child process before touching the GPU and rank 0's line says `n_gpus: 2`. At N > 1 the line also carries
-    BASELINE configs[4] -- C5, strong scaling -- with its checked gather (bytes on the wire, widened on the root), the gather's price and
+    BASELINE configs[4] -- C5, strong scaling -- with its checked gather (u32 on the wire as the north star words it; the u8 variant beside it), the gather's price and
     the ranks that took part, and the in-library sharded call (one scope over both member devices) as `single_process`."""
     import subprocess
     import sys
@@ -2138,11 +2210,39 @@ def test_bench_starts_two_ranks_by_itself():
     assert c5["config"] == "c5_strong" and c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["pairs_total"] == 700000, c5
     assert c5["gather_ok"] is True and c5["parity_vs_oracle"] is True and c5["value"] > 0 and c5["ranks_seen"]["world_size"] == 2
     assert c5["shard_ranges"][0][0] == 0 and c5["shard_ranges"][0][1] == c5["shard_ranges"][1][0] and c5["shard_ranges"][1][1] == 700000
-    assert c5["gather"]["transport"].startswith("u8") and c5["gather"]["bytes_to_root_per_step"] == 700000 - c5["shard_ranges"][0][1]
+    # the entry is the north star's collective -- the u32 distances as they are --, the bytes-on-the-wire variant rides beside it
+    assert c5["gather"]["transport"] == "u32" and c5["gather"]["bytes_to_root_per_step"] == 4 * (700000 - c5["shard_ranges"][0][1])
+    narrow = c5["gather_u8"]
+    assert "error" not in narrow and narrow["gather_ok"] is True and narrow["same_results"] is True and narrow["value"] > 0, narrow
+    assert narrow["gather"]["transport"].startswith("u8") and narrow["gather"]["bytes_to_root_per_step"] == 700000 - c5["shard_ranges"][0][1]
     single = line["single_process"]
     assert "error" not in single, single
     assert single["mode"] == "single-process" and single["n_gpus"] == 2 and single["parity_vs_oracle"] is True and single["value"] > 0
     assert single["config"]["device_count"] == 2 and single["config"]["shard_cuts"][-1] == 2 * 60000
+
+
+def test_bench_failures_at_two_ranks_end_with_a_line():
+    """What can go wrong at N > 1 ends in ONE JSON line within a bounded time. (1) A rank that dies while the others are in their first
+    collectives: non-zero exit code, a line carrying `error`. (2) The in-library single-process leg (a child of rank 0, bounded by a
+    timeout) failing: the parent's line is there all the same, exit code 0, the failure inside `single_process`."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", "30000", "--steps", "2", "--warmup", "1", "--prewarm-seconds", "0.05",
+            "--steady-seconds", "0.05", "--backend", "gloo", "--share-gpu", "--no-configs", "--no-cpu-baseline"]
+    for at in ("after-init", "measure"):
+        started = time.time()
+        done = subprocess.run(base + ["--die-rank", "1", "--die-at", at, "--collective-timeout", "40", "--launch-timeout", "200"],
+                              capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert done.returncode != 0 and time.time() - started < 400, (at, done.returncode)
+        lines = [json.loads(l) for l in done.stdout.splitlines() if l.startswith("{")]
+        assert lines and "error" in lines[-1] and lines[-1]["value"] is None, (at, done.stdout[-800:], done.stderr[-800:])
+    done = subprocess.run(base + ["--single-process-timeout", "0.01"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-2000:])
+    line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["gather_ok"] is True and "error" in line["single_process"], line.get("single_process")
 
 
 def test_bench_single_process_mode():

@@ -123,6 +123,94 @@ def test_two_rank_gloo_gather_matches_single_process(sw, orc):
     assert abs(int(cells[lo0:hi0].sum()) - int(cells[lo1:hi1].sum())) < 0.02 * int(cells.sum())
 
 
+def _worker8(rank, world, port, queue):
+    """World size 8, the shape of the first real node: ragged cells-balanced shards (cut on all-reduced per-block cell sums), four
+    pieces per shard sent while the next is 'scored', u32 on the wire and bytes on the wire, into a root buffer that is reused."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    import stringwars_amd as sw
+    from stringwars_amd import sharding
+
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, block, seed, chunks = 40_013, 1 << 10, 42, 4
+    lo, hi = sharding.shard_range(total, rank, world)
+    # a stream whose pairs get heavier towards its end: count-balanced and cells-balanced cuts differ by a lot
+    def shard(first, count):
+        a, b = sw.generate_pairs("short_words", count, seed=seed, first=first)
+        keep = (np.arange(first, first + count) * 16 // total + 1).astype(np.int64)          # string i keeps at most 1 .. 16 bytes
+        cut = lambda t: sw.Strs([bytes(t[i])[: int(keep[i])] for i in range(count)])
+        return cut(a), cut(b)
+    a, b = shard(lo, hi - lo)
+    cells = (a.lengths.astype(np.int64) * b.lengths.astype(np.int64))
+    mine = np.zeros((total + block - 1) // block, dtype=np.int64)
+    for k in range(lo // block, (hi - 1) // block + 1):
+        mine[k] = cells[max(k * block, lo) - lo:min((k + 1) * block, hi) - lo].sum()
+    summed = torch.from_numpy(mine)
+    dist.all_reduce(summed)
+    ranges = sharding.shard_ranges_by_block_cells(summed.numpy(), block, total, world)
+    lo, hi = ranges[rank]
+    a, b = shard(lo, hi - lo)
+    local = torch.from_numpy(oracle.levenshtein_pairs(a, b, algo="hyyro").astype(np.int32))
+    my_cells = int((a.lengths.astype(np.int64) * b.lengths.astype(np.int64)).sum())
+    all_cells = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(all_cells, torch.tensor([my_cells]))
+    sums = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sums, torch.tensor([int(local.to(torch.int64).sum()), int(np.bitwise_xor.reduce(local.numpy())) if hi > lo else 0]))
+    reused = torch.full((total,), -7, dtype=torch.int32) if rank == 0 else None
+    results = []
+    for transport in (None, torch.uint8, None):
+        if rank == 0:
+            reused.fill_(-7)
+        gather = sharding.ChunkedGather(ranges, chunks, torch.int32, "cpu", full=reused, transport=transport)
+        for j in range(chunks):
+            gather.send_chunk(local, j)           # piece j leaves while piece j + 1 would be scored
+        full = gather.wait()
+        if rank == 0:
+            ok = all(int(full[l:h].to(torch.int64).sum()) == int(sums[r][0]) and
+                     (int(np.bitwise_xor.reduce(full[l:h].numpy())) if h > l else 0) == int(sums[r][1]) for r, (l, h) in enumerate(ranges))
+            results.append((ok, full.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        queue.put({"ranges": ranges, "cells": [int(c) for c in all_cells], "results": results})
+
+
+def test_eight_rank_gloo_chunked_gather_of_ragged_shards(sw, orc):
+    """`ChunkedGather` at world size 8 (the node the scaling curve is taken on): cells-balanced RAGGED shards -- the stream's pairs get
+    heavier towards its end, so the first rank's shard holds several times the pairs of the last --, four pieces per shard, u32 and
+    u8 on the wire, the root's buffer reused; every rank's slice arrives in its place (per-rank sum and xor checked on the root)
+    and the gathered vector is the single-process result."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    queue, port, world = ctx.Queue(), _free_port(), 8
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = queue.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    total = 40_013
+    ranges = out["ranges"]
+    assert ranges[0][0] == 0 and ranges[-1][1] == total and all(ranges[r][1] == ranges[r + 1][0] for r in range(7))
+    counts = [h - l for l, h in ranges]
+    assert max(counts) > 2 * min(counts)                                   # ragged: balanced on cells, not on pairs
+    assert max(out["cells"]) - min(out["cells"]) < 0.05 * sum(out["cells"]) / 8
+    a, b = sw.generate_pairs("short_words", total, seed=42)
+    keep = (np.arange(total) * 16 // total + 1)
+    a = sw.Strs([bytes(a[i])[: int(keep[i])] for i in range(total)]); b = sw.Strs([bytes(b[i])[: int(keep[i])] for i in range(total)])
+    want = orc.levenshtein_pairs(a, b, algo="hyyro").astype(np.int32)
+    assert len(out["results"]) == 3
+    for ok, full in out["results"]:
+        assert ok and (full == want).all()
+
+
 def test_shard_helpers():
     from stringwars_amd import sharding
     for total in (0, 1, 7, 1000):

@@ -104,6 +104,9 @@ LEGS = {
                       text="C4 with affine gaps (-11, -1)"),
     "c4_bytes": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=128,
                      text="C4 over the full byte alphabet (all 256 classes of the matrix in use), 2 K pairs ~4 KB, linear gaps -4"),
+    "c4_letters52": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="letters52", check=128, letters=52,
+                         text="C4 over a 52-letter alphabet (a-z, A-Z: what a rust-bio style scoring closure over mixed-case text distinguishes, "
+                              "bench.rs:746-752; 53 symbol classes), 2 K pairs ~4 KB, linear gaps -4: the column-profile kernel on the wide class table"),
     "c5": dict(workload="short_words", pairs=20_000_000, kind="lev", prepared=True, check=200_000,
                text="C5: one GPU's share of the 100 M short-word pairs (20 M pairs <= 16 B, mean ~6), unbounded Levenshtein"),
     # beyond BASELINE's five: what round 4 added kernels for
@@ -113,7 +116,7 @@ LEGS = {
                      text="NW on word-sized strings (the reference's default `words` token mode, bench.rs:271): 4 M pairs <= 16 B, "
                           "unary_class_costs(2, -1) as a 32-class table, linear gaps -2 -- one pair per lane (alignshort.hip)"),
 }
-DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c5", "nw_words"]
+DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words"]
 
 
 def parse_args():
@@ -327,6 +330,12 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
     pairs = pairs_override or leg["pairs"]
     started = time.perf_counter()
     a, b = sw.generate_pairs(leg["workload"], pairs, seed=seed)
+    letters = None
+    if leg.get("letters"):   # the byte workload folded onto an alphabet of that many letters (a-z, A-Z, 0-9 ...): same lengths, same edits
+        letters = (bytes(range(97, 123)) + bytes(range(65, 91)) + bytes(range(48, 58)))[:leg["letters"]]
+        fold = np.frombuffer(letters, dtype=np.uint8)
+        a.data[:] = fold[a.data % len(letters)]
+        b.data[:] = fold[b.data % len(letters)]
     generate_s = time.perf_counter() - started
     if int(a.offsets[-1]) < 2 ** 32 and int(b.offsets[-1]) < 2 ** 32:
         a, b = a.with_offsets(np.uint32), b.with_offsets(np.uint32)
@@ -342,7 +351,7 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
         engine = sw.NeedlemanWunschScores(byte_to_class, class_costs, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)
         model = "nw_linear" if leg["gaps"][0] == leg["gaps"][1] else "nw_affine"
     elif kind == "nw":
-        alphabet = None if leg["workload"] == "bytes4k" else sw.synth.AMINO_ACIDS
+        alphabet = letters if letters else (None if leg["workload"] == "bytes4k" else sw.synth.AMINO_ACIDS)
         matrix = sw.substitution_matrix(seed, alphabet)
         engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)
         model = "nw_linear" if leg["gaps"][0] == leg["gaps"][1] else "nw_affine"

@@ -920,7 +920,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             const uint32_t later = spec.bound <= band_max_bound() ? std::min(band_cost(spec.bound), unbounded_cost) : unbounded_cost;
             doubling_need = 1.25 * band_cost(kDoublingBound) / std::max(later, 1u);
             if (scope->doubling_rest) --scope->doubling_rest;
-            else doubling = doubling_need <= 0.9 && (uint64_t)pairs * blocks >= 200000;
+            else doubling = doubling_need <= 0.95 && (uint64_t)pairs * blocks >= 200000;
         }
         if (doubling) {
             PrepassArgs first = pre;
@@ -930,6 +930,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             kf.job.bound = kDoublingBound;
             launch_banded(scope, kf, pairs);
             pre.redo_filter = 1; pre.redo_done_upto = kDoublingBound;
+            // What is left after a first stage that settles nearly everything is a few thousand pairs: too few to fill the device with
+            // the two-word band's items (one wave walks a pair's every column: C3's lines at k = 100, 2 % left over, 0.19 ms), while a
+            // bit-parallel item spreads ONE pair over the lanes of its blocks (0.07 ms). Where the scope's previous doubling call left
+            // less than a tenth, the second stage plans without the band (the results are clamped to the bound either way).
+            if (scope->doubling_settled >= 0.9f) pre.banded = 0;
         }
         launch_prepass(scope, pre);
         // The bit-parallel kernel reads its work list from the device plan, so it is enqueued right away;
@@ -969,6 +974,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             // what the first stage left over: the pairs the second plan filed under a kernel class
             const uint64_t redo = plan.class_start[kMaxClasses] - plan.class_count[kClassTrivial];
             const double settled = 1.0 - (double)redo / (double)pairs;
+            scope->doubling_settled = (float)settled;
             if (settled < doubling_need) scope->doubling_rest = 8;
         }
 
@@ -989,13 +995,13 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             launch_bitparallel_long(scope, kl, plan);
         }
 
-        // Global or local alignment on a class table (<= 32 symbol classes), pairs of more than 384 columns: the column-profile kernel
+        // Global or local alignment on a class table (<= 32 symbol classes; 33 .. 128 on the wide table), pairs of more than 384 columns: the column-profile kernel
         // (nwprofile.hip) takes them -- perm is sorted by class, so they are one contiguous range -- and the wavefront
         // kernels below see a plan without them. STRINGWARS_AMD_NW=classic keeps everything on the wavefront kernels.
         static const bool nw_classic = [] { const char *e = getenv("STRINGWARS_AMD_NW"); return e && strcmp(e, "classic") == 0; }();
         uint32_t profile_first = 0, profile_count = 0;
         Plan wf_plan = plan;
-        if ((engine->kind == 1 || engine->kind == 2) && engine->scoring.class_table && sym_bytes == 1 && !nw_classic) {
+        if ((engine->kind == 1 || engine->kind == 2) && (engine->scoring.class_table || engine->scoring.wide_table) && sym_bytes == 1 && !nw_classic) {
             profile_first = plan.class_start[kClassWf64 + kNwProfileFirstWide];
             for (int c = kClassWf64 + kNwProfileFirstWide; c <= kClassWfMulti; ++c) { profile_count += plan.class_count[c]; wf_plan.class_count[c] = 0; }
         }
@@ -1457,8 +1463,10 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
     // reference's own byte_to_class + 32x32 model, bench.rs:95-108; also 20 amino acids + "other") the kernels keep a
     // 32-byte cost row in registers per step instead of one LDS lookup per cell.
     {
-        uint8_t table[1024 + 256];
-        int rep[32], classes = 0;
+        constexpr int kMost = (int)kWideClasses;
+        static thread_local uint8_t table[kMost * kMost + 256];
+        uint8_t map[256];
+        int rep[kMost], classes = 0;
         bool fits = true;
         for (int b = 0; b < 256 && fits; ++b) {
             int found = -1;
@@ -1469,10 +1477,10 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
                 if (same) found = c;
             }
             if (found < 0) {
-                if (classes == 32) { fits = false; break; }
+                if (classes == kMost) { fits = false; break; }
                 rep[classes] = b; found = classes++;
             }
-            table[1024 + b] = (uint8_t)found;
+            map[b] = (uint8_t)found;
         }
         // Global alignment runs on scores relative to the all-gaps baseline (wavefront.hip): the table holds
         // cost - extend - open (= cost - 2 g for linear gaps; the affine kernel keeps H + (open - extend) in its strips and
@@ -1484,13 +1492,21 @@ static swh_status_t alignment_init(int kind, swh_scope_t handle, const int8_t *m
                 if (v < -128 || v > 127) { fits = false; break; }
             }
         if (fits) {
-            memset(table, 0, 1024);
+            // up to 32 classes: the register cost-row model every class kernel reads (rows of 32 bytes); 33 .. 128: rows of kWideClasses
+            // bytes for the column-profile kernel alone (Scoring::wide_table)
+            const bool wide = classes > 32;
+            const int stride = wide ? kMost : 32;
+            const size_t bytes = (size_t)stride * stride + 256;
+            memset(table, 0, bytes);
             for (int i = 0; i < classes; ++i)
-                for (int j = 0; j < classes; ++j) table[i * 32 + j] = (uint8_t)(int8_t)((int)matrix[rep[i] * 256 + rep[j]] + bias);
-            hipError_t err = hipMalloc((void **)&engine->class_dev, sizeof table);
-            if (err == hipSuccess) err = hipMemcpy(engine->class_dev, table, sizeof table, hipMemcpyHostToDevice);
+                for (int j = 0; j < classes; ++j) table[i * stride + j] = (uint8_t)(int8_t)((int)matrix[rep[i] * 256 + rep[j]] + bias);
+            memcpy(table + (size_t)stride * stride, map, 256);
+            hipError_t err = hipMalloc((void **)&engine->class_dev, bytes);
+            if (err == hipSuccess) err = hipMemcpy(engine->class_dev, table, bytes, hipMemcpyHostToDevice);
             if (err != hipSuccess) { swh_levenshtein_free((swh_levenshtein_t)engine); return fail_hip(error, HipFailure{err, "class table upload"}); }
-            engine->scoring.class_table = engine->class_dev; engine->scoring.classes = (uint32_t)classes;
+            if (wide) engine->scoring.wide_table = engine->class_dev;
+            else engine->scoring.class_table = engine->class_dev;
+            engine->scoring.classes = (uint32_t)classes;
             int widest = 0;   // of the costs themselves (not the biased table)
             for (int i = 0; i < classes; ++i)
                 for (int j = 0; j < classes; ++j) widest = std::max(widest, std::abs((int)matrix[rep[i] * 256 + rep[j]]));

@@ -350,7 +350,14 @@ struct Scoring {
     const uint8_t *class_table;  // device: 32x32 i8 class costs then 256 B byte->class map, when the matrix has <= 32 classes
     uint32_t classes;            // how many of the 32 classes are in use (0: unknown, treat as 32)
     uint32_t step_span;          // class model: max |class cost| + |open| + |extend| -- neighbouring DP cells differ by no more (0: unknown)
+    // 33 .. 128 symbol classes (mixed-case text, IUPAC codes + case: what a rust-bio style scoring closure distinguishes, bench.rs:746-752):
+    // too many for the register cost rows of the 32-class model, but the column-profile kernel (nwprofile.hip) only needs a cost row per
+    // class while it builds a pass's profile. Device: kWideClasses x kWideClasses i8 costs (biased like class_table), then the 256 B
+    // byte -> class map; `classes` says how many are in use. class_table stays null: pairs too narrow for the profile kernel take the
+    // 256 x 256 matrix in LDS as before.
+    const uint8_t *wide_table;
 };
+constexpr uint32_t kWideClasses = 128;
 
 // ------------------------------------------------------------------------------------------------
 // Host-side scope.
@@ -406,6 +413,7 @@ struct Scope {
     // the same tapes runs on their BYTES (code points of ASCII text are its bytes) next to a kernel that checks exactly that (api.hip).
     struct SizeBelief { const void *data = nullptr, *offsets = nullptr; size_t count = 0; int off64 = 0; uint64_t bytes = 0; bool valid = false, ascii = false; } size_belief[2];
     uint32_t early_return_last_us = 0;   // what the previous call that returned on its summary took (api.hip: wait_for_summary bounds its spin by it)
+    float doubling_settled = -1.0f;   // share of the pairs the first stage of the scope's previous doubling call settled (< 0: none yet)
     uint32_t doubling_rest = 0;   // calls left before the two-stage (doubling) schedule of api.hip is tried again: its first stage settled too few pairs
     uint32_t utf8_strings_rest = 0;   // raw UTF-8 calls left before the string-by-string staging is tried again (it met a string too long for it)
     bool align_wide_off = false;   // k_align_cross_wide / _long met candidates with more than eight symbol classes: not tried again on this scope

@@ -96,6 +96,7 @@ __device__ __forceinline__ int umax16(int a, int b) {
 // <= 0, so a phantom cell never exceeds the real cell it descends from and the running maximum needs no column test.
 template <int WE, bool kAffine, bool kRead, bool kWrite, bool kLocal, bool kNarrow>
 __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uint32_t ring_at, const uint8_t *ctab, const uint8_t *cmap,
+                                         const uint8_t *table_src, uint32_t cstride,
                                          uint32_t classes, uint32_t row_bytes, const uint8_t *col_data, const uint8_t *row_data,
                                          uint32_t rows, uint32_t cols, uint32_t c0, int32_t *bnd_h, int32_t *bnd_e, uint64_t p, int &best) {
     constexpr int kPlanes = WE / 4;
@@ -105,12 +106,8 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     const uint32_t mine = c0 + (uint32_t)lane * WE;      // 0-based index of my first column
     const uint32_t steps = (rows + 63 + 3) & ~3u;
     // ---- the column profile of this pass ----------------------------------------------------------------------------
-    // (the 32x32 class costs are only needed here: they are brought into the space the rings use afterwards)
-    {
-        const uint32_t *src = (const uint32_t *)args.scoring.class_table;
-        for (int i = lane; i < 1024 / 4; i += 64) ((uint32_t *)(smem + ring_at))[i] = src[i];
-    }
-    wave_lds_fence();
+    // (the class costs are only needed here: they are brought into the space the rings use afterwards -- all 32 x 32 of the register
+    // model's table at once, a wide table's rows of kWideClasses bytes as many at a time as fit)
     {
         uint32_t ccls[WE];
 #pragma unroll
@@ -120,19 +117,29 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
             const uint32_t sym = real ? (uint32_t)col_data[j] : 0u;
             ccls[k] = real ? (uint32_t)cmap[sym] : 0xFFu;
         }
-        for (uint32_t c = 0; c < classes; ++c) {
-            const uint8_t *crow = ctab + c * 32;
-#pragma unroll
-            for (int pl = 0; pl < kPlanes; ++pl) {
-                uint32_t dw = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t cl = ccls[4 * pl + i];
-                    const uint32_t byte = cl != 0xFFu ? (uint32_t)crow[cl & 31u] : 0u;   // phantom columns score 0: harmless, never read back
-                    dw |= byte << (8 * i);
-                }
-                ((uint32_t *)(smem + c * row_bytes))[pl * 64 + lane] = dw;
+        const uint32_t rows_at_once = kScratchBytes / cstride;   // 88 rows of 32 bytes (every class of the small table), 22 of 128
+        for (uint32_t cfirst = 0; cfirst < classes; cfirst += rows_at_once) {
+            const uint32_t cn = classes - cfirst < rows_at_once ? classes - cfirst : rows_at_once;
+            {
+                const uint32_t *src = (const uint32_t *)(table_src + cfirst * cstride);
+                for (uint32_t i = (uint32_t)lane; i < cn * cstride / 4; i += 64) ((uint32_t *)(smem + ring_at))[i] = src[i];
             }
+            wave_lds_fence();
+            for (uint32_t c = cfirst; c < cfirst + cn; ++c) {
+                const uint8_t *crow = ctab + (c - cfirst) * cstride;
+#pragma unroll
+                for (int pl = 0; pl < kPlanes; ++pl) {
+                    uint32_t dw = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t cl = ccls[4 * pl + i];
+                        const uint32_t byte = cl != 0xFFu ? (uint32_t)crow[cl & (cstride - 1u)] : 0u;   // phantom columns score 0: harmless, never read back
+                        dw |= byte << (8 * i);
+                    }
+                    ((uint32_t *)(smem + c * row_bytes))[pl * 64 + lane] = dw;
+                }
+            }
+            wave_lds_fence();   // the next rows of the table (or the rings) overwrite these
         }
     }
     wave_lds_fence();   // everybody is done with the class costs: the rings take their place
@@ -429,7 +436,10 @@ __global__ __launch_bounds__(64) void k_nwprofile(KernelArgs args, uint32_t firs
     const int lane = threadIdx.x;
     // the byte -> class map stays resident; the 32x32 biased class costs (sub - ext - open, api.hip: alignment_init) are
     // reloaded per pass into the rings' space (run_pass)
-    ((uint32_t *)(smem + cmap_at))[lane] = ((const uint32_t *)args.scoring.class_table)[256 + lane];
+    const bool wide = args.scoring.class_table == nullptr;   // 33 .. 128 classes: Scoring::wide_table, rows of kWideClasses bytes
+    const uint8_t *table_src = wide ? args.scoring.wide_table : args.scoring.class_table;
+    const uint32_t cstride = wide ? kWideClasses : 32u;
+    ((uint32_t *)(smem + cmap_at))[lane] = ((const uint32_t *)(table_src + cstride * cstride))[lane];
     wave_lds_fence();
     const uint8_t *ctab = (const uint8_t *)(smem + ring_at);
     const uint8_t *cmap = (const uint8_t *)(smem + cmap_at);
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(64) void k_nwprofile(KernelArgs args, uint32_t firs
             const uint32_t c0 = pass * 64 * W;
             const uint32_t w = pass < full ? (uint32_t)W : w_last;
 #define SWH_PASS2(WE, RD, WR)                                                                                                  \
-    run_pass<WE, kAffine, RD, WR, kLocal, kNarrow>(args, smem, ring_at, ctab, cmap, classes, kRowBytes, col_data, row_data, rows, cols, c0, bnd_h, bnd_e, p, best)
+    run_pass<WE, kAffine, RD, WR, kLocal, kNarrow>(args, smem, ring_at, ctab, cmap, table_src, cstride, classes, kRowBytes, col_data, row_data, rows, cols, c0, bnd_h, bnd_e, p, best)
 #define SWH_PASS(WE)                                                                    \
     do {                                                                                \
         if (pass == 0) { if (passes == 1) SWH_PASS2(WE, false, false); else SWH_PASS2(WE, false, true); } \
@@ -502,10 +512,11 @@ void launch_w(Scope *scope, const KernelArgs &args, uint32_t first, uint32_t cou
 
 template <bool kAffine, bool kLocal, bool kNarrow = false>
 void launch_strip(Scope *scope, const KernelArgs &args, uint32_t first, uint32_t count, uint32_t classes, uint32_t blocks, uint32_t strip,
-                  const char *n16, const char *n12, const char *n8) {
+                  const char *n16, const char *n12, const char *n8, const char *n4) {
     if (strip == 16) launch_w<16, kAffine, kLocal, kNarrow>(scope, args, first, count, classes, blocks, n16);
     else if (strip == 12) launch_w<12, kAffine, kLocal, kNarrow>(scope, args, first, count, classes, blocks, n12);
-    else launch_w<8, kAffine, kLocal, kNarrow>(scope, args, first, count, classes, blocks, n8);
+    else if (strip == 8) launch_w<8, kAffine, kLocal, kNarrow>(scope, args, first, count, classes, blocks, n8);
+    else launch_w<4, kAffine, kLocal, kNarrow>(scope, args, first, count, classes, blocks, n4);
 }
 
 }  // namespace
@@ -514,8 +525,12 @@ void launch_strip(Scope *scope, const KernelArgs &args, uint32_t first, uint32_t
 uint32_t nwprofile_strip(uint32_t classes) {
     // comparison knob STRINGWARS_AMD_NWP_STRIP=8|12|16 (honoured when the profile still fits a workgroup's 64 KB)
     static const uint32_t forced = [] { const char *e = getenv("STRINGWARS_AMD_NWP_STRIP"); return e ? (uint32_t)atoi(e) : 0u; }();
-    if ((forced == 8 || forced == 12 || forced == 16) && (size_t)classes * 64 * forced + kScratchBytes + 256 <= 65536) return forced;
-    return classes <= 16 ? 16u : (classes <= 24 ? 12u : 8u);
+    if ((forced == 4 || forced == 8 || forced == 12 || forced == 16) && (size_t)classes * 64 * forced + kScratchBytes + 256 <= 65536 && classes * 64 * forced <= 65535) return forced;
+    // beyond the 32 classes of the register model (Scoring::wide_table): the profile's rows are what LDS holds -- strips of eight columns
+    // as long as five single-wave workgroups fit a CU (56 classes: 32 KB each), of four beyond (128 classes: 36 KB, four per CU).
+    // Measured on 2 K pairs of ~4 KB over 52 letters (53 classes, bench.py c4_letters52): W = 8 on five waves 5.3 TCUPS, W = 4 on nine 4.5 --
+    // against 3.8 for one LDS look-up per cell (k_wavefront's matrix model); the 21 classes of config C4 run W = 12 on eight waves at 11.8.
+    return classes <= 16 ? 16u : (classes <= 24 ? 12u : (classes <= 56 ? 8u : 4u));
 }
 
 // Narrow strips (see kCenter): everything a wave holds at one time must fit 16 bits around its middle.
@@ -543,13 +558,13 @@ void launch_nwprofile(Scope *scope, KernelArgs args, uint32_t first, uint32_t co
     SWH_HIP_CHECK(hipMemsetAsync(args.ticket, 0, 4, scope->stream));
     const uint32_t strip = nwprofile_strip(classes);
     if (!args.local) {
-        if (!args.affine) launch_strip<false, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_w16", "nwprofile_w12", "nwprofile_w8");
+        if (!args.affine) launch_strip<false, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_w16", "nwprofile_w12", "nwprofile_w8", "nwprofile_w4");
         else if (nwprofile_narrow(args.scoring, strip))
-            launch_strip<true, false, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_affine_narrow_w16", "nwprofile_affine_narrow_w12", "nwprofile_affine_narrow_w8");
-        else launch_strip<true, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_affine_w16", "nwprofile_affine_w12", "nwprofile_affine_w8");
+            launch_strip<true, false, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_affine_narrow_w16", "nwprofile_affine_narrow_w12", "nwprofile_affine_narrow_w8", "nwprofile_affine_narrow_w4");
+        else launch_strip<true, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_affine_w16", "nwprofile_affine_w12", "nwprofile_affine_w8", "nwprofile_affine_w4");
     } else {
-        if (!args.affine) launch_strip<false, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_w16", "nwprofile_local_w12", "nwprofile_local_w8");
-        else launch_strip<true, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_affine_w16", "nwprofile_local_affine_w12", "nwprofile_local_affine_w8");
+        if (!args.affine) launch_strip<false, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_w16", "nwprofile_local_w12", "nwprofile_local_w8", "nwprofile_local_w4");
+        else launch_strip<true, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_affine_w16", "nwprofile_local_affine_w12", "nwprofile_local_affine_w8", "nwprofile_local_affine_w4");
     }
     SWH_HIP_CHECK(hipGetLastError());
 }

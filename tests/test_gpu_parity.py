@@ -501,6 +501,45 @@ def test_class_table_needleman_wunsch(sw, orc, scope, gaps, classes):
 
 
 @pytest.mark.parametrize("gaps", [(-4, -4), (-11, -1)])
+@pytest.mark.parametrize("classes", [33, 52, 64, 100, 128, 129])
+def test_wide_class_table_needleman_wunsch(sw, orc, scope, gaps, classes):
+    """33 .. 128 symbol classes -- mixed-case text, IUPAC codes with case: what a rust-bio style scoring closure distinguishes
+    (bench.rs:746-752 is a closure over ANY alphabet) -- are too many for the register cost rows of the 32-class model, but the
+    column-profile kernel only needs one cost row per class while it builds a pass's profile: such matrices get a table of
+    128-byte rows (Scoring::wide_table) and their long pairs run on k_nwprofile with strips of eight (<= 56 classes) or four columns,
+    global and local, linear and affine (52 letters: 5.3 TCUPS against 3.8 for the LDS gather); 129 classes and up keep the 256 x 256 matrix in LDS. Scores are the oracle's throughout:
+    strings on both sides of the profile kernel's 384 columns, several passes, rows beyond a ring block, empty strings."""
+    rng = np.random.default_rng(classes * 11 - gaps[1])
+    byte_to_class = rng.integers(0, classes, 256).astype(np.int64)
+    byte_to_class[rng.permutation(256)[:classes]] = np.arange(classes)              # every class in use
+    costs = rng.integers(-9, 12, (classes, classes)).astype(np.int8)               # asymmetric on purpose
+    costs[np.arange(classes), np.arange(classes)] = rng.integers(4, 12, classes)
+    costs[0, 1] = -9; costs[1, 0] = 11                                              # no two classes alike
+    full = costs[byte_to_class][:, byte_to_class].astype(np.int8)
+    lengths = [0, 1, 7, 40, 129, 383, 384, 385, 511, 512, 513, 700, 1023, 1024, 1025, 1100, 1600, 2049, 3100]
+    items_a, items_b = random_pairs(rng, 150, lengths, 256)
+    items_a += [bytes(rng.integers(0, 256, 7000, dtype=np.uint8)), bytes(rng.integers(0, 256, 5000, dtype=np.uint8))]
+    items_b += [bytes(rng.integers(0, 256, 6600, dtype=np.uint8)), items_a[-1][100:4900]]
+    a, b = sw.Strs(items_a), sw.Strs(items_b)
+    for local in (False, True):
+        Engine = sw.SmithWatermanScores if local else sw.NeedlemanWunschScores
+        engine = Engine(substitution_matrix=full, open=gaps[0], extend=gaps[1], capabilities=scope)
+        want = np.array([orc.nw_score(x, y, full, gaps[0], gaps[1], local=local) for x, y in zip(items_a, items_b)])
+        scope.set_profiling(True)
+        got = engine.pairs(a, b, scope)
+        name = scope.last_timing()["dominant_name"]
+        scope.set_profiling(False)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (classes, gaps, local, bad[:5], got[bad[:5]], want[bad[:5]], a.lengths[bad[:5]], b.lengths[bad[:5]])
+        if classes <= 128:
+            assert name.startswith("nwprofile") and name.endswith("_w8" if classes <= 56 else "_w4"), name
+        else:
+            assert name.startswith("wavefront"), name
+        pa, pb = sw.PreparedTape(scope, a), sw.PreparedTape(scope, b)
+        assert (engine.pairs(pa, pb, scope) == want).all()
+
+
+@pytest.mark.parametrize("gaps", [(-4, -4), (-11, -1)])
 @pytest.mark.parametrize("classes", [5, 21, 32])
 def test_column_profile_kernel_every_strip_shape(sw, orc, scope, gaps, classes):
     """nwprofile.hip (global alignment on a class table, pairs of more than 384 columns): every strip width the kernel
@@ -2157,7 +2196,7 @@ def test_bench_line_carries_every_config():
     assert abs(line["value"] - line["config"]["cells_per_gpu"] * 5 / (line["ms_per_step"] * 5e-3) / 1e9) < 0.02 * line["value"]
     assert line["roofline"]["bound"] == "valu" and line["roofline"]["kernel_ms"] > 0 and line["roofline"]["kernel"] == "bitparallel_tiled"
     assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes",
-                                                        "c5", "nw_words"]
+                                                        "c4_letters52", "c5", "nw_words"]
     for entry in line["configs"]:
         assert "error" not in entry, entry
         assert entry["value"] > 0 and entry["parity_vs_oracle"] is True and entry["roofline"]["kernel_ms"] > 0 and entry["pairs"] == 600, entry

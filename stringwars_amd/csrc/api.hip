@@ -911,6 +911,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         double doubling_need = 0;
         constexpr uint32_t kDoublingBound = 63;
         static const bool doubling_on = [] { const char *e = getenv("STRINGWARS_AMD_DOUBLING"); return !e || atoi(e) != 0; }();
+        static const uint64_t doubling_min = [] { const char *e = getenv("STRINGWARS_AMD_DOUBLING_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)200000; }();   // tuning knob: pairs x blocks
         if (doubling_on && bitpar_ok && pre.unit_costs && engine->algorithm == swh_algorithm_auto_k && spec.bound > kDoublingBound &&
             (prepared || scope->hint_lengths)) {
             const uint32_t la_max = prepared ? (utf8 ? spec.pa->longest_symbols : spec.pa->longest_bytes) : scope->hint_max_la;
@@ -920,7 +921,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             const uint32_t later = spec.bound <= band_max_bound() ? std::min(band_cost(spec.bound), unbounded_cost) : unbounded_cost;
             doubling_need = 1.25 * band_cost(kDoublingBound) / std::max(later, 1u);
             if (scope->doubling_rest) --scope->doubling_rest;
-            else doubling = doubling_need <= 0.95 && (uint64_t)pairs * blocks >= 200000;
+            else doubling = doubling_need <= 0.95 && (uint64_t)pairs * blocks >= doubling_min;   // (a second plan and a second tail: not for small batches)
         }
         if (doubling) {
             PrepassArgs first = pre;

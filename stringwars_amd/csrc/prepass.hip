@@ -1730,22 +1730,118 @@ void launch_utf8_decode(Scope *scope, const Utf8Args &args) {
 // For tapes of lines and longer (api.hip: a mean string of >= kUtf8StringsMeanBytes bytes); a string beyond kUtf8StringLongest
 // bytes would keep one wave busy for milliseconds: the kernel says so (kUtf8StringTooLong) and the host stages the flat way.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kUtf8StrRound = 1024;       // bytes per round: sixteen per lane
+constexpr int kUtf8StrRound = 1024;       // bytes per full round: sixteen per lane
 constexpr int kUtf8StrWaves = 4;
 struct Utf8StringsLds {
     Utf8Lead table[256];
-    uint32_t raw[kUtf8StrWaves][kUtf8StrRound / 4 + 4];    // a round's bytes and the word after them (look-ahead of its last sequences)
-    uint16_t leads[kUtf8StrWaves][kUtf8StrRound];          // byte positions of the round's lead bytes in rank order
+    uint32_t win[kUtf8StrWaves][kUtf8StrRound];   // the round's sequences in rank order: the four bytes from each lead byte on
 };
 
-// sixteen bytes from `pos` on; bytes past the tape read as zero (a branch only the tape's last bytes take)
-__device__ __forceinline__ uint4 utf8_load16(const uint8_t *data, uint64_t pos, uint64_t total) {
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (pos + 16 <= total) { __builtin_memcpy(&v, data + pos, 16); return v; }
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    for (int j = 0; j < 16; ++j)
+// D dwords from `pos` on; bytes past the tape read as zero (a branch only the tape's last bytes take)
+template <int D>
+__device__ __forceinline__ void utf8_load_dwords(const uint8_t *data, uint64_t pos, uint64_t total, uint32_t (&w)[D]) {
+    if (pos + 4 * D <= total) { __builtin_memcpy(w, data + pos, 4 * D); return; }
+#pragma unroll
+    for (int q = 0; q < D; ++q) w[q] = 0;
+    for (int j = 0; j < 4 * D; ++j)
         if (pos + (uint64_t)j < total) w[j >> 2] |= (uint32_t)data[pos + j] << (8 * (j & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// One round of one string: the 256 D bytes from `pos` on, 4 D per lane (D = 4 for every round but a string's last, whose D is what
+// the rest needs: no lane works on bytes the string does not have). `rem`: bytes of the string from `pos` on.
+//   1. every lane flags the lead bytes of its dwords (bytes behind the string's end are zeroed first -- a sequence that reaches past
+//      the end then fails its continuation check -- and are no lead bytes), a wave scan ranks them;
+//   2. every lead byte's WINDOW -- the four bytes from it on, cut from the lane's registers (the dword after its last comes from the
+//      next lane by DPP) -- goes to win[rank]: the round's sequences in order, no list of positions, no second look at the bytes;
+//   3. lane k decodes sequences k, k + 64, ... (the table of k_utf8_tile_decode: one 16-byte entry per first byte) and stores code
+//      points k, k + 64, ...: full lines.
+template <int D>
+__device__ __forceinline__ uint32_t utf8_string_round(const Utf8Lead *table, uint32_t *win, const uint8_t *data, uint64_t pos, uint64_t total, uint64_t rem,
+                                                      uint32_t *out, uint32_t &wrong_pair, uint32_t &wrong_tops, uint32_t &shapes, uint32_t &high) {
+    const int lane = threadIdx.x & 63;
+    uint32_t dw[D + 1];
+    {
+        uint32_t got[D];
+        utf8_load_dwords<D>(data, pos + (uint64_t)(4 * D) * (uint32_t)lane, total, got);
+#pragma unroll
+        for (int q = 0; q < D; ++q) dw[q] = got[q];
+    }
+    uint32_t after[1] = {0u};
+    if (lane == 63) utf8_load_dwords<1>(data, pos + 256u * D, total, after);   // look-ahead of the round's last sequences
+    uint32_t tail_mask[D];   // (string's last round) which bytes of my dwords are the string's
+#pragma unroll
+    for (int q = 0; q < D; ++q) tail_mask[q] = 0xFFFFFFFFu;
+    if (rem < 256u * D) {   // (wave-uniform) the string ends inside this round: what lies behind its end reads as zero
+        const uint32_t mine = 4u * D * (uint32_t)lane;
+        const uint32_t have = (uint32_t)rem > mine ? (uint32_t)rem - mine : 0u;   // bytes of the string in my dwords (>= 4 D: all of them)
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+            const uint32_t nv = have > 4u * q ? (have - 4u * q < 4u ? have - 4u * q : 4u) : 0u;
+            tail_mask[q] = (uint32_t)~(~0ull << (8u * nv));
+            dw[q] &= tail_mask[q];
+        }
+    }
+    {   // the word behind the round holds bytes of the string only as far as the string goes (wave-uniform arithmetic, lane 63's word)
+        const uint32_t beyond = rem > 256u * D ? (rem - 256u * D < 4u ? (uint32_t)(rem - 256u * D) : 4u) : 0u;
+        after[0] &= (uint32_t)~(~0ull << (8u * beyond));
+    }
+    // the string's lead bytes are counted on the masked flags (a zero byte behind the end is no lead byte of the string) ...
+    uint32_t mine_count = 0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+        high |= dw[q];
+        mine_count += (uint32_t)__popc(lead_flags4(dw[q]) & tail_mask[q]);
+    }
+    const uint32_t incl = wave_inclusive_sum_u32(mine_count);
+    const uint32_t total_leads = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    // the dword after my last: the next lane's first (wave_shl:1; lane 63 keeps the word behind the round)
+    dw[D] = (uint32_t)__builtin_amdgcn_update_dpp((int)after[0], (int)dw[0], 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+    // ... and ranked by position. The zero bytes behind the string's end pass the test below, but they come AFTER every byte of the
+    // string: their windows land behind the string's own (win[] holds 1024) and are never decoded. The test itself is one compare on
+    // the byte (a lead byte is anything but 10xxxxxx: as a signed byte, >= -64), no flag word to pick bits from.
+    // (Written out: hipcc turns the byte test into v_and + v_cmp and moves the rank through a second register -- six vector
+    // instructions per byte slot where these are three. s_and_saveexec right behind the v_cmp that feeds it is what hipcc emits itself.)
+    uint32_t rank = incl - mine_count;
+    const uint32_t win_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32 *)win);
+    const int least_lead = -64;
+#define SWH_UTF8_SLOT(BYTE, WINDOW)                                                                                          \
+    do {                                                                                                                     \
+        unsigned long long saved__;                                                                                          \
+        uint32_t addr__;                                                                                                     \
+        asm volatile("v_cmp_le_i32_sdwa vcc, %[k], sext(%[dw]) src0_sel:DWORD src1_sel:BYTE_" #BYTE "\n\t"                  \
+                     "s_and_saveexec_b64 %[sv], vcc\n\t"                                                                    \
+                     "v_lshl_add_u32 %[ad], %[rk], 2, %[bs]\n\t"                                                            \
+                     "ds_write_b32 %[ad], %[w]\n\t"                                                                         \
+                     "v_add_u32 %[rk], 1, %[rk]\n\t"                                                                        \
+                     "s_or_b64 exec, exec, %[sv]"                                                                            \
+                     : [rk] "+v"(rank), [sv] "=&s"(saved__), [ad] "=&v"(addr__)                                              \
+                     : [k] "v"(least_lead), [dw] "v"(dw[q]), [w] "v"(WINDOW), [bs] "s"(win_base)                             \
+                     : "vcc", "memory");                                                                                     \
+    } while (0)
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+        const uint32_t w1 = __builtin_amdgcn_alignbit(dw[q + 1], dw[q], 8), w2 = __builtin_amdgcn_alignbit(dw[q + 1], dw[q], 16);
+        const uint32_t w3 = __builtin_amdgcn_alignbit(dw[q + 1], dw[q], 24);
+        SWH_UTF8_SLOT(0, dw[q]);
+        SWH_UTF8_SLOT(1, w1);
+        SWH_UTF8_SLOT(2, w2);
+        SWH_UTF8_SLOT(3, w3);
+    }
+#undef SWH_UTF8_SLOT
+    wave_lds_fence();   // the lanes read each other's windows
+    for (uint32_t k = (uint32_t)lane; k < total_leads; k += 64) {
+        const uint32_t sq = win[k];
+        const uint4 t = *(const uint4 *)&table[sq & 0xFFu];   // x lead, y shape, z cont, w range (see k_utf8_tile_decode)
+        uint32_t inside;
+        asm volatile("v_med3_u16 %0, %1, %2, %2 op_sel:[0,0,1,0]" : "=v"(inside) : "v"(sq), "v"(t.w));
+        wrong_pair |= inside ^ sq;
+        wrong_tops |= (sq ^ 0x80800000u) & t.z;
+        shapes += t.y;
+        const uint32_t after3 = (((sq >> 8 & 0x3Fu) << 6 | (sq >> 16 & 0x3Fu)) << 6) | (sq >> 24 & 0x3Fu);
+        out[k] = t.x | __builtin_amdgcn_ubfe(after3, t.y, t.z);
+    }
+    wave_lds_fence();   // the next round rewrites the windows
+    return total_leads;
 }
 
 template <typename Off>
@@ -1762,8 +1858,7 @@ __global__ __launch_bounds__(kUtf8StrWaves * 64) void k_utf8_strings(Utf8Strings
             j.extents[2 * j.count] = j.total;
         }
     }
-    uint32_t *raw = lds.raw[wave];
-    uint16_t *leads = lds.leads[wave];
+    uint32_t *win = lds.win[wave];
     const uint64_t strings = ja.count + jb.count;
     const uint64_t waves_total = (uint64_t)gridDim.x * kUtf8StrWaves;
     uint32_t high_a = 0, high_b = 0;
@@ -1786,67 +1881,21 @@ __global__ __launch_bounds__(kUtf8StrWaves * 64) void k_utf8_strings(Utf8Strings
             continue;
         }
         uint32_t done = 0;                 // code points of the rounds before this one
-        uint32_t wrong_pair = 0, wrong_tops = 0, shapes = 0, over = 0, high = 0;
-        uint32_t *out = symbols + o;
-        for (uint64_t at0 = 0; at0 < len; at0 += kUtf8StrRound) {
-            // rounds start AT the string (unaligned 16-byte loads): no bytes in front of it to mask away
-            const uint4 v = utf8_load16(data, o + at0 + 16u * (uint32_t)lane, total);
-            uint32_t after = 0;
-            if (lane == 0) { const uint4 nx = utf8_load16(data, o + at0 + kUtf8StrRound, total); after = nx.x; }
-            const uint32_t f0 = lead_flags4(v.x), f1 = lead_flags4(v.y), f2 = lead_flags4(v.z), f3 = lead_flags4(v.w);
-            high |= v.x | v.y | v.z | v.w;
-            const uint32_t mine = (uint32_t)(__popc(f0) + __popc(f1) + __popc(f2) + __popc(f3));
-            const uint32_t incl = wave_inclusive_sum_u32(mine);
-            *(uint4 *)&raw[4 * lane] = v;
-            if (lane == 0) raw[kUtf8StrRound / 4] = after;
-            // Bytes behind the string's end (the last round only) come AFTER every byte of it, so their lead bytes rank behind
-            // the string's own: they are listed and never decoded. How many of the round's lead bytes are the string's is found
-            // on the scalar unit: the lane that holds the end, its flags below the end, its exclusive prefix.
-            uint32_t valid = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const uint64_t rem = len - at0;
-            if (rem < kUtf8StrRound) {
-                const uint32_t el = (uint32_t)rem >> 4, eb = (uint32_t)rem & 15u;   // lane and byte of the first byte behind the string
-                const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, el), g1 = (uint32_t)__builtin_amdgcn_readlane((int)f1, el);
-                const uint32_t g2 = (uint32_t)__builtin_amdgcn_readlane((int)f2, el), g3 = (uint32_t)__builtin_amdgcn_readlane((int)f3, el);
-                const uint32_t excl_el = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), el);
-                const uint32_t dw = eb >> 2, below = (1u << (8u * (eb & 3u))) - 1u;
-                const uint32_t part = dw == 0 ? g0 : (dw == 1 ? g1 : (dw == 2 ? g2 : g3));
-                uint32_t cnt = (uint32_t)__popc(part & below);
-                cnt += dw > 0 ? (uint32_t)__popc(g0) : 0u;
-                cnt += dw > 1 ? (uint32_t)__popc(g1) : 0u;
-                cnt += dw > 2 ? (uint32_t)__popc(g2) : 0u;
-                valid = excl_el + cnt;
-            }
-            uint32_t rank = incl - mine;
-            const uint32_t fl[4] = {f0, f1, f2, f3};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if ((fl[q] >> (8 * u + 7)) & 1u) leads[rank++] = (uint16_t)(16 * lane + 4 * q + u);
-            wave_lds_fence();   // the lanes read each other's bytes and list entries
-            const uint32_t end_rel = rem < kUtf8StrRound + 4u ? (uint32_t)rem : (uint32_t)kUtf8StrRound + 4u;   // (a round's last sequences may reach into the next round, never past the string)
-            for (uint32_t k = (uint32_t)lane; k < valid; k += 64) {
-                const uint32_t at = leads[k];
-                const uint32_t lo = raw[at >> 2], hi = raw[(at >> 2) + 1];
-                const uint32_t sq = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * (at & 3u)));
-                const uint4 t = *(const uint4 *)&lds.table[sq & 0xFFu];   // x lead, y shape, z cont, w range (see k_utf8_tile_decode)
-                uint32_t inside;
-                asm volatile("v_med3_u16 %0, %1, %2, %2 op_sel:[0,0,1,0]" : "=v"(inside) : "v"(sq), "v"(t.w));
-                wrong_pair |= inside ^ sq;
-                wrong_tops |= (sq ^ 0x80800000u) & t.z;
-                shapes += t.y;
-                over |= (at + (t.y >> 16) > end_rel) ? 1u : 0u;
-                const uint32_t after3 = (((sq >> 8 & 0x3Fu) << 6 | (sq >> 16 & 0x3Fu)) << 6) | (sq >> 24 & 0x3Fu);
-                out[done + k] = t.x | __builtin_amdgcn_ubfe(after3, t.y, t.z);
-            }
-            done += valid;
-            wave_lds_fence();   // the next round rewrites the bytes and the list
-        }
+        uint32_t wrong_pair = 0, wrong_tops = 0, shapes = 0, high = 0;
+        // rounds start AT the string (unaligned loads): no bytes in front of it to mask away; full rounds of 1 KB, then one round of
+        // one to four dwords per lane for what is left
+        uint64_t at0 = 0;
+        for (; len - at0 > (uint64_t)kUtf8StrRound; at0 += kUtf8StrRound)
+            done += utf8_string_round<4>(lds.table, win, data, o + at0, total, len - at0, symbols + o + done, wrong_pair, wrong_tops, shapes, high);
+        const uint64_t rest = len - at0;
+        if (rest > 768) done += utf8_string_round<4>(lds.table, win, data, o + at0, total, rest, symbols + o + done, wrong_pair, wrong_tops, shapes, high);
+        else if (rest > 512) done += utf8_string_round<3>(lds.table, win, data, o + at0, total, rest, symbols + o + done, wrong_pair, wrong_tops, shapes, high);
+        else if (rest > 256) done += utf8_string_round<2>(lds.table, win, data, o + at0, total, rest, symbols + o + done, wrong_pair, wrong_tops, shapes, high);
+        else if (rest > 0) done += utf8_string_round<1>(lds.table, win, data, o + at0, total, rest, symbols + o + done, wrong_pair, wrong_tops, shapes, high);
         if (second) high_b |= high; else high_a |= high;
         // what the sequences claim against what the string holds; any lane's complaint is the string's
         const uint32_t claimed = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum_u32(shapes >> 16), 63);
-        const bool bad_lane = (((wrong_pair & 0xFFFFu) | (wrong_tops & 0xC0C00000u)) | over) != 0;
+        const bool bad_lane = ((wrong_pair & 0xFFFFu) | (wrong_tops & 0xC0C00000u)) != 0;
         const bool bad = __ballot(bad_lane) != 0 || claimed != (uint32_t)len;
         if (lane == 0) {
             extents[2 * i] = o;

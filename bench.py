@@ -21,7 +21,7 @@ algorithm skips. Fields of the line:
   value_steady       the same calls over at least `--steady-seconds` (default 1 s) of wall time
   value_pipelined    K steps enqueued asynchronously on two internal lanes (not the reference's metric; what a caller
                      that does not need each result before the next call gets)
-  roofline           dominant kernel of the synchronous call: executed lane-ops (PMC constants, profiles/r4) over the kernel
+  roofline           dominant kernel of the synchronous call: executed lane-ops (PMC constants, profiles/r5) over the kernel
                      time measured live with hipEvents inside the library, on the kernel's own stream
   configs            (N = 1) every other BASELINE config at full size, same measurement per entry: C1, C3 prepared / raw,
                      C4 linear / affine / full byte alphabet, C5 at 20 M pairs per GPU -- each with its synchronous-call
@@ -69,7 +69,7 @@ PEAK_HBM_GBS = 8000.0
 NOMINAL_OPS_PER_CELL = {"lev": 5, "lev_utf8": 5, "nw_linear": 6, "nw_affine": 11}
 # Executed VALU instructions and HBM traffic per call come from rocprofv3 PMC passes over `bench.py --only-config ...`
 # (tools/refresh_profiles.sh -> tools/pmc_constants.py); they cannot be read from inside the process.
-PMC_CONSTANTS = os.path.join(ROOT, "profiles", "r4", "pmc_constants.json")
+PMC_CONSTANTS = os.path.join(ROOT, "profiles", "r5", "pmc_constants.json")
 PMC_CONSTANTS_NAME = os.path.relpath(PMC_CONSTANTS, ROOT)
 
 CONFIGS = {
@@ -829,7 +829,7 @@ def measure(cfg_name, args, env, steps, warmup, prewarm_seconds, steady_seconds,
     # They cost a few microseconds per call, so `value` above comes from the run without them; same calls, same conditions
     # -- what `rocprofv3 --kernel-trace --stats` of `bench.py --no-pipelined --no-configs --no-cpu-baseline` averages over.
     scope.set_profiling(True)
-    timed_region(steps)
+    profiled_elapsed = max_over_ranks(timed_region(steps))
     totals = scope.timing_totals()
     sync_timing = scope.last_timing()
     scope.set_profiling(False)
@@ -863,7 +863,7 @@ def measure(cfg_name, args, env, steps, warmup, prewarm_seconds, steady_seconds,
     fence()
     return dict(cfg=cfg, workload=workload, strong=strong, a=a, b=b, pairs=pairs, total_pairs=total_pairs, cells=cells, total_cells=total_cells,
                 offsets_dtype=offsets_dtype, n_pieces=len(pieces), elapsed=elapsed, steps=steps, sync_result=sync_result, gather_ok=gather_ok,
-                gather=gather, totals=totals, sync_timing=sync_timing, steady=steady, pipelined_rate=pipelined_rate,
+                gather=gather, totals=totals, sync_timing=sync_timing, profiled_elapsed=profiled_elapsed, steady=steady, pipelined_rate=pipelined_rate,
                 pipelined_result=pipelined_result, pipelined_ms=pipelined_ms, ranges=ranges)
 
 
@@ -998,10 +998,19 @@ def run(args):
         totals, sync_timing = head["totals"], head["sync_timing"]
         calls_timed = max(totals["calls"], 1)
         kernel_ms = totals["compute_ms"] / calls_timed
+        # The event pairs slow a step down (a few microseconds per call, 8 % of a step of C5 at 100 M pairs): a kernel cannot outlast the
+        # step that contains it, so the profiled repeat's kernel time is brought to the unprofiled steps' scale where the repeat ran slower
+        profiled_ms_per_step = head["profiled_elapsed"] / args.steps * 1e3
+        unprofiled_ms_per_step = head["elapsed"] / args.steps * 1e3
+        scale = min(1.0, unprofiled_ms_per_step / profiled_ms_per_step) if profiled_ms_per_step > 0 else 1.0
+        kernel_ms_profiled = kernel_ms
+        kernel_ms *= scale
         roofline = roofline_of(sync_timing["dominant_name"], kernel_ms, int(cells / n_pieces), int(sync_timing["bytes"]), head["workload"],
                                pairs // n_pieces, constants,
-                               extra={"all_kernels_ms": round(totals["total_ms"] / calls_timed, 4), "launches_timed": totals["calls"],
-                                      "measured": "hipEvents inside the library over a repeat of the K timed synchronous steps (average per call)"})
+                               extra={"all_kernels_ms": round(totals["total_ms"] / calls_timed * scale, 4), "launches_timed": totals["calls"],
+                                      "kernel_ms_profiled_repeat": round(kernel_ms_profiled, 4), "profiled_repeat_ms_per_step": round(profiled_ms_per_step, 4),
+                                      "measured": "hipEvents inside the library over a repeat of the K timed synchronous steps (average per call), scaled by "
+                                                  "ms_per_step / profiled_repeat_ms_per_step where the repeat with event pairs ran slower than the timed steps"})
         roofline["unit_note"] = "bound = integer VALU issue (not MFMA: min-plus has no dense contraction; not HBM: see `hbm`)"
         parity = None
         cpu_baseline, cpu_baselines = None, None

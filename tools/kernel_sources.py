@@ -19,6 +19,7 @@ KERNELS = {
     "bitparallel_tiled_u32": ("swh::k_bitparallel_tiled<unsigned int,", ("tiled.hip", "bp_item.hpp", "bp_window.hpp", "common.hpp")),
     "bitparallel_long": ("swh::k_bitparallel_long<unsigned char", ("bitparallel.hip", "bp_item.hpp", "bp_window.hpp", "common.hpp")),
     "direct_short": ("swh::k_direct_short<", ("prepass.hip", "bp_window.hpp", "common.hpp")),
+    "utf8_strings": ("swh::k_utf8_strings<", ("prepass.hip", "common.hpp")),
     "short_tiled": ("swh::k_short_tiled<", ("short.hip", "common.hpp")),
     "banded": ("swh::k_banded<", ("banded.hip", "common.hpp")),
     "wavefront": ("swh::k_wavefront<", ("wavefront.hip", "common.hpp")),

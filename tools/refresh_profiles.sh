@@ -8,11 +8,11 @@ OUT=$REPO/gpurun_out/refresh
 mkdir -p "$OUT"
 cd "$REPO"
 # entries of legs that are not re-profiled in this run stay as committed (a fresh box has no gpurun_out/)
-[ -f "$OUT/pmc_constants.json" ] || cp profiles/r4/pmc_constants.json "$OUT/pmc_constants.json" 2>/dev/null || cp profiles/r3/pmc_constants.json "$OUT/pmc_constants.json" 2>/dev/null
-LEGS=${*:-c2 c1 c3 c3_raw c3_k100 c4_linear c4_affine c4_bytes c5 nw_words}
-declare -A WORKLOAD=([c1]=words16 [c2]=tokens64 [c3]=utf8_lines [c3_raw]=utf8_lines [c3_k100]=utf8_lines [nw_words]=words16 [c4_linear]=protein4k [c4_affine]=protein4k [c4_bytes]=bytes4k [c5]=short_words)
-declare -A PAIRS=([c1]=10000 [c2]=1000000 [c3]=100000 [c3_raw]=100000 [c3_k100]=100000 [nw_words]=4000000 [c4_linear]=10000 [c4_affine]=10000 [c4_bytes]=2000 [c5]=20000000)
-declare -A VARIANT=([c1]="" [c2]="" [c3]=k32 [c3_raw]=k32 [c3_k100]=k100 [nw_words]=unary_linear [c4_linear]=linear [c4_affine]=affine [c4_bytes]=linear [c5]="")
+[ -f "$OUT/pmc_constants.json" ] || cp profiles/r5/pmc_constants.json "$OUT/pmc_constants.json" 2>/dev/null || cp profiles/r4/pmc_constants.json "$OUT/pmc_constants.json" 2>/dev/null
+LEGS=${*:-c2 c1 c3 c3_raw c3_raw_cold utf8_unbounded_raw c3_k100 c4_linear c4_affine c4_bytes c4_letters52 c5 nw_words}
+declare -A WORKLOAD=([c1]=words16 [c2]=tokens64 [c3]=utf8_lines [c3_raw]=utf8_lines [c3_raw_cold]=utf8_lines [utf8_unbounded_raw]=utf8_lines [c3_k100]=utf8_lines [nw_words]=words16 [c4_linear]=protein4k [c4_affine]=protein4k [c4_bytes]=bytes4k [c4_letters52]=bytes4k [c5]=short_words)
+declare -A PAIRS=([c1]=10000 [c2]=1000000 [c3]=100000 [c3_raw]=100000 [c3_raw_cold]=100000 [utf8_unbounded_raw]=100000 [c3_k100]=100000 [nw_words]=4000000 [c4_linear]=10000 [c4_affine]=10000 [c4_bytes]=2000 [c4_letters52]=2000 [c5]=20000000)
+declare -A VARIANT=([c1]="" [c2]="" [c3]=k32 [c3_raw]=k32 [c3_raw_cold]=k32 [utf8_unbounded_raw]=unbounded [c3_k100]=k100 [nw_words]=unary_linear [c4_linear]=linear [c4_affine]=affine [c4_bytes]=linear [c4_letters52]=letters52 [c5]="")
 CALLS=3
 # 1. PMC passes per config: exactly $CALLS engine calls each -> per-call totals in pmc_constants.json (stamped with a digest
 #    of the kernel's sources). c3_raw shares c3's dominant kernel and key; its pass is kept as a JSON summary only.
@@ -25,7 +25,7 @@ for leg in $LEGS; do
     tag=$(echo $set | cut -d' ' -f1)
     timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$dir" -o "$tag" -- python3 "$REPO/bench.py" --only-config $leg --calls $CALLS --no-cpu-baseline > "$dir/$tag.log" 2>&1
   done
-  if [ "$leg" != c3_raw ]; then
+  if [ "$leg" != c3_raw ] && [ "$leg" != c3_raw_cold ]; then   # (they share c3's dominant kernel and key: their passes are kept as JSON summaries only)
     python3 "$REPO/tools/pmc_constants.py" "$dir" --workload ${WORKLOAD[$leg]} --pairs ${PAIRS[$leg]} --calls $CALLS --variant "${VARIANT[$leg]}" --out "$OUT/pmc_constants.json" \
       --source "rocprofv3 --pmc passes over 'bench.py --only-config $leg --calls $CALLS --no-cpu-baseline' (tools/refresh_profiles.sh)"
   fi
@@ -51,11 +51,12 @@ stats bench_c2_full "$REPO/bench.py" --no-cpu-baseline --no-configs
 for leg in $LEGS; do stats leg_$leg "$REPO/bench.py" --only-config $leg --no-cpu-baseline; done
 # 3. the bench lines themselves, with the fresh constants in place
 cd "$REPO"
-mkdir -p profiles/r4 && cp "$OUT/pmc_constants.json" profiles/r4/pmc_constants.json
+mkdir -p profiles/r5 && cp "$OUT/pmc_constants.json" profiles/r5/pmc_constants.json
 timeout -k 10 600 python3 bench.py > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
 timeout -k 10 400 python3 bench.py --config c5 --steps 20 --warmup 2 --no-cpu-baseline --no-configs > "$OUT/bench_c5_100m.json" 2> "$OUT/bench_c5_100m.err"
 timeout -k 10 300 python3 tools/bench_cross.py > "$OUT/crossproduct_table.jsonl" 2> "$OUT/cross.err"
 timeout -k 10 300 python3 tools/bench_bounds.py > "$OUT/bounds_table.jsonl" 2> "$OUT/bounds.err"
 timeout -k 10 300 python3 tools/bench_bounds.py --bytes >> "$OUT/bounds_table.jsonl" 2>> "$OUT/bounds.err"
+timeout -k 10 600 python3 tools/bench_sizes.py > "$OUT/c2_sizes.jsonl" 2> "$OUT/c2_sizes.err"
 rm -rf "$OUT"/pmc_*/
 du -sh "$OUT"; ls "$OUT"

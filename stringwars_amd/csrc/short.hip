@@ -28,11 +28,15 @@ namespace swh {
 #ifndef SWH_SHORT_THREADS
 #define SWH_SHORT_THREADS 256
 #endif
-constexpr int kShortThreads = SWH_SHORT_THREADS, kShortWaves = kShortThreads / 64, kShortPer = 4;
+// (make EXTRA=-DSWH_SHORT_PER=2: chunks of 512 pairs, 28 KB of LDS, five workgroups per compute unit instead of four -- measured in round 5)
+#ifndef SWH_SHORT_PER
+#define SWH_SHORT_PER 4
+#endif
+constexpr int kShortThreads = SWH_SHORT_THREADS, kShortWaves = kShortThreads / 64, kShortPer = SWH_SHORT_PER;
 constexpr int kShortChunk = kShortThreads * kShortPer;   // pairs per chunk
 constexpr int kShortMaxLen = 16;
-constexpr int kShortCap = 6912 * kShortThreads / 256;      // bytes of one tape's segment a chunk may bring into LDS (432 units of 16; keeps the workgroup below 40 KB)
-constexpr int kShortPerCu = kShortThreads == 256 ? 4 : 13;   // workgroups a compute unit holds (LDS)
+constexpr int kShortCap = 6912 * kShortThreads / 256 * kShortPer / 4;      // bytes of one tape's segment a chunk may bring into LDS (432 units of 16; keeps the workgroup below 40 KB)
+constexpr int kShortPerCu = kShortThreads == 256 ? (kShortPer == 4 ? 4 : 5) : 13;   // workgroups a compute unit holds (LDS)
 constexpr int kShortPad = 16;        // before (tail windows reach back 8 bytes) and after (16-byte windows reach forward)
 constexpr int kShortKeys = 256;      // (text length - 1) * 16 + (pattern length - 1)
 

@@ -14,10 +14,12 @@ declare -A WORKLOAD=([c1]=words16 [c2]=tokens64 [c3]=utf8_lines [c3_raw]=utf8_li
 declare -A PAIRS=([c1]=10000 [c2]=1000000 [c3]=100000 [c3_raw]=100000 [c3_raw_cold]=100000 [utf8_unbounded_raw]=100000 [c3_k100]=100000 [nw_words]=4000000 [c4_linear]=10000 [c4_affine]=10000 [c4_bytes]=2000 [c4_letters52]=2000 [c5]=20000000)
 declare -A VARIANT=([c1]="" [c2]="" [c3]=k32 [c3_raw]=k32 [c3_raw_cold]=k32 [utf8_unbounded_raw]=unbounded [c3_k100]=k100 [nw_words]=unary_linear [c4_linear]=linear [c4_affine]=affine [c4_bytes]=linear [c4_letters52]=letters52 [c5]="")
 CALLS=3
+declare -A LEG_CALLS=([utf8_unbounded_raw]=9 [c3_k100]=9)   # two-stage calls: the first call of a scope runs in one stage (no lengths, no record yet) -- diluted
 # 1. PMC passes per config: exactly $CALLS engine calls each -> per-call totals in pmc_constants.json (stamped with a digest
 #    of the kernel's sources). c3_raw shares c3's dominant kernel and key; its pass is kept as a JSON summary only.
 cd /tmp && export TMPDIR=/tmp
 for leg in $LEGS; do
+  CALLS=${LEG_CALLS[$leg]:-3}
   dir="$OUT/pmc_$leg"; rm -rf "$dir"; mkdir -p "$dir"
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \

@@ -491,8 +491,26 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 slot.ascii = false;
                 return bytes;
             };
-            a_bytes = total_of(spec.a, dev_a_data, dev_a_off, scope->size_belief[0]);
-            b_bytes = same_tape ? a_bytes : total_of(spec.b, dev_b_data, dev_b_off, scope->size_belief[1]);
+            // (two device tapes the scope has no belief about: both totals in ONE round trip -- two copies, one wait -- instead of two)
+            const bool both_fresh = !same_tape && dev_a_off && dev_b_off && dev_a_data && dev_b_data &&
+                                    !(believe && utf8 && !spec.force_planned && (same_as_believed(spec.a, scope->size_belief[0]) || same_as_believed(spec.b, scope->size_belief[1])));
+            if (both_fresh) {
+                uint64_t *words = (uint64_t *)(scope->plan_host + 1) + 3;   // (pinned: bytes 24 .. 39 behind the plan; the UTF-8 flag words land in its first 20)
+                words[0] = words[1] = 0;
+                const size_t wa = spec.a.off64 ? 8 : 4, wb = spec.b.off64 ? 8 : 4;
+                SWH_HIP_CHECK(hipMemcpyAsync(&words[0], (const char *)spec.a.offsets + spec.a.count * wa, wa, hipMemcpyDeviceToHost, stream));
+                SWH_HIP_CHECK(hipMemcpyAsync(&words[1], (const char *)spec.b.offsets + spec.b.count * wb, wb, hipMemcpyDeviceToHost, stream));
+                SWH_HIP_CHECK(hipStreamSynchronize(stream));
+                a_bytes = words[0]; b_bytes = words[1];
+                auto remember = [](Scope::SizeBelief &slot, const HostTape &t, uint64_t bytes) {
+                    slot.data = t.data; slot.offsets = t.offsets; slot.count = t.count; slot.off64 = t.off64; slot.bytes = bytes; slot.valid = true; slot.ascii = false;
+                };
+                remember(scope->size_belief[0], spec.a, a_bytes);
+                remember(scope->size_belief[1], spec.b, b_bytes);
+            } else {
+                a_bytes = total_of(spec.a, dev_a_data, dev_a_off, scope->size_belief[0]);
+                b_bytes = same_tape ? a_bytes : total_of(spec.b, dev_b_data, dev_b_off, scope->size_belief[1]);
+            }
         }
         // device-resident outputs are written in place with the caller's strides; host outputs are produced
         // compactly in device staging and scattered into the caller's strides by a 2-D copy

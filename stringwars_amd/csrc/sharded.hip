@@ -560,7 +560,33 @@ static swh_status_t sharded_arguments(swh_scope_t handle, swh_sharded_t sharded,
 }
 
 // Alignment engines keep a substitution matrix (and its class table) on one device: a multi-device scope clones the engine
-// per member on first use (keyed by the engine's uid; the clones live as long as the scope).
+// per member on first use (keyed by the engine's uid; the clones live as long as the scope). The map is shared with drop_engine_clones
+// (an engine freed on another thread): looked up and published under g_multi_mutex, the callers work on a COPY of the pointers; the clones
+// are built and freed outside the lock (freeing one calls drop_engine_clones itself).
+static swh_status_t engine_clones_of(MultiScope *multi, const Engine *source, std::vector<void *> &out, const char **error) {
+    {
+        std::lock_guard<std::mutex> lock(g_multi_mutex);
+        auto it = multi->engine_clones.find(source->uid);
+        if (it != multi->engine_clones.end() && !it->second.empty()) { out = it->second; return swh_success_k; }
+    }
+    std::vector<void *> fresh(multi->members.size(), nullptr);
+    for (size_t r = 0; r < multi->members.size(); ++r) {
+        const swh_status_t status = clone_alignment_engine(source, multi->members[r], &fresh[r], error);
+        if (status != swh_success_k) {
+            for (void *clone : fresh) if (clone) swh_nw_free((swh_nw_t)clone);
+            return status;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_multi_mutex);
+        std::vector<void *> &slot = multi->engine_clones[source->uid];
+        if (slot.empty()) { slot = fresh; out = fresh; fresh.clear(); }
+        else out = slot;   // (another thread published its clones first)
+    }
+    for (void *clone : fresh) if (clone) swh_nw_free((swh_nw_t)clone);
+    return swh_success_k;
+}
+
 static swh_status_t alignment_sharded(int kind, void *engine, swh_scope_t handle, swh_sharded_t sharded, int32_t *out, const char **error) {
     swh_status_t status = sharded_arguments(handle, sharded, engine, error);
     if (status != swh_success_k) return status;
@@ -568,18 +594,9 @@ static swh_status_t alignment_sharded(int kind, void *engine, swh_scope_t handle
     if (source->kind != kind || !source->matrix_host) return sharded_fail(error, swh_invalid_argument_k, "not an engine of this kind");
     if (((ShardedPairs *)sharded)->utf8) return sharded_fail(error, swh_not_implemented_k, "substitution-matrix scoring over UTF-8 code points (the matrix is indexed by bytes)");
     MultiScope *multi = (MultiScope *)((Scope *)handle)->multi;
-    std::vector<void *> &clones = multi->engine_clones[source->uid];
-    if (clones.empty()) {
-        clones.assign(multi->members.size(), nullptr);
-        for (size_t r = 0; r < multi->members.size(); ++r) {
-            status = clone_alignment_engine(source, multi->members[r], &clones[r], error);
-            if (status != swh_success_k) {
-                for (void *clone : clones) if (clone) swh_nw_free((swh_nw_t)clone);
-                multi->engine_clones.erase(source->uid);
-                return status;
-            }
-        }
-    }
+    std::vector<void *> clones;
+    status = engine_clones_of(multi, source, clones, error);
+    if (status != swh_success_k) return status;
     ShardScore score = kind == 1
         ? (ShardScore)[](void *e, swh_scope_t m, const swh_prepared_view_t *a, const swh_prepared_view_t *b, uint32_t, uint32_t *dst, const char **err) {
               return swh_nw_pairs_prepared((swh_nw_t)e, m, a, b, (int32_t *)dst, 4, err); }
@@ -691,18 +708,9 @@ static swh_status_t cross_sharded(void *engine, int kind, swh_scope_t handle, sw
     std::vector<void *> engines(members, engine);
     if (kind != 0) {   // alignment engines: one clone per member (see alignment_sharded)
         const Engine *source = (const Engine *)engine;
-        std::vector<void *> &clones = multi->engine_clones[source->uid];
-        if (clones.empty()) {
-            clones.assign(members, nullptr);
-            for (size_t r = 0; r < members; ++r) {
-                swh_status_t status = clone_alignment_engine(source, multi->members[r], &clones[r], error);
-                if (status != swh_success_k) {
-                    for (void *clone : clones) if (clone) swh_nw_free((swh_nw_t)clone);
-                    multi->engine_clones.erase(source->uid);
-                    return status;
-                }
-            }
-        }
+        std::vector<void *> clones;
+        const swh_status_t status = engine_clones_of(multi, source, clones, error);
+        if (status != swh_success_k) return status;
         engines = clones;
     }
     auto stream_of = [&](size_t r) { return ((Scope *)multi->members[r])->stream; };

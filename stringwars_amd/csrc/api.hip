@@ -847,7 +847,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 flat.flat_staging = true;
                 return run_call_on(scope, engine, flat, error);
             }
-            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in an input tape (marker %u)", *invalid_host - 1);
+            snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in an input tape (marker %u: the string's index when staged string by string, else a 4-byte word inside the 1 KiB tile that failed)", *invalid_host - 1);
             if (error) *error = g_error_text;
             return swh_invalid_utf8_k;
         };
@@ -1382,7 +1382,7 @@ static swh_status_t prepare_tape(Scope *scope, const HostTape &tape, bool utf8, 
             if (decode_error != hipSuccess) throw HipFailure{decode_error, "UTF-8 decode"};
             if (host_words[4]) {
                 free_prepared(p);
-                snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in the tape (marker %u)", host_words[4] - 1);
+                snprintf(g_error_text, sizeof g_error_text, "invalid UTF-8 in the tape (marker %u: a 4-byte word inside the 1 KiB tile that failed)", host_words[4] - 1);
                 if (error) *error = g_error_text;
                 return swh_invalid_utf8_k;
             }

@@ -24,16 +24,22 @@
 // single word saturates near 88 dequeues/us (MI355X_MICROARCH.md "dequeue"), slower than the DP itself on
 // short items -- k_bitparallel_long, whose items take milliseconds, does use one.
 // Definition matched: `rapidfuzz::distance::levenshtein::distance` (bench.rs:416-419).
-#include "bp_item.hpp"
+#include "bp_dense.hpp"
 
 namespace swh {
+
+#ifdef SWH_TEST_HOOKS
+// (test library) [0]: items that ran on a dense alphabet, [1]: items whose dictionary overflowed and went to the group tables
+__device__ uint32_t g_dense_items[2];
+#endif
 
 // kBpWaves: waves per workgroup. Byte strings run ONE 16-wave workgroup per compute unit whose waves take the CU's share
 // of the items (item = blockIdx.x + turn * gridDim.x) from an LDS ticket: the hardware serves a CU's oldest waves first, so
 // with a fixed list per wave the youngest were left to finish theirs alone, one wave per SIMD -- the regime where this
 // serial recurrence issues at half rate (see tiled.hip). A ticket in LDS costs nothing next to an item (the global one
 // this kernel started with saturated at 88 dequeues per microsecond).
-template <typename Sym, int kBpWaves, bool kWide>
+// kDense: code-point items of kDenseMinBlocks blocks and more first try the per-pair dense alphabet (bp_dense.hpp).
+template <typename Sym, int kBpWaves, bool kWide, bool kDense>
 __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const uint64_t a_total, const uint64_t b_total) {
     constexpr int kBpTableWords = bp_table_words<Sym>();
     constexpr bool kTicket = kBpWaves > BpTraits<Sym>::kWaves;
@@ -55,7 +61,7 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
             if ((int)threadIdx.x >= off) incl += up;
         }
         item_prefix[threadIdx.x] = incl - mine;
-        if (threadIdx.x == 63) { item_prefix[64] = incl; item_prefix[66] = 0; }   // [66]: the workgroup's ticket
+        if (threadIdx.x == 63) { item_prefix[64] = incl; item_prefix[66] = 0; item_prefix[67] = 0; item_prefix[68] = 0; }   // [66]: the workgroup's ticket
     }
     __syncthreads();
     const uint32_t items_total = item_prefix[64];
@@ -88,20 +94,37 @@ __device__ __forceinline__ void bp_run(const KernelArgs &args, char *smem, const
             if (args.off64) pair_extent<uint64_t>(args.job, p, a0, la, b0, lb);
             else pair_extent<uint32_t>(args.job, p, a0, la, b0, lb);
         }
+        if constexpr (sizeof(Sym) == 4 && kDense) {
+            // (a workgroup whose items keep having too many symbols for their dictionaries -- lines of Chinese -- tries only every eighth: being
+            // sent away costs an item its pattern fetch and two LDS round trips before the group tables start over; [67] / [68] of the
+            // prefix array count the workgroup's items that ran dense / were sent away)
+            if (G >= kDenseMinBlocks) {
+                const uint32_t ran = item_prefix[67], failed = item_prefix[68];
+                bool dense = false;
+                if (failed < 3 || failed <= 2 * ran || (failed & 7u) == 0) {
+                    dense = bp_item_dense(args, wv, G, have, p, a0, la, b0, lb);
+#ifdef SWH_TEST_HOOKS
+                    if (lane == 0) atomicAdd(&g_dense_items[dense ? 0 : 1], 1u);
+#endif
+                }
+                if (lane == 0) __hip_atomic_fetch_add(&item_prefix[dense ? 67 : 68], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dense) continue;
+            }
+        }
         bp_item<Sym, kWide>(args, wv, G, have, p, a0, la, b0, lb);
     }
 }
 
-template <typename Sym, int kBpWaves>
+template <typename Sym, int kBpWaves, bool kDense = true>
 __global__ __launch_bounds__(kBpWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel(KernelArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint64_t a_total = tape_total(args.job.a, args.off64);
     const uint64_t b_total = tape_total(args.job.b, args.off64);
     if constexpr (sizeof(Sym) == 1) {
-        if (a_total >= 16 && b_total >= 16) bp_run<Sym, kBpWaves, true>(args, smem, a_total, b_total);
-        else bp_run<Sym, kBpWaves, false>(args, smem, a_total, b_total);
+        if (a_total >= 16 && b_total >= 16) bp_run<Sym, kBpWaves, true, false>(args, smem, a_total, b_total);
+        else bp_run<Sym, kBpWaves, false, false>(args, smem, a_total, b_total);
     } else {
-        bp_run<Sym, kBpWaves, false>(args, smem, a_total, b_total);
+        bp_run<Sym, kBpWaves, false, kDense>(args, smem, a_total, b_total);
     }
 }
 
@@ -341,7 +364,7 @@ void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_hos
     SWH_HIP_CHECK(hipGetLastError());
 }
 
-template <typename Sym, int kWaves>
+template <typename Sym, int kWaves, bool kDense = true>
 static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     // The work list lives in the device plan; the host only bounds the grid (an item holds >= 1 pair).
     constexpr size_t lds = (size_t)kWaves * (bp_table_words<Sym>() + 64) * 4 + 80 * 4;
@@ -352,9 +375,9 @@ static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_
     const uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
     uint32_t max_blocks = (uint32_t)scope->compute_units * (per_cu ? per_cu : 1u);
     uint32_t blocks = blocks64 > max_blocks ? max_blocks : (uint32_t)blocks64;
-    opt_in_dynamic_lds(scope, (const void *)k_bitparallel<Sym, kWaves>, lds);
+    opt_in_dynamic_lds(scope, (const void *)k_bitparallel<Sym, kWaves, kDense>, lds);
     StampGuard guard(scope, sizeof(Sym) == 1 ? "bitparallel" : "bitparallel_u32");
-    hipLaunchKernelGGL((k_bitparallel<Sym, kWaves>), dim3(blocks), dim3(kWaves * 64), lds, scope->stream, k);
+    hipLaunchKernelGGL((k_bitparallel<Sym, kWaves, kDense>), dim3(blocks), dim3(kWaves * 64), lds, scope->stream, k);
     SWH_HIP_CHECK(hipGetLastError());
 }
 
@@ -366,9 +389,21 @@ void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs) {
         // 14.25 KB of tables and accumulators per wave: eleven waves are what a CU's 160 KB hold, with 2.9 KB to spare. Code points
         // are latency-bound (seven dependent look-ups per column): 8 / 10 / 11 waves measure 1.31 / 1.13 / 1.05 ms on C3's lines.
         // (Bytes are issue-bound: two workgroups of nine waves lose 8 % against the one of sixteen.)
+#ifdef SWH_TEST_HOOKS
+        else if (const char *e = test_hook("STRINGWARS_AMD_BP_DENSE"); e && e[0] == '0') launch_bitparallel_sym<uint32_t, 11, false>(scope, args, pairs);   // the group tables for every item: the tests' second implementation
+#endif
         else launch_bitparallel_sym<uint32_t, 11>(scope, args, pairs);
     } else if (forced == 4) launch_bitparallel_sym<uint8_t, 4>(scope, args, pairs);
     else launch_bitparallel_sym<uint8_t, 16>(scope, args, pairs);
 }
 
 }  // namespace swh
+
+#ifdef SWH_TEST_HOOKS
+// (test library) reads and zeroes the current device's dense-alphabet item counters
+extern "C" int swh_test_dense_items(uint32_t out[2]) {
+    const uint32_t zero[2] = {0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(swh::g_dense_items), sizeof zero) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(swh::g_dense_items), zero, sizeof zero) != hipSuccess;
+}
+#endif

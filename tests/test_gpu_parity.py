@@ -2623,3 +2623,75 @@ def test_golden_words_alignment_rows(sw, scope):
             assert (engine.pairs(a, b, scope) == want).all() and (engine.pairs(a, b, scope) == want).all(), (kind, tag, "raw tapes, twice")
             cross = engine(sw.PreparedTape(scope, a.subview(0, 16)), sw.PreparedTape(scope, b.subview(0, 16)), scope)
             assert (cross == z[f"words16.cross16.{kind}_unary_{tag}"]).all(), (kind, tag, "cross-product")
+
+
+def test_code_point_items_on_a_dense_alphabet(sw, orc, request):
+    """bp_dense.hpp: a code-point work item of 16 blocks and more gives the distinct symbols of each pair's pattern 8-bit ids (the slot
+    of a 255-slot dictionary in LDS that takes a symbol is its id) and then runs on the byte kernel's nibble tables; text symbols the
+    pattern does not hold translate to the id with the empty match vector; a pattern of more than 255 distinct symbols overflows the
+    dictionary and the item goes to the seven group tables as before. `LevenshteinDistancesUtf8`, bench.rs:386-399: lines of 481 ...
+    2048 code points over alphabets of 2 / 32 / ~190 / 230 / 251 / 256 / 3000 symbols, the edges of every UTF-8 length, related and
+    unrelated pairs, shorter and longer strings around them. (Test library: its kernel counts the items of either kind.)"""
+    if not run_in_child(request, test_library=True):
+        return
+    import ctypes as C
+    from stringwars_amd import _native as N
+    scope = sw.DeviceScope(gpu_device=0)
+    rng = np.random.default_rng(77)
+    edges = [0, 1, 0x7F, 0x80, 0x7FF, 0x800, 0xD7FF, 0xE000, 0xFFFF, 0x10000, 0x10FFFF]
+    pools = {
+        "two": [0x430, 0x1F600],
+        "few": list(range(0x430, 0x450)),
+        "text": list(range(0x20, 0x7F)) + list(range(0x400, 0x460)),
+        "edges": edges + list(range(0x3040, 0x3040 + 60)),
+        "230": list(range(0x4E00, 0x4E00 + 230)),
+        "251": list(range(0x4E00, 0x4E00 + 251)),
+        "256": list(range(0x4E00, 0x4E00 + 256)),
+        "many": list(range(0x4E00, 0x4E00 + 3000)),
+    }
+    def draw(pool, n, cover=False):
+        picks = rng.choice(pool, n)
+        if cover and n >= len(pool):
+            picks[rng.permutation(n)[: len(pool)]] = pool      # every symbol of the pool at least once
+        return "".join(chr(int(c)) for c in picks)
+    def edit(s, pool, edits):
+        out = list(s)
+        for _ in range(edits):
+            at = int(rng.integers(0, len(out) + 1))
+            kind = int(rng.integers(0, 3))
+            if kind == 0 and out: out.pop(min(at, len(out) - 1))
+            elif kind == 1: out.insert(at, chr(int(rng.choice(pool))))
+            elif out: out[min(at, len(out) - 1)] = chr(int(rng.choice(pool)))
+        return "".join(out)
+    items_a, items_b, kinds = [], [], []
+    for name, pool in pools.items():
+        for n in (481, 512, 513, 700, 1000, 1024, 1500, 2047, 2048, 300, 2100):
+            for variant in range(3):
+                s = draw(pool, n, cover=True)
+                if variant == 0: t = edit(s, pool, int(rng.integers(0, 40)))                     # related, same alphabet
+                elif variant == 1: t = draw(pool, int(rng.integers(max(1, n - 200), n + 200)))   # unrelated, same alphabet
+                else: t = edit(s, pools["text"], int(rng.integers(20, 200)))                     # symbols the other side does not hold
+                items_a.append(s); items_b.append(t); kinds.append(name)
+    order = rng.permutation(len(items_a))
+    a, b = sw.Strs([items_a[i] for i in order]), sw.Strs([items_b[i] for i in order])
+    want = orc.levenshtein_pairs(a, b, utf8=True)
+    counts = (C.c_uint32 * 2)()
+    N.lib.swh_test_dense_items.argtypes = [C.POINTER(C.c_uint32)]
+    assert N.lib.swh_test_dense_items(counts) == 0
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    for tapes in ((a, b), (sw.PreparedTape(scope, a, utf8=True), sw.PreparedTape(scope, b, utf8=True))):
+        got = engine.pairs(*tapes, scope)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], [kinds[order[i]] for i in bad[:5]])
+        assert N.lib.swh_test_dense_items(counts) == 0
+        assert counts[0] > 30 and counts[1] > 10, list(counts)          # both kinds of item ran: the dense ones and the overflowing ones
+    for bound in (0, 31, 200, 5000):                                    # (bounds beyond the band kernels' clamp what the blocks return)
+        assert (engine.pairs(a, b, scope, bound=bound) == np.minimum(want, bound + 1)).all(), bound
+    # the same batch with the dense alphabet switched off: the group tables alone give the same distances
+    os.environ["STRINGWARS_AMD_BP_DENSE"] = "0"
+    try:
+        assert N.lib.swh_test_dense_items(counts) == 0                  # (zeroes the counters)
+        assert (engine.pairs(a, b, scope) == want).all()
+        assert N.lib.swh_test_dense_items(counts) == 0 and counts[0] == 0 and counts[1] == 0, list(counts)
+    finally:
+        del os.environ["STRINGWARS_AMD_BP_DENSE"]

@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, "stringwars_amd", "csrc")
 # stamp name used by the library's timing (swh_timing_t::dominant_name) -> (substring of the kernel symbol, sources)
 KERNELS = {
     "bitparallel": ("swh::k_bitparallel<unsigned char,", ("bitparallel.hip", "bp_item.hpp", "bp_window.hpp", "common.hpp")),
-    "bitparallel_u32": ("swh::k_bitparallel<unsigned int,", ("bitparallel.hip", "bp_item.hpp", "bp_window.hpp", "common.hpp")),
+    "bitparallel_u32": ("swh::k_bitparallel<unsigned int,", ("bitparallel.hip", "bp_item.hpp", "bp_dense.hpp", "bp_window.hpp", "common.hpp")),
     "bitparallel_tiled": ("swh::k_bitparallel_tiled<unsigned char,", ("tiled.hip", "bp_item.hpp", "bp_window.hpp", "common.hpp")),
     "bitparallel_tiled_u32": ("swh::k_bitparallel_tiled<unsigned int,", ("tiled.hip", "bp_item.hpp", "bp_window.hpp", "common.hpp")),
     "bitparallel_long": ("swh::k_bitparallel_long<unsigned char", ("bitparallel.hip", "bp_item.hpp", "bp_window.hpp", "common.hpp")),

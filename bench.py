@@ -98,6 +98,11 @@ LEGS = {
     "c3_raw_cold": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, cold=3, variant="k32", check=1_000,
                         text="C3 on raw device tapes the scope has not seen in its previous call (three copies of the tapes in turn: the library's "
                              "beliefs about a tape's byte total and its ASCII-ness never apply)"),
+    "utf8_unrelated_raw": dict(workload="script_lines", pairs=50_000, kind="lev_utf8", prepared=False, variant="unbounded", check=500,
+                               text="UNRELATED article lines of 700-1300 code points, one script each (Latin / Cyrillic / Greek / Arabic / Devanagari), unbounded "
+                                    "Levenshtein over code points on raw device tapes: what the reference's cross-product of XLSum lines pairs up for "
+                                    "LevenshteinDistancesUtf8 (bench.rs:386-399, similarities/README.md:18, :39-40) -- nothing for a band to settle; the "
+                                    "block kernel on per-pair dense alphabets (bp_dense.hpp)"),
     "c4_linear": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=128,
                       text="C4: NW, 256x256 i8 matrix (20 amino acids + other), 10 K pairs ~4 KB, linear gaps -4"),
     "c4_affine": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-11, -1), prepared=True, variant="affine", check=128,
@@ -116,7 +121,7 @@ LEGS = {
                      text="NW on word-sized strings (the reference's default `words` token mode, bench.rs:271): 4 M pairs <= 16 B, "
                           "unary_class_costs(2, -1) as a 32-class table, linear gaps -2 -- one pair per lane (alignshort.hip)"),
 }
-DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words"]
+DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words"]
 
 
 def parse_args():

@@ -26,6 +26,9 @@ typedef enum swh_workload_t {
     swh_workload_utf8_lines_k = 3,    /* C3: ~1 KB UTF-8 lines, script mix, b = a with U[0,64] code-point edits */
     swh_workload_protein4k_k = 4,     /* C4: lengths U[3072,5120], 20 amino-acid letters, 15% edits */
     swh_workload_short_words_k = 5,   /* C5: word lengths 1..16, mean ~6, a-z, as C1 */
+    swh_workload_script_lines_k = 6,  /* article lines, ONE script each (Latin / Cyrillic / Greek / Arabic / Devanagari letters 80 %, ASCII spaces,
+                                         punctuation, digits 20 %), U[700,1300] code points, a and b INDEPENDENT: what a cross-product of
+                                         XLSum lines pairs up (similarities/README.md:18, :39-40) */
     swh_workload_bytes4k_k = 40       /* C4 variant: full 0..255 byte alphabet */
 } swh_workload_t;
 

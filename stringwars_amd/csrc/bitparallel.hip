@@ -29,8 +29,9 @@
 namespace swh {
 
 #ifdef SWH_TEST_HOOKS
-// (test library) [0]: items that ran on a dense alphabet, [1]: items whose dictionary overflowed and went to the group tables
-__device__ uint32_t g_dense_items[2];
+// (test library) [0]: items that ran on a dense alphabet, [1]: items that were sent away / whose dictionary overflowed and went to the
+// group tables; [2] / [3]: the same for the passes of k_bitparallel_long<u32>
+__device__ uint32_t g_dense_items[4];
 #endif
 
 // kBpWaves: waves per workgroup. Byte strings run ONE 16-wave workgroup per compute unit whose waves take the CU's share
@@ -134,18 +135,31 @@ __global__ __launch_bounds__(kBpWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) voi
 // bit per text column) are parked in a per-wave carry array and fed to the next pass's first block in place of the
 // DP boundary. 32 columns per word, shifted in from the top by lane 63 and shifted out from the bottom by lane 0.
 // ------------------------------------------------------------------------------------------------------------
-template <typename Sym>
+template <typename Window>
+__device__ __forceinline__ uint32_t window_symbol(const Window &w, int idx) {   // (code-point windows only; the byte kernel never calls it)
+    if constexpr (std::is_same<Window, SymWindow32>::value) return w.fetch(idx);
+    else return 0;
+}
+
+// Code points (kDense): a pass runs on the pair's dense alphabet (bp_dense.hpp) as long as the pattern's symbols so far fit its
+// dictionary -- the dictionary and the sketch stay in LDS from pass to pass (a symbol that an earlier pass entered keeps its id, a
+// text symbol that only a LATER pass's blocks hold finds this pass's nibble tables empty for its id); from the pass that does not
+// fit on, the pair runs on the group tables.
+template <typename Sym, bool kDense = true>
 __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel_long(KernelArgs args) {
     constexpr int kBpWaves = BpTraits<Sym>::kWaves, kBpTableWords = bp_table_words<Sym>();
     constexpr bool kBytes = sizeof(Sym) == 1;
+    constexpr bool kTryDense = !kBytes && kDense;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     uint32_t *table = (uint32_t *)smem + (size_t)wave_in_block * kBpTableWords;  // [entries][64 lanes]
     [[maybe_unused]] NibbleTables nib;
     [[maybe_unused]] GroupTables3 grp;
+    [[maybe_unused]] DenseRegion dense;
     if constexpr (kBytes) nib.init(table, lane);
     else grp.init(table, lane);
+    if constexpr (kTryDense) dense.init(table, lane);
 #pragma unroll
     for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
     const uint32_t cstart = args.plan->class_start[kClassBpLong], ccount = args.plan->class_count[kClassBpLong];
@@ -187,6 +201,7 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                  a_is_pattern ? b_total : a_total);
         const uint32_t blocks_total = (m + 31) >> 5, passes = (blocks_total + 63) >> 6;
         int part = 0;   // my blocks' share of the vertical deltas in the last column
+        [[maybe_unused]] bool dense_ok = kTryDense;   // (wave-uniform) the pattern's symbols so far fit the pair's dictionary
 
         for (uint32_t pass = 0; pass < passes; ++pass) {
             const uint32_t blocks_here = blocks_total - pass * 64 < 64 ? blocks_total - pass * 64 : 64;
@@ -196,27 +211,141 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
             const bool record = pass + 1 < passes;   // a full pass of 64 blocks: lane 63 leaves the carries
             const uint32_t *cin_ph = carry + (size_t)((pass + 1) & 1) * 2 * cwords, *cin_mh = cin_ph + cwords;
             uint32_t *cout_ph = carry + (size_t)(pass & 1) * 2 * cwords, *cout_mh = cout_ph + cwords;
+            const uint32_t n_eff = n + blocks_here - 1;
+            const uint32_t steps = (n_eff + 15) & ~15u;
 
-            constexpr int kTextRegs = kBytes ? 4 : 16;
-            uint32_t tnxt[kTextRegs];
-            int tshift[kBytes ? 4 : 1];
-            auto fetch_text = [&](int first) {
-                if constexpr (kBytes) {
+            // The pass's columns. kDensePass: the text arrives as ids through the pair's ring (sixteen lanes translate a symbol each per
+            // round of sixteen steps), the match vectors come from the nibble tables; else every lane fetches its own text and looks it
+            // up in the byte / group tables. `text_ahead` / `text_ahead2`: what was requested before the tables were built.
+            auto columns = [&](auto dense_tag, uint32_t (&tnxt)[kBytes ? 4 : 16], int (&tshift)[kBytes ? 4 : 1], uint32_t tsym_next) {
+                constexpr bool kDensePass = decltype(dense_tag)::value;
+                constexpr int kTextRegs = kBytes ? 4 : 16;
+                [[maybe_unused]] const uint32_t *const dict = kTryDense ? dense.dicts : nullptr;
+                [[maybe_unused]] uint8_t *const ring = kTryDense ? dense.rings : nullptr;
+                [[maybe_unused]] const bool translator = lane < 16;
+                auto fetch_text = [&](int first) {
+                    if constexpr (kBytes) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4_raw(first + q * 4, tshift[q]);
-                } else {
+                        for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4_raw(first + q * 4, tshift[q]);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 16; q += 4) {
-                        uint32_t four[4];
-                        txt.fetch4(first + q, four);
+                        for (int q = 0; q < 16; q += 4) {
+                            uint32_t four[4];
+                            txt.fetch4(first + q, four);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) tnxt[q + r] = four[r];
+                            for (int r = 0; r < 4; ++r) tnxt[q + r] = four[r];
+                        }
+                    }
+                };
+                uint32_t cw_ph = 0, cw_mh = 0, cw_ph_next = 0, cw_mh_next = 0;   // carries entering lane 0, 32 columns per word
+                if (pass) {
+                    cw_ph_next = __hip_atomic_load(cin_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cw_mh_next = __hip_atomic_load(cin_mh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                uint32_t ow_ph = 0, ow_mh = 0;   // carries leaving lane 63
+                uint32_t pv = 0xFFFFFFFFu, mv = 0, ph = 0, mh = 0;
+                for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
+                    [[maybe_unused]] uint32_t tcur[kTextRegs];
+                    [[maybe_unused]] uint32_t ids[4];
+                    [[maybe_unused]] uint32_t coming = 0, first_slot = 0, first_key = 0;
+                    if constexpr (kDensePass) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ids[q] = dense_ring_ids(ring, s0 + 4 * q - (uint32_t)lane);
+                        coming = tsym_next;
+                        if (translator) tsym_next = window_symbol(txt, (int)s0 + 32 + lane);
+                        first_slot = dense_hash(coming);
+                        first_key = dict[first_slot];
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < kTextRegs; ++q) {
+                            if constexpr (kBytes) tcur[q] = ByteWindow::realign(tnxt[q], tshift[q]);
+                            else tcur[q] = tnxt[q];
+                        }
+                        fetch_text((int)s0 + 16 - lane);
+                    }
+                    if (pass && (s0 & 31u) == 0) {   // lane 0 is at column s0: the word for columns s0 .. s0 + 31
+                        cw_ph = cw_ph_next;
+                        cw_mh = cw_mh_next;
+                        const uint32_t nxt = (s0 >> 5) + 1 < cwords ? (s0 >> 5) + 1 : cwords - 1;
+                        cw_ph_next = __hip_atomic_load(cin_ph + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        cw_mh_next = __hip_atomic_load(cin_mh + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t gs = s0 + q * 4;
+                        if (gs >= n_eff) break;  // wave-uniform
+                        uint32_t eqs[4];
+                        if constexpr (kDensePass) {
+                            eqs[0] = dense.nib.template lookup<0>(ids[q]);
+                            eqs[1] = dense.nib.template lookup<1>(ids[q]);
+                            eqs[2] = dense.nib.template lookup<2>(ids[q]);
+                            eqs[3] = dense.nib.template lookup<3>(ids[q]);
+                        } else if constexpr (kBytes) {
+                            eqs[0] = nib.template lookup<0>(tcur[q]);
+                            eqs[1] = nib.template lookup<1>(tcur[q]);
+                            eqs[2] = nib.template lookup<2>(tcur[q]);
+                            eqs[3] = nib.template lookup<3>(tcur[q]);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) eqs[u] = grp.lookup(tcur[q * 4 + u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t s = gs + u;
+                            // what enters block 64 * pass in column s: the DP boundary (+1) or the previous pass's carries
+                            uint32_t in_ph = 0x80000000u, in_mh = 0;
+                            if (pass) {   // uniform
+                                in_ph = cw_ph << 31; in_mh = cw_mh << 31;
+                                cw_ph >>= 1; cw_mh >>= 1;
+                            }
+                            uint32_t ph_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ph, 0x138, 0xf, 0xf, true);
+                            uint32_t mh_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x138, 0xf, 0xf, true);
+                            ph_in = (uint32_t)__builtin_amdgcn_bitop3_b32((int)ph_in, (int)keep_mask, (int)in_ph, 0xE2);  // (a & b) | (c & ~b)
+                            mh_in = (uint32_t)__builtin_amdgcn_bitop3_b32((int)mh_in, (int)keep_mask, (int)in_mh, 0xE2);
+                            if (my_block && s - (uint32_t)lane < n) {
+                                uint32_t eq = eqs[u];
+                                uint32_t xv = eq | mv;
+                                eq |= mh_in >> 31;
+                                uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+                                ph = mv | ~(xh | pv);
+                                mh = pv & xh;
+                                uint32_t ph_s = __builtin_amdgcn_alignbit(ph, ph_in, 31);
+                                uint32_t mh_s = __builtin_amdgcn_alignbit(mh, mh_in, 31);
+                                pv = mh_s | ~(xv | ph_s);
+                                mv = ph_s & xv;
+                                if (record) {   // uniform; only lane 63's words are stored
+                                    ow_ph = (ow_ph >> 1) | (ph & 0x80000000u);
+                                    ow_mh = (ow_mh >> 1) | (mh & 0x80000000u);
+                                }
+                            }
+                            // lane 63 has just finished column s - 63: a word is complete every 32 columns
+                            if (record && s >= 63 && ((s - 63) & 31u) == 31u && s - 63 < n && lane == 63) {
+                                cout_ph[(s - 63) >> 5] = ow_ph;
+                                cout_mh[(s - 63) >> 5] = ow_mh;
+                            }
+                        }
+                    }
+                    if constexpr (kDensePass) {
+                        if (translator) dense_ring_put(ring, s0 + 16 + (uint32_t)lane, dense_translate(dict, coming, first_slot, first_key));
+                        wave_lds_fence();   // the ring's new ids are read from the next round on
                     }
                 }
+                if (record && (n & 31u) && lane == 63) {   // the last, partial word: bits sit at the top
+                    cout_ph[n >> 5] = ow_ph >> (32 - (n & 31u));
+                    cout_mh[n >> 5] = ow_mh >> (32 - (n & 31u));
+                }
+                const uint32_t mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
+                part += __popc(pv & mask) - __popc(mv & mask);
             };
-            fetch_text(0 - lane);
-            // ---- match tables of my block ------------------------------------------------------------------
+
+            uint32_t tnxt[kBytes ? 4 : 16];
+            int tshift[kBytes ? 4 : 1];
+            bool dense_pass = false;
             if constexpr (kBytes) {
+                // ---- match tables of my block ------------------------------------------------------------------
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tnxt[q] = txt.fetch4_raw(0 - lane + q * 4, tshift[q]);
                 uint32_t praw[8];
                 int pshift[8];
 #pragma unroll
@@ -232,6 +361,7 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
                         nib.template insert<3>(dw, row_mask & (1u << (q * 4 + 3)));
                     }
                 }
+                columns(std::false_type{}, tnxt, tshift, 0u);
             } else {
                 uint32_t psym[32];
 #pragma unroll
@@ -241,93 +371,60 @@ __global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWave
 #pragma unroll
                     for (int r = 0; r < 4; ++r) psym[q + r] = four[r];
                 }
+                if constexpr (kTryDense) {
+                    if (dense_ok) {
+                        uint32_t *const dict = dense.dicts, *const sketch = dense.dicts + 256;   // (one pair per wave: the second dictionary's place)
+                        const bool translator = lane < 16;
+                        const uint32_t tsym = translator ? txt.fetch(lane) : 0u, tsym_next = translator ? txt.fetch(16 + lane) : 0u;
+                        dense_sketch_add(sketch, psym, brows);
+                        wave_lds_fence();
+                        uint32_t pid[8];
+                        if (__ballot(dense_sketch_bits(sketch) > kDenseSketchBits) || dense_enter(dict, psym, brows, pid)) {
+                            dense_ok = false;   // from here on the group tables: what the dense passes left in LDS goes
+                            wave_lds_fence();
 #pragma unroll
-                for (int q = 0; q < 32; ++q)
-                    if ((uint32_t)q < brows) grp.insert(psym[q], 1u << q);
-            }
-            const uint32_t n_eff = n + blocks_here - 1;
-            const uint32_t steps = (n_eff + 15) & ~15u;
-            uint32_t cw_ph = 0, cw_mh = 0, cw_ph_next = 0, cw_mh_next = 0;   // carries entering lane 0, 32 columns per word
-            if (pass) {
-                cw_ph_next = __hip_atomic_load(cin_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cw_mh_next = __hip_atomic_load(cin_mh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            uint32_t ow_ph = 0, ow_mh = 0;   // carries leaving lane 63
-            uint32_t pv = 0xFFFFFFFFu, mv = 0, ph = 0, mh = 0;
-            for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
-                uint32_t tcur[kTextRegs];
-#pragma unroll
-                for (int q = 0; q < kTextRegs; ++q) {
-                    if constexpr (kBytes) tcur[q] = ByteWindow::realign(tnxt[q], tshift[q]);
-                    else tcur[q] = tnxt[q];
-                }
-                fetch_text((int)s0 + 16 - lane);
-                if (pass && (s0 & 31u) == 0) {   // lane 0 is at column s0: the word for columns s0 .. s0 + 31
-                    cw_ph = cw_ph_next;
-                    cw_mh = cw_mh_next;
-                    const uint32_t nxt = (s0 >> 5) + 1 < cwords ? (s0 >> 5) + 1 : cwords - 1;
-                    cw_ph_next = __hip_atomic_load(cin_ph + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    cw_mh_next = __hip_atomic_load(cin_mh + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t gs = s0 + q * 4;
-                    if (gs >= n_eff) break;  // wave-uniform
-                    uint32_t eqs[4];
-                    if constexpr (kBytes) {
-                        eqs[0] = nib.template lookup<0>(tcur[q]);
-                        eqs[1] = nib.template lookup<1>(tcur[q]);
-                        eqs[2] = nib.template lookup<2>(tcur[q]);
-                        eqs[3] = nib.template lookup<3>(tcur[q]);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) eqs[u] = grp.lookup(tcur[q * 4 + u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t s = gs + u;
-                        // what enters block 64 * pass in column s: the DP boundary (+1) or the previous pass's carries
-                        uint32_t in_ph = 0x80000000u, in_mh = 0;
-                        if (pass) {   // uniform
-                            in_ph = cw_ph << 31; in_mh = cw_mh << 31;
-                            cw_ph >>= 1; cw_mh >>= 1;
-                        }
-                        uint32_t ph_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ph, 0x138, 0xf, 0xf, true);
-                        uint32_t mh_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x138, 0xf, 0xf, true);
-                        ph_in = (uint32_t)__builtin_amdgcn_bitop3_b32((int)ph_in, (int)keep_mask, (int)in_ph, 0xE2);  // (a & b) | (c & ~b)
-                        mh_in = (uint32_t)__builtin_amdgcn_bitop3_b32((int)mh_in, (int)keep_mask, (int)in_mh, 0xE2);
-                        if (my_block && s - (uint32_t)lane < n) {
-                            uint32_t eq = eqs[u];
-                            uint32_t xv = eq | mv;
-                            eq |= mh_in >> 31;
-                            uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-                            ph = mv | ~(xh | pv);
-                            mh = pv & xh;
-                            uint32_t ph_s = __builtin_amdgcn_alignbit(ph, ph_in, 31);
-                            uint32_t mh_s = __builtin_amdgcn_alignbit(mh, mh_in, 31);
-                            pv = mh_s | ~(xv | ph_s);
-                            mv = ph_s & xv;
-                            if (record) {   // uniform; only lane 63's words are stored
-                                ow_ph = (ow_ph >> 1) | (ph & 0x80000000u);
-                                ow_mh = (ow_mh >> 1) | (mh & 0x80000000u);
-                            }
-                        }
-                        // lane 63 has just finished column s - 63: a word is complete every 32 columns
-                        if (record && s >= 63 && ((s - 63) & 31u) == 31u && s - 63 < n && lane == 63) {
-                            cout_ph[(s - 63) >> 5] = ow_ph;
-                            cout_mh[(s - 63) >> 5] = ow_mh;
+                            for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
+                            wave_lds_fence();
+                        } else {
+                            dense_pass = true;
+                            dense_rows_in(dense.nib, pid, brows);
+                            wave_lds_fence();
+                            if (translator) dense_ring_put(dense.rings, (uint32_t)lane, dense_translate(dict, tsym, dense_hash(tsym), dict[dense_hash(tsym)]));
+                            wave_lds_fence();
+                            columns(std::true_type{}, tnxt, tshift, tsym_next);
                         }
                     }
                 }
-            }
-            if (record && (n & 31u) && lane == 63) {   // the last, partial word: bits sit at the top
-                cout_ph[n >> 5] = ow_ph >> (32 - (n & 31u));
-                cout_mh[n >> 5] = ow_mh >> (32 - (n & 31u));
-            }
-            const uint32_t mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
-            part += __popc(pv & mask) - __popc(mv & mask);
+                if (!dense_pass) {
 #pragma unroll
-            for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
+                    for (int q = 0; q < 16; q += 4) {
+                        uint32_t four[4];
+                        txt.fetch4(0 - lane + q, four);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tnxt[q + r] = four[r];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 32; ++q)
+                        if ((uint32_t)q < brows) grp.insert(psym[q], 1u << q);
+                    columns(std::false_type{}, tnxt, tshift, 0u);
+                }
+            }
+#ifdef SWH_TEST_HOOKS
+            if (!kBytes && lane == 0) atomicAdd(&g_dense_items[dense_pass ? 2 : 3], 1u);
+#endif
+            bool tables_cleared = false;
+            if constexpr (kTryDense) {
+                if (dense_pass && pass + 1 < passes) {
+                    // the next pass keeps the dictionary and the sketch: only the nibble tables go (the ring is rewritten before it is read)
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) dense.nib_words[k * 64 + lane] = 0;
+                    tables_cleared = true;
+                }
+            }
+            if (!tables_cleared) {
+#pragma unroll
+                for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
+            }
             __builtin_amdgcn_s_waitcnt(0);   // carries are in memory before the next pass asks for them
             wave_lds_fence();
         }
@@ -358,6 +455,14 @@ void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_hos
         opt_in_dynamic_lds(scope, (const void *)k_bitparallel_long<uint8_t>, lds);
         hipLaunchKernelGGL(k_bitparallel_long<uint8_t>, dim3(blocks), dim3(waves * 64), lds, scope->stream, args);
     } else {
+#ifdef SWH_TEST_HOOKS
+        if (const char *e = test_hook("STRINGWARS_AMD_BP_DENSE"); e && e[0] == '0') {   // the group tables for every pass: the tests' second implementation
+            opt_in_dynamic_lds(scope, (const void *)k_bitparallel_long<uint32_t, false>, lds);
+            hipLaunchKernelGGL((k_bitparallel_long<uint32_t, false>), dim3(blocks), dim3(waves * 64), lds, scope->stream, args);
+            SWH_HIP_CHECK(hipGetLastError());
+            return;
+        }
+#endif
         opt_in_dynamic_lds(scope, (const void *)k_bitparallel_long<uint32_t>, lds);
         hipLaunchKernelGGL(k_bitparallel_long<uint32_t>, dim3(blocks), dim3(waves * 64), lds, scope->stream, args);
     }
@@ -401,8 +506,8 @@ void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs) {
 
 #ifdef SWH_TEST_HOOKS
 // (test library) reads and zeroes the current device's dense-alphabet item counters
-extern "C" int swh_test_dense_items(uint32_t out[2]) {
-    const uint32_t zero[2] = {0, 0};
+extern "C" int swh_test_dense_items(uint32_t out[4]) {
+    const uint32_t zero[4] = {0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(swh::g_dense_items), sizeof zero) != hipSuccess) return 1;
     return hipMemcpyToSymbol(HIP_SYMBOL(swh::g_dense_items), zero, sizeof zero) != hipSuccess;
 }

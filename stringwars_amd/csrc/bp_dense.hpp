@@ -50,69 +50,46 @@ __device__ __forceinline__ uint32_t dense_next(uint32_t h, uint32_t step) {
     return n >= kDenseSlots ? n - kDenseSlots : n;
 }
 
-// Returns false (wave-uniform) when a pair of the item has more distinct pattern symbols than a dictionary holds; the wave's
-// tables are all zero again then, as they are after an item that ran.
-__device__ __forceinline__ bool bp_item_dense(const KernelArgs &args, BpWave<uint32_t> &wv, const uint32_t G, const bool have, const uint64_t p,
-                                              const uint64_t a0, const uint32_t la, const uint64_t b0, const uint32_t lb) {
-    const int lane = wv.lane;
-    uint32_t *const acc = wv.acc;
-    // the wave's 14 KB: [nibble tables 8 KB on a 4 KB boundary][four dictionaries 4 KB][rings] or [rings 2 KB][tables][dictionaries]
-    char *const region = (char *)wv.table;
-    const bool on_page = ((uint32_t)(uintptr_t)(lds_u32 *)wv.table & 4095u) == 0;
-    uint32_t *const nib_words = (uint32_t *)(region + (on_page ? 0 : 2048));
-    const uint32_t slot = (uint32_t)lane / G, blk = (uint32_t)lane - slot * G;
-    uint32_t *const dict = (uint32_t *)(region + (on_page ? 8192 : 10240)) + slot * 256;
-    uint8_t *const ring = (uint8_t *)(region + (on_page ? 12288 : 0)) + slot * (kDenseRing + 4);
+// Where the pieces live in the 14 KB of a wave's group tables (which start on a 2 KB boundary, the odd waves' in the middle of a 4 KB
+// page): [nibble tables 8 KB on a 4 KB boundary][four dictionaries of 1 KB][rings 2 KB] or [rings 2 KB][nibble tables][dictionaries].
+struct DenseRegion {
     NibbleTables nib;
-    nib.init(nib_words, lane);
-
-    const bool a_is_pattern = bp_pattern_is_a(la, lb);
-    const uint32_t m = a_is_pattern ? la : lb, n = a_is_pattern ? lb : la;
-    SymWindow32 pat, txt;
-    pat.init((const uint32_t *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? a0 : b0, a_is_pattern ? wv.a_total : wv.b_total);
-    txt.init((const uint32_t *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? b0 : a0, a_is_pattern ? wv.b_total : wv.a_total);
-    const uint32_t row0 = blk * 32;
-    const uint32_t brows = have ? (m > row0 ? (m - row0 < 32 ? m - row0 : 32) : 0) : 0;
-    const bool translator = have && blk < 16;   // the lanes that translate the pair's text, one symbol each per sixteen steps
-
-    // the first two rounds of text and the block's pattern symbols: all requested before anything is waited for
-    uint32_t tsym = translator ? txt.fetch((int)blk) : 0u, tsym_next = translator ? txt.fetch(16 + (int)blk) : 0u;
-    uint32_t psym[32];
-#pragma unroll
-    for (int q = 0; q < 32; q += 4) {
-        uint32_t four[4];
-        pat.fetch4((int)row0 + q, four);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) psym[q + r] = four[r];
+    uint32_t *nib_words;   // [32][64 lanes]
+    uint32_t *dicts;   // [4][256]
+    uint8_t *rings;    // [4][kDenseRing + 4]; 2 KB in all
+    __device__ __forceinline__ void init(uint32_t *table, int lane) {
+        char *const region = (char *)table;
+        const bool on_page = ((uint32_t)(uintptr_t)(lds_u32 *)table & 4095u) == 0;
+        nib_words = (uint32_t *)(region + (on_page ? 0 : 2048));
+        nib.init(nib_words, lane);
+        dicts = (uint32_t *)(region + (on_page ? 8192 : 10240));
+        rings = (uint8_t *)(region + (on_page ? 12288 : 0));
     }
-    // ---- is it worth trying? A 256-bit sketch per pair (one bit per hashed symbol, `ds_or` without return: 32 in flight) counts the
-    // pattern's distinct symbols well enough to send a line of Chinese away after two LDS round trips -- entering its symbols until
-    // the probes run out costs a wave ~40 us of serial LDS atomics, a third of such an item.
-    {
-        uint32_t *const sketch = (uint32_t *)ring;
+};
+
+// A 256-bit sketch of a block's symbols (one bit per hashed symbol, `ds_or` without return: 32 in flight) and its population count:
+// what sends a line of Chinese away after two LDS round trips -- entering its symbols until the probes run out costs a wave ~40 us of
+// serial LDS atomics, a third of such an item.
+__device__ __forceinline__ void dense_sketch_add(uint32_t *sketch, const uint32_t (&psym)[32], uint32_t brows) {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const uint32_t bit = __umulhi(psym[q] * 0x9E3779B1u, 256u);
-            if ((uint32_t)q < brows) __hip_atomic_fetch_or(&sketch[bit >> 5], 1u << (bit & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        wave_lds_fence();
-        uint32_t bits = 0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) bits += (uint32_t)__popc(sketch[w]);
-        if (__ballot(have && bits > kDenseSketchBits)) {
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < BpTraits<uint32_t>::kEntries; ++k) wv.table[k * 64 + lane] = 0;
-            wave_lds_fence();
-            return false;
-        }
+    for (int q = 0; q < 32; ++q) {
+        const uint32_t bit = __umulhi(psym[q] * 0x9E3779B1u, 256u);
+        if ((uint32_t)q < brows) __hip_atomic_fetch_or(&sketch[bit >> 5], 1u << (bit & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // ---- the pair's dictionary; my rows' ids, four to a word ---------------------------------------------------------------
-    // (eight symbols' first probes go out together: at the loads of real text most of them land, and a round trip of `ds_cmpst_rtn`
-    // is what this phase is made of)
+}
+__device__ __forceinline__ uint32_t dense_sketch_bits(const uint32_t *sketch) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) bits += (uint32_t)__popc(sketch[w]);
+    return bits;
+}
+
+// Enters a block's symbols into the pair's dictionary; pid = the rows' ids, four to a word. Eight symbols' first probes go out
+// together: at the loads of real text most of them land, and a round trip of `ds_cmpst_rtn` is what this phase is made of. Returns
+// true (wave-uniform) when some lane ran out of probes: the wave stops at the next group of eight.
+__device__ __forceinline__ bool dense_enter(uint32_t *dict, const uint32_t (&psym)[32], uint32_t brows, uint32_t (&pid)[8]) {
     bool overflow = false;
     uint32_t budget = kDenseBudget;
-    uint32_t pid[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) pid[q] = 0;
 #pragma unroll
@@ -140,15 +117,33 @@ __device__ __forceinline__ bool bp_item_dense(const KernelArgs &args, BpWave<uin
                 pid[q >> 2] |= h << (8 * (q & 3));
             }
         }
-        if (__ballot(overflow)) break;
+        if (__ballot(overflow)) return true;
     }
-    if (__ballot(overflow)) {
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < BpTraits<uint32_t>::kEntries; ++k) wv.table[k * 64 + lane] = 0;
-        wave_lds_fence();
-        return false;
+    return false;
+}
+
+// A text symbol's id: the first probe's answer `k` (slot `h`) is in already -- it was requested a round of columns ago.
+__device__ __forceinline__ uint32_t dense_translate(const uint32_t *dict, uint32_t c, uint32_t h, uint32_t k) {
+    const uint32_t key = c + 1, step = dense_step(c);
+    for (uint32_t tries = 1;; ++tries) {   // (a symbol that was entered sits within its first kDenseTries probes)
+        if (k == key) return h;
+        if (k == 0 || tries == kDenseTries) return kDenseAbsent;
+        h = dense_next(h, step);
+        k = dict[h];
     }
+}
+__device__ __forceinline__ void dense_ring_put(uint8_t *ring, uint32_t j, uint32_t id) {
+    const uint32_t pos = j & (kDenseRing - 1);
+    ring[pos] = (uint8_t)id;
+    if (pos < 4) ring[kDenseRing + pos] = (uint8_t)id;   // the first word again behind the last: a reader's second word never wraps
+}
+// the ids of text positions j .. j + 3, one to a byte
+__device__ __forceinline__ uint32_t dense_ring_ids(const uint8_t *ring, uint32_t j) {
+    const uint32_t pos = j & (kDenseRing - 1);
+    const uint32_t *const words = (const uint32_t *)ring;
+    return __builtin_amdgcn_alignbyte(words[(pos >> 2) + 1], words[pos >> 2], pos & 3u);
+}
+__device__ __forceinline__ void dense_rows_in(const NibbleTables &nib, const uint32_t (&pid)[8], uint32_t brows) {
     const uint32_t row_mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -159,25 +154,58 @@ __device__ __forceinline__ bool bp_item_dense(const KernelArgs &args, BpWave<uin
             nib.template insert<3>(pid[q], row_mask & (1u << (q * 4 + 3)));
         }
     }
+}
+
+// Returns false (wave-uniform) when a pair of the item has more distinct pattern symbols than a dictionary takes; the wave's
+// tables are all zero again then, as they are after an item that ran.
+__device__ __forceinline__ bool bp_item_dense(const KernelArgs &args, BpWave<uint32_t> &wv, const uint32_t G, const bool have, const uint64_t p,
+                                              const uint64_t a0, const uint32_t la, const uint64_t b0, const uint32_t lb) {
+    const int lane = wv.lane;
+    uint32_t *const acc = wv.acc;
+    DenseRegion region;
+    region.init(wv.table, lane);
+    const NibbleTables &nib = region.nib;
+    const uint32_t slot = (uint32_t)lane / G, blk = (uint32_t)lane - slot * G;
+    uint32_t *const dict = region.dicts + slot * 256;
+    uint8_t *const ring = region.rings + slot * (kDenseRing + 4);
+    auto give_up = [&]() {
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < BpTraits<uint32_t>::kEntries; ++k) wv.table[k * 64 + lane] = 0;
+        wave_lds_fence();
+        return false;
+    };
+
+    const bool a_is_pattern = bp_pattern_is_a(la, lb);
+    const uint32_t m = a_is_pattern ? la : lb, n = a_is_pattern ? lb : la;
+    SymWindow32 pat, txt;
+    pat.init((const uint32_t *)(a_is_pattern ? args.job.a.data : args.job.b.data), a_is_pattern ? a0 : b0, a_is_pattern ? wv.a_total : wv.b_total);
+    txt.init((const uint32_t *)(a_is_pattern ? args.job.b.data : args.job.a.data), a_is_pattern ? b0 : a0, a_is_pattern ? wv.b_total : wv.a_total);
+    const uint32_t row0 = blk * 32;
+    const uint32_t brows = have ? (m > row0 ? (m - row0 < 32 ? m - row0 : 32) : 0) : 0;
+    const bool translator = have && blk < 16;   // the lanes that translate the pair's text, one symbol each per sixteen steps
+
+    // the first two rounds of text and the block's pattern symbols: all requested before anything is waited for
+    uint32_t tsym = translator ? txt.fetch((int)blk) : 0u, tsym_next = translator ? txt.fetch(16 + (int)blk) : 0u;
+    uint32_t psym[32];
+#pragma unroll
+    for (int q = 0; q < 32; q += 4) {
+        uint32_t four[4];
+        pat.fetch4((int)row0 + q, four);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) psym[q + r] = four[r];
+    }
+    // ---- is it worth trying? (the sketch borrows the ring's first words) ------------------------------------------------------
+    dense_sketch_add((uint32_t *)ring, psym, brows);
+    wave_lds_fence();
+    if (__ballot(have && dense_sketch_bits((const uint32_t *)ring) > kDenseSketchBits)) return give_up();
+    // ---- the pair's dictionary; my rows under their ids in the nibble tables -------------------------------------------------
+    uint32_t pid[8];
+    if (dense_enter(dict, psym, brows, pid)) return give_up();
+    dense_rows_in(nib, pid, brows);
     acc[lane] = 0;
     wave_lds_fence();   // the dictionaries are complete; acc slots are accumulated into by other lanes below
-
-    // a text symbol's id: the first probe's answer `k` (slot `h`) is in already -- it was requested a round of columns ago
-    auto translate = [&](uint32_t c, uint32_t h, uint32_t k) -> uint32_t {
-        const uint32_t key = c + 1, step = dense_step(c);
-        for (uint32_t tries = 1;; ++tries) {   // (a symbol that was entered sits within its first kDenseTries probes)
-            if (k == key) return h;
-            if (k == 0 || tries == kDenseTries) return kDenseAbsent;
-            h = dense_next(h, step);
-            k = dict[h];
-        }
-    };
-    auto ring_put = [&](uint32_t j, uint32_t id) {
-        const uint32_t pos = j & (kDenseRing - 1);
-        ring[pos] = (uint8_t)id;
-        if (pos < 4) ring[kDenseRing + pos] = (uint8_t)id;
-    };
-    if (translator) ring_put(blk, translate(tsym, dense_hash(tsym), dict[dense_hash(tsym)]));
+    if (translator) dense_ring_put(ring, blk, dense_translate(dict, tsym, dense_hash(tsym), dict[dense_hash(tsym)]));
     wave_lds_fence();
 
     const uint32_t n_eff = wave_max_u32(have ? n + G - 1 : 0);
@@ -203,16 +231,11 @@ __device__ __forceinline__ bool bp_item_dense(const KernelArgs &args, BpWave<uin
             mv = ph_s & xv;
         }
     };
-    const uint32_t *const ring_words = (const uint32_t *)ring;
     for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
         // the ids of this round's sixteen steps (translated one round ago), requested together
         uint32_t ids[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t pos = (s0 + 4 * q - blk) & (kDenseRing - 1);
-            const uint32_t w0 = ring_words[pos >> 2], w1 = ring_words[(pos >> 2) + 1];
-            ids[q] = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
-        }
+        for (int q = 0; q < 4; ++q) ids[q] = dense_ring_ids(ring, s0 + 4 * q - blk);
         // the next round's symbols become ids at the END of this round: their first probe goes out now (every lane: the others ask for
         // the slot of symbol 0) and has long answered by then; the round after that is requested from memory
         const uint32_t coming = tsym_next;
@@ -232,7 +255,7 @@ __device__ __forceinline__ bool bp_item_dense(const KernelArgs &args, BpWave<uin
 #pragma unroll
             for (int u = 0; u < 4; ++u) column(eqs[u], gs + u);
         }
-        if (translator) ring_put(s0 + 16 + blk, translate(coming, first_slot, first_key));
+        if (translator) dense_ring_put(ring, s0 + 16 + blk, dense_translate(dict, coming, first_slot, first_key));
         wave_lds_fence();   // the ring's new ids are read from the next round on
     }
 

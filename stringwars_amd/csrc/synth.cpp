@@ -91,9 +91,36 @@ static void fill(int workload, Rng &rng, Symbols &s, uint32_t len) {
     for (uint32_t i = 0; i < len; ++i) s[i] = draw_symbol(workload, rng);
 }
 
+// One line of swh_workload_script_lines_k: letters of one script, ASCII spaces / punctuation / digits between them.
+static void script_line(Rng &rng, Symbols &s) {
+    static const struct { uint32_t first, count; } scripts[5][2] = {
+        {{0x61, 26}, {0x41, 26}},        // Latin
+        {{0x430, 32}, {0x410, 32}},      // Cyrillic
+        {{0x3B1, 25}, {0x391, 25}},      // Greek
+        {{0x621, 42}, {0x621, 42}},      // Arabic
+        {{0x905, 53}, {0x93E, 16}},      // Devanagari: letters, vowel signs
+    };
+    static const char common[] = "            .,;:!?-()\"'0123456789";
+    const uint32_t script = rng.below(5), len = rng.range(700, 1300);
+    s.resize(len);
+    for (uint32_t i = 0; i < len; ++i) {
+        const uint32_t r = rng.below(100);
+        if (r < 20) s[i] = (uint32_t)common[rng.below(sizeof common - 1)];
+        else {
+            const auto &range = scripts[script][r < 30];   // (an eighth of the letters from the second range: capitals, vowel signs)
+            s[i] = range.first + rng.below(range.count);
+        }
+    }
+}
+
 static void make_pair(int workload, uint64_t seed, uint64_t index, Symbols &a, Symbols &b) {
     Rng rng(seed, index);
     a.clear(); b.clear();
+    if (workload == swh_workload_script_lines_k) {
+        script_line(rng, a);
+        script_line(rng, b);
+        return;
+    }
     if (workload == swh_workload_utf8_lines_k) {
         uint32_t target = rng.range(768, 1280), bytes = 0;
         while (bytes < target) { uint32_t cp = draw_symbol(workload, rng); a.push_back(cp); bytes += utf8_len(cp); }
@@ -132,13 +159,13 @@ SWH_EXPORT swh_status_t swh_synth_generate(int workload, uint64_t seed, uint64_t
     memset(out, 0, sizeof *out);
     switch (workload) {
     case swh_workload_words16_k: case swh_workload_tokens64_k: case swh_workload_utf8_lines_k:
-    case swh_workload_protein4k_k: case swh_workload_short_words_k: case swh_workload_bytes4k_k: break;
+    case swh_workload_protein4k_k: case swh_workload_short_words_k: case swh_workload_bytes4k_k: case swh_workload_script_lines_k: break;
     default: if (error) *error = bad; return swh_invalid_argument_k;
     }
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
     if ((size_t)threads > count / 1024 + 1) threads = (int)(count / 1024 + 1);
-    const bool utf8 = workload == swh_workload_utf8_lines_k;
+    const bool utf8 = workload == swh_workload_utf8_lines_k || workload == swh_workload_script_lines_k;
     std::vector<Shard> shards(threads);
     auto work = [&](int t) {
         size_t lo = count * (size_t)t / threads, hi = count * (size_t)(t + 1) / threads;

@@ -19,6 +19,7 @@ WORKLOADS = {
     "utf8_lines": 3,   # C3
     "protein4k": 4,    # C4
     "short_words": 5,  # C5
+    "script_lines": 6, # unrelated article lines, one script each (the UTF-8 engine's cross-product regime)
     "bytes4k": 40,     # C4, full byte alphabet
 }
 AMINO_ACIDS = b"ACDEFGHIKLMNPQRSTVWY"

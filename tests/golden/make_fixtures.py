@@ -69,8 +69,29 @@ def multilingual_words():
     print({k: v.shape for k, v in out.items()})
 
 
+def script_lines():
+    """tests/golden/script_lines.npz: the first 64 pairs of the `script_lines` workload -- unrelated article lines of 700 ... 1300 code points,
+    one script each: what the reference's cross-product of XLSum lines pairs up for `LevenshteinDistancesUtf8` (bench.rs:386-399,
+    similarities/README.md:18, :39-40) -- as a SHA-256 over the generated tapes, the first 8 pairs verbatim, and the oracle's distances
+    over code points and over bytes (Wagner-Fischer, cross-checked against the Hyyro restatement before anything is written)."""
+    count, verbatim = 64, 8
+    a, b = sw.generate_pairs("script_lines", count, seed=42)
+    head_a, head_b = sw.generate_pairs("script_lines", verbatim, seed=42)
+    out = {"a_data": head_a.data, "a_offsets": head_a.offsets, "b_data": head_b.data, "b_offsets": head_b.offsets,
+           "n64.sha256": np.frombuffer(tape_digest(a, b).encode(), dtype=np.uint8)}
+    out["n64.lev_utf8"] = oracle.levenshtein_pairs(a, b, utf8=True)
+    assert (out["n64.lev_utf8"] == oracle.levenshtein_pairs(a, b, utf8=True, algo="hyyro")).all()
+    out["n64.lev_bytes"] = oracle.levenshtein_pairs(a, b)
+    assert (out["n64.lev_bytes"] == oracle.levenshtein_pairs(a, b, algo="hyyro")).all()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "script_lines.npz"), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
 def main():
+    if sys.argv[1:] == ["script_lines"]:   # (this fixture alone: the others are not rewritten)
+        return script_lines()
     multilingual_words()
+    script_lines()
     out = {}
     for name, verbatim in VERBATIM.items():
         a, b = sw.generate_pairs(name, FULL, seed=42)

@@ -62,7 +62,7 @@ def test_bench_legs_cover_every_baseline_config():
     configs beside the headline C2, each at its full size -- and the two shapes round 4 added kernels for (C3's lines at k = 100,
     NW on word-sized strings)."""
     bench = load(os.path.join(ROOT, "bench.py"), "bench_module_legs")
-    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words"]
+    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words"]
     # the reference's literal UTF-8 calls (bench.rs:538-546): raw tapes, no bound -- and raw tapes the scope's beliefs do not cover
     assert not bench.LEGS["utf8_unbounded_raw"]["prepared"] and "bound" not in bench.LEGS["utf8_unbounded_raw"] and bench.LEGS["c3_raw_cold"]["cold"] >= 2
     assert all(bench.LEGS[name]["check"] >= 100 for name in ("c4_linear", "c4_affine", "c4_bytes", "c4_letters52"))

@@ -114,6 +114,28 @@ def test_golden_slices_needleman_wunsch(sw, scope, name):
     assert (affine.pairs(a, b, scope) == z[f"{name}.nw_affine_m11_m1"]).all()
 
 
+def test_golden_script_lines(sw, scope):
+    """tests/golden/script_lines.npz: 64 pairs of unrelated article lines, one script each (the reference's cross-product of XLSum lines,
+    similarities/README.md:18, :39-40) -- the committed oracle distances over code points (`LevenshteinDistancesUtf8`: the dense-alphabet
+    items of bp_dense.hpp) and over bytes, raw and prepared tapes, every algorithm switch, bounded."""
+    import hashlib
+    z = np.load(os.path.join(GOLDEN, "script_lines.npz"))
+    a, b = sw.generate_pairs("script_lines", 64, seed=42)
+    h = hashlib.sha256()
+    for array in (a.data, a.offsets, b.data, b.offsets):
+        h.update(np.ascontiguousarray(array).tobytes())
+    assert h.hexdigest() == bytes(z["n64.sha256"]).decode()
+    for algorithm in ALGORITHMS:
+        assert (sw.LevenshteinDistancesUTF8(capabilities=scope, algorithm=algorithm).pairs(a, b, scope) == z["n64.lev_utf8"]).all(), algorithm
+        assert (sw.LevenshteinDistances(capabilities=scope, algorithm=algorithm).pairs(a, b, scope) == z["n64.lev_bytes"]).all(), algorithm
+    utf8 = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    pa, pb = sw.PreparedTape(scope, a, utf8=True), sw.PreparedTape(scope, b, utf8=True)
+    for _ in range(2):
+        assert (utf8.pairs(pa, pb, scope) == z["n64.lev_utf8"]).all()
+    for bound in (32, 100, 700):
+        assert (utf8.pairs(a, b, scope, bound=bound) == np.minimum(z["n64.lev_utf8"], bound + 1)).all(), bound
+
+
 @pytest.mark.parametrize("name", ["words16", "tokens64", "utf8_lines", "protein4k", "short_words", "bytes4k"])
 def test_golden_256_pairs_of_every_config(sw, scope, name):
     """the first 256 pairs of each synthetic config against the committed oracle outputs. The KB-sized
@@ -2195,7 +2217,7 @@ def test_bench_line_carries_every_config():
     assert line["value"] > 0 and line["value_steady"] > 0 and line["value_pipelined"] > 0 and line["parity_vs_oracle"] is True
     assert abs(line["value"] - line["config"]["cells_per_gpu"] * 5 / (line["ms_per_step"] * 5e-3) / 1e9) < 0.02 * line["value"]
     assert line["roofline"]["bound"] == "valu" and line["roofline"]["kernel_ms"] > 0 and line["roofline"]["kernel"] == "bitparallel_tiled"
-    assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes",
+    assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes",
                                                         "c4_letters52", "c5", "nw_words"]
     for entry in line["configs"]:
         assert "error" not in entry, entry
@@ -2672,10 +2694,19 @@ def test_code_point_items_on_a_dense_alphabet(sw, orc, request):
                 elif variant == 1: t = draw(pool, int(rng.integers(max(1, n - 200), n + 200)))   # unrelated, same alphabet
                 else: t = edit(s, pools["text"], int(rng.integers(20, 200)))                     # symbols the other side does not hold
                 items_a.append(s); items_b.append(t); kinds.append(name)
+    # patterns of more than 64 blocks (k_bitparallel_long: passes of 64 blocks that share the pair's dictionary): a few symbols all along, a
+    # pattern whose SECOND pass brings the symbols that do not fit (the first pass has run dense by then), one whose first pass does
+    for n, make in ((2100, lambda: draw(pools["text"], 2100)), (4500, lambda: draw(pools["few"], 4500, cover=True)), (6200, lambda: draw(pools["text"], 6200)),
+                    (3300, lambda: draw(pools["few"], 2048) + draw(pools["many"], 1252)), (3300, lambda: draw(pools["many"], 2048) + draw(pools["few"], 1252)),
+                    (4200, lambda: draw(pools["few"], 2048) + draw(pools["text"], 2048) + draw(pools["edges"], 104))):
+        for variant in range(2):
+            s = make()
+            t = edit(s, pools["text"], int(rng.integers(0, 60))) if variant == 0 else draw(pools["text"], int(rng.integers(n, n + 300)))
+            items_a.append(s); items_b.append(t + draw(pools["few"], 40)); kinds.append(f"long {n}")   # (b is the longer one: a is the pattern)
     order = rng.permutation(len(items_a))
     a, b = sw.Strs([items_a[i] for i in order]), sw.Strs([items_b[i] for i in order])
     want = orc.levenshtein_pairs(a, b, utf8=True)
-    counts = (C.c_uint32 * 2)()
+    counts = (C.c_uint32 * 4)()
     N.lib.swh_test_dense_items.argtypes = [C.POINTER(C.c_uint32)]
     assert N.lib.swh_test_dense_items(counts) == 0
     engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
@@ -2684,7 +2715,8 @@ def test_code_point_items_on_a_dense_alphabet(sw, orc, request):
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], [kinds[order[i]] for i in bad[:5]])
         assert N.lib.swh_test_dense_items(counts) == 0
-        assert counts[0] > 30 and counts[1] > 10, list(counts)          # both kinds of item ran: the dense ones and the overflowing ones
+        assert counts[0] > 30 and counts[1] > 10, list(counts)          # both kinds of item ran: the dense ones and the ones sent to the group tables
+        assert counts[2] >= 16 and counts[3] >= 6, list(counts)         # ... and both kinds of pass of the long kernel
     for bound in (0, 31, 200, 5000):                                    # (bounds beyond the band kernels' clamp what the blocks return)
         assert (engine.pairs(a, b, scope, bound=bound) == np.minimum(want, bound + 1)).all(), bound
     # the same batch with the dense alphabet switched off: the group tables alone give the same distances
@@ -2692,6 +2724,6 @@ def test_code_point_items_on_a_dense_alphabet(sw, orc, request):
     try:
         assert N.lib.swh_test_dense_items(counts) == 0                  # (zeroes the counters)
         assert (engine.pairs(a, b, scope) == want).all()
-        assert N.lib.swh_test_dense_items(counts) == 0 and counts[0] == 0 and counts[1] == 0, list(counts)
+        assert N.lib.swh_test_dense_items(counts) == 0 and counts[0] == 0 and counts[1] == 0 and counts[2] == 0 and counts[3] > 0, list(counts)
     finally:
         del os.environ["STRINGWARS_AMD_BP_DENSE"]

@@ -205,6 +205,22 @@ def _digest(a, b) -> str:
     return h.hexdigest()
 
 
+def test_golden_script_lines_reproducible(orc, sw):
+    """tests/golden/script_lines.npz = generator(seed 42) + oracle: the digest pins the `script_lines` generator (unrelated article lines, one
+    script each), the stored distances are the oracle's over code points and over bytes, by both of its Levenshtein routines."""
+    z = np.load(os.path.join(GOLDEN, "script_lines.npz"))
+    a, b = sw.generate_pairs("script_lines", 64, seed=42)
+    assert _digest(a, b) == bytes(z["n64.sha256"]).decode()
+    head = sw.Strs(data=z["a_data"], offsets=z["a_offsets"])
+    assert all(head[i] == a[i] for i in range(8))
+    for utf8, key in ((True, "n64.lev_utf8"), (False, "n64.lev_bytes")):
+        assert (orc.levenshtein_pairs(a, b, utf8=utf8, count=16) == z[key][:16]).all()
+        assert (orc.levenshtein_pairs(a, b, utf8=utf8, algo="hyyro") == z[key]).all()
+    lines = [a[i].decode() for i in range(64)] + [b[i].decode() for i in range(64)]
+    assert all(700 <= len(line) <= 1300 for line in lines)
+    assert max(len(set(line)) for line in lines) < 120        # one script and the common ASCII: what a 251-slot dictionary takes with room to spare
+
+
 def test_golden_slices_reproducible(orc, sw):
     """The committed fixture = generator(seed 42) + oracle; regenerate and compare (catches drift in either).
     All six workloads: the SHA-256 of the first 256 generated pairs; oracle outputs for the word-sized ones at 256

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cross-product rows in the shape of the reference's published tables (similarities/README.md:30-136): queries [0, side)
 x candidates [side, 2*side), side = round(sqrt(BATCH_PER_CORE * compute units)) (bench.rs:113-117), synthetic stand-ins
-for its datasets (ACGT 100 B / 1 KB, ~5 B words, ~3.2 KB lines). Matrix stays on the device (UnifiedMat role)."""
+for its datasets (ACGT 100 B / 1 KB, ~5 B words, ~3.2 KB lines; `ulines`: lines of one non-Latin or Latin script each, ~1000 code points). Matrix stays on the device (UnifiedMat role)."""
 import argparse, ctypes as C, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +23,8 @@ def tokens(kind, count, rng):
         lens = np.clip(rng.poisson(4.0, count) + 1, 1, 24)
     elif kind == "lines":
         lens = np.clip(rng.normal(3200, 1200, count).astype(int), 200, 9000)
+    elif kind == "ulines":   # article lines of 700 ... 1300 code points, one script each (~1.8 KB): XLSum lines as the UTF-8 engine sees them
+        return sw.generate_pairs("script_lines", count, seed=42)[0]
     if kind in ("uwords", "twords"):   # multilingual word-sized tokens (what XLSum words look like to the UTF-8 engine): ~5 code points of four scripts
         cps = np.array([0x61, 0x65, 0x6F, 0x74, 0xE9, 0xFC, 0x430, 0x435, 0x43E, 0x442, 0x4E2D, 0x6587, 0x65E5, 0x672C], dtype=np.uint32)
         lens = np.clip(rng.poisson(4.0, count) + 1, 1, 24)
@@ -40,7 +42,7 @@ def tokens(kind, count, rng):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kinds", default="acgt100,acgt1k,words,uwords,lines")
+    ap.add_argument("--kinds", default="acgt100,acgt1k,words,uwords,lines,ulines")
     ap.add_argument("--batch-per-core", type=int, default=0)
     ap.add_argument("--repeats", type=int, default=3)
     args = ap.parse_args()
@@ -48,7 +50,7 @@ def main():
     rng = np.random.default_rng(42)
     classes, costs = sw.unary_class_costs(2, -1)
     for kind in args.kinds.split(","):
-        per_core = args.batch_per_core or (256 if kind == "lines" else 16384)   # similarities/README.md:22-23
+        per_core = args.batch_per_core or (256 if kind in ("lines", "ulines") else 16384)   # similarities/README.md:22-23
         side = max(1, round((per_core * scope.compute_units) ** 0.5))
         tape = tokens(kind, 2 * side, rng)
         q, c = tape.subview(0, side).to_device(scope), tape.subview(side, 2 * side).to_device(scope)

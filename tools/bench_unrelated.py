@@ -2,7 +2,7 @@
 """Measuring tool: UNRELATED lines through the UTF-8 engine, unbounded -- what the reference's cross-product of article lines is made
 of (similarities/README.md:39-40, :56: XLSum lines, one language per line), and what the two-stage schedule cannot settle.
 Lines of ~1000 code points, each in ONE script (its letters + ASCII punctuation / digits / spaces), pair i = (line i, line i + 1):
-    python tools/bench_unrelated.py [--pairs 50000] [--scripts cyrillic,latin,...] [--mixed]
+    python tools/bench_unrelated.py [--pairs 50000] [--scripts cyrillic,latin,...] [--cps 700,1300] [--mixed]
 --mixed: C3's synthetic lines instead (four scripts in every line, ~340 distinct symbols: beyond a 255-slot dictionary).
 Rows: code points on prepared tapes, the same on raw tapes, and the same tapes as bytes. STRINGWARS_AMD_DOUBLING=0 is set: the first
 stage would be tried once and then sit out (nothing to settle); the rows are the block kernels' own."""
@@ -24,11 +24,11 @@ SCRIPTS = {
 COMMON = [0x20] * 12 + list(b".,;:!?-()\"'") + list(range(0x30, 0x3A))
 
 
-def lines(count, scripts, rng):
+def lines(count, scripts, rng, lo=700, hi=1300):
     out = []
     for i in range(count):
         letters = SCRIPTS[scripts[i % len(scripts)]]
-        n = int(rng.integers(700, 1300))
+        n = int(rng.integers(lo, hi))
         pick = np.where(rng.random(n) < 0.8, rng.choice(letters, n), rng.choice(COMMON, n))
         out.append("".join(map(chr, pick.tolist())).encode())
     return out
@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=50_000)
     ap.add_argument("--scripts", default="latin,cyrillic,greek,arabic,devanagari")
     ap.add_argument("--mixed", action="store_true")
+    ap.add_argument("--cps", default="700,1300", help="code points per line, lo,hi (beyond 2048: the kernel of several passes)")
     args = ap.parse_args()
     import torch
     scope = sw.DeviceScope(gpu_device=0)
@@ -47,8 +48,9 @@ def main():
         a, _ = sw.generate_pairs("utf8_lines", args.pairs + 1, seed=42)
         label = "C3's synthetic lines (four scripts per line)"
     else:
-        a = sw.Strs(lines(args.pairs + 1, args.scripts.split(","), rng))
-        label = args.scripts
+        lo, hi = (int(x) for x in args.cps.split(","))
+        a = sw.Strs(lines(args.pairs + 1, args.scripts.split(","), rng, lo, hi))
+        label = f"{args.scripts} {lo}-{hi} code points"
     left, right = a.subview(0, args.pairs), a.subview(1, args.pairs + 1)
     leads = np.concatenate([[0], np.cumsum((a.data & 0xC0) != 0x80)])
     cps = leads[a.offsets[1:].astype(np.int64)] - leads[a.offsets[:-1].astype(np.int64)]

@@ -2649,11 +2649,12 @@ def test_golden_words_alignment_rows(sw, scope):
 
 def test_code_point_items_on_a_dense_alphabet(sw, orc, request):
     """bp_dense.hpp: a code-point work item of 16 blocks and more gives the distinct symbols of each pair's pattern 8-bit ids (the slot
-    of a 255-slot dictionary in LDS that takes a symbol is its id) and then runs on the byte kernel's nibble tables; text symbols the
-    pattern does not hold translate to the id with the empty match vector; a pattern of more than 255 distinct symbols overflows the
-    dictionary and the item goes to the seven group tables as before. `LevenshteinDistancesUtf8`, bench.rs:386-399: lines of 481 ...
-    2048 code points over alphabets of 2 / 32 / ~190 / 230 / 251 / 256 / 3000 symbols, the edges of every UTF-8 length, related and
-    unrelated pairs, shorter and longer strings around them. (Test library: its kernel counts the items of either kind.)"""
+    of a 251-slot dictionary in LDS that takes a symbol is its id) and then runs on the byte kernel's nibble tables; text symbols the
+    pattern does not hold translate to the id with the empty match vector; a pattern with more distinct symbols than the dictionary takes
+    (~200: a sketch sends it away, or a lane runs out of probes) goes to the seven group tables as before, and so does every later pass
+    of a pattern beyond 2048 symbols (k_bitparallel_long keeps the dictionary from pass to pass). `LevenshteinDistancesUtf8`,
+    bench.rs:386-399: lines of 300 ... 6200 code points over alphabets of 2 / 32 / ~190 / 230 / 251 / 256 / 3000 symbols, the edges of
+    every UTF-8 length, related and unrelated pairs. (Test library: its kernels count the items and passes of either kind.)"""
     if not run_in_child(request, test_library=True):
         return
     import ctypes as C

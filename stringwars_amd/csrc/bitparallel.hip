@@ -145,9 +145,14 @@ __device__ __forceinline__ uint32_t window_symbol(const Window &w, int idx) {   
 // dictionary -- the dictionary and the sketch stay in LDS from pass to pass (a symbol that an earlier pass entered keeps its id, a
 // text symbol that only a LATER pass's blocks hold finds this pass's nibble tables empty for its id); from the pass that does not
 // fit on, the pair runs on the group tables.
+// Code points: ONE eleven-wave workgroup per compute unit (what 14.25 KB of tables per wave leave room for, as in k_bitparallel<u32, 11>) and at most
+// 168 registers, i.e. three waves on a SIMD: the kernel asked for 207 -- 256 with the dense passes -- and ran two waves per SIMD in five workgroups of
+// two (eight waves per CU); capped, it spills ~80 registers outside its column loop and runs lines of ~3000 code points 20 % faster.
+constexpr int kBpLongWavesU32 = 11;
 template <typename Sym, bool kDense = true>
-__global__ __launch_bounds__(BpTraits<Sym>::kWaves * 64, BpTraits<Sym>::kMinWavesPerSimd) void k_bitparallel_long(KernelArgs args) {
-    constexpr int kBpWaves = BpTraits<Sym>::kWaves, kBpTableWords = bp_table_words<Sym>();
+__global__ __launch_bounds__((sizeof(Sym) == 4 ? kBpLongWavesU32 : BpTraits<Sym>::kWaves) * 64, (sizeof(Sym) == 4 ? 3 : BpTraits<Sym>::kMinWavesPerSimd))
+void k_bitparallel_long(KernelArgs args) {
+    constexpr int kBpWaves = sizeof(Sym) == 4 ? kBpLongWavesU32 : BpTraits<Sym>::kWaves, kBpTableWords = bp_table_words<Sym>();
     constexpr bool kBytes = sizeof(Sym) == 1;
     constexpr bool kTryDense = !kBytes && kDense;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -438,10 +443,10 @@ void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_hos
     const uint32_t count = plan_host.class_count[kClassBpLong];
     if (!count) return;
     const bool bytes = args.sym_bytes == 1;
-    const int waves = bytes ? BpTraits<uint8_t>::kWaves : BpTraits<uint32_t>::kWaves;
-    const size_t lds = bytes ? bp_lds_bytes<uint8_t>() : bp_lds_bytes<uint32_t>();
+    const int waves = bytes ? BpTraits<uint8_t>::kWaves : kBpLongWavesU32;
+    const size_t lds = bytes ? bp_lds_bytes<uint8_t>() : (size_t)kBpLongWavesU32 * (bp_table_words<uint32_t>() + 64) * 4 + 80 * 4;
     uint32_t blocks = (count + waves - 1) / waves;
-    const uint32_t max_blocks = (uint32_t)scope->compute_units * (bytes ? 4 : 5);
+    const uint32_t max_blocks = (uint32_t)scope->compute_units * (bytes ? 4 : 1);
     if (blocks > max_blocks) blocks = max_blocks;
     // args.boundary / boundary_stride: the carry words, sized by the caller (bp_long_carry_words, <= 4096 waves)
     static const bool round_robin = [] { const char *e = getenv("STRINGWARS_AMD_LONG_TICKET"); return e && atoi(e) == 0; }();   // comparison knob

@@ -1005,8 +1005,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         // patterns of more than 64 blocks: multi-pass bit-parallel kernel, carries between passes in scratch
         if (bitpar_ok && plan.class_count[kClassBpLong]) {
             const uint64_t stride = bp_long_carry_words(plan.max_la > plan.max_lb ? plan.max_la : plan.max_lb);
-            // one carry area per wave the launch can have: ceil(count / waves-per-block) blocks of <= 4 waves
-            const uint64_t waves = plan.class_count[kClassBpLong] + 4 < kBpLongMaxWaves ? plan.class_count[kClassBpLong] + 4 : kBpLongMaxWaves;
+            // one carry area per wave the launch can have: ceil(count / waves-per-block) blocks of 4 (bytes) or 11 (code points) waves
+            const uint64_t waves = plan.class_count[kClassBpLong] + 16 < kBpLongMaxWaves ? plan.class_count[kClassBpLong] + 16 : kBpLongMaxWaves;
             ensure(scope->boundary, scope->boundary_bytes, waves * stride * sizeof(uint32_t));
             KernelArgs kl = k;
             kl.boundary = (int32_t *)scope->boundary;

@@ -222,8 +222,13 @@ void k_bitparallel_long(KernelArgs args) {
             // The pass's columns. kDensePass: the text arrives as ids through the pair's ring (sixteen lanes translate a symbol each per
             // round of sixteen steps), the match vectors come from the nibble tables; else every lane fetches its own text and looks it
             // up in the byte / group tables. `text_ahead` / `text_ahead2`: what was requested before the tables were built.
-            auto columns = [&](auto dense_tag, uint32_t (&tnxt)[kBytes ? 4 : 16], int (&tshift)[kBytes ? 4 : 1], uint32_t tsym_next) {
-                constexpr bool kDensePass = decltype(dense_tag)::value;
+            // kCarryIn (not the first pass) / kRecord (not the last): compile-time, so that a pass pays only for what it does -- as run-time flags
+            // they cost every column a uniform branch, four shifts, and two `v_cndmask` around the recording (36 instructions per step
+            // against the plain item's 23). The carries travel oldest column at the TOP of a word: the producer shifts a column in from below
+            // with one `v_alignbit` per word, the consumer hands the whole word to lane 0 (only bit 31 of what enters a block is looked at)
+            // and shifts it left: two instructions per step on either side.
+            auto columns_as = [&](auto dense_tag, auto carry_tag, auto record_tag, uint32_t (&tnxt)[kBytes ? 4 : 16], int (&tshift)[kBytes ? 4 : 1], uint32_t tsym_next) {
+                constexpr bool kDensePass = decltype(dense_tag)::value, kCarryIn = decltype(carry_tag)::value, kRecord = decltype(record_tag)::value;
                 constexpr int kTextRegs = kBytes ? 4 : 16;
                 [[maybe_unused]] const uint32_t *const dict = kTryDense ? dense.dicts : nullptr;
                 [[maybe_unused]] uint8_t *const ring = kTryDense ? dense.rings : nullptr;
@@ -243,7 +248,7 @@ void k_bitparallel_long(KernelArgs args) {
                     }
                 };
                 uint32_t cw_ph = 0, cw_mh = 0, cw_ph_next = 0, cw_mh_next = 0;   // carries entering lane 0, 32 columns per word
-                if (pass) {
+                if constexpr (kCarryIn) {
                     cw_ph_next = __hip_atomic_load(cin_ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     cw_mh_next = __hip_atomic_load(cin_mh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -269,7 +274,7 @@ void k_bitparallel_long(KernelArgs args) {
                         }
                         fetch_text((int)s0 + 16 - lane);
                     }
-                    if (pass && (s0 & 31u) == 0) {   // lane 0 is at column s0: the word for columns s0 .. s0 + 31
+                    if (kCarryIn && (s0 & 31u) == 0) {   // lane 0 is at column s0: the word for columns s0 .. s0 + 31
                         cw_ph = cw_ph_next;
                         cw_mh = cw_mh_next;
                         const uint32_t nxt = (s0 >> 5) + 1 < cwords ? (s0 >> 5) + 1 : cwords - 1;
@@ -300,9 +305,9 @@ void k_bitparallel_long(KernelArgs args) {
                             const uint32_t s = gs + u;
                             // what enters block 64 * pass in column s: the DP boundary (+1) or the previous pass's carries
                             uint32_t in_ph = 0x80000000u, in_mh = 0;
-                            if (pass) {   // uniform
-                                in_ph = cw_ph << 31; in_mh = cw_mh << 31;
-                                cw_ph >>= 1; cw_mh >>= 1;
+                            if constexpr (kCarryIn) {   // (bit 31 is this column's; the bits below it are not looked at)
+                                in_ph = cw_ph; in_mh = cw_mh;
+                                cw_ph <<= 1; cw_mh <<= 1;
                             }
                             uint32_t ph_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ph, 0x138, 0xf, 0xf, true);
                             uint32_t mh_in = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x138, 0xf, 0xf, true);
@@ -319,13 +324,13 @@ void k_bitparallel_long(KernelArgs args) {
                                 uint32_t mh_s = __builtin_amdgcn_alignbit(mh, mh_in, 31);
                                 pv = mh_s | ~(xv | ph_s);
                                 mv = ph_s & xv;
-                                if (record) {   // uniform; only lane 63's words are stored
-                                    ow_ph = (ow_ph >> 1) | (ph & 0x80000000u);
-                                    ow_mh = (ow_mh >> 1) | (mh & 0x80000000u);
+                                if constexpr (kRecord) {   // only lane 63's words are stored
+                                    ow_ph = __builtin_amdgcn_alignbit(ow_ph, ph, 31);   // (ow << 1) | (ph >> 31)
+                                    ow_mh = __builtin_amdgcn_alignbit(ow_mh, mh, 31);
                                 }
                             }
                             // lane 63 has just finished column s - 63: a word is complete every 32 columns
-                            if (record && s >= 63 && ((s - 63) & 31u) == 31u && s - 63 < n && lane == 63) {
+                            if (kRecord && s >= 63 && ((s - 63) & 31u) == 31u && s - 63 < n && lane == 63) {
                                 cout_ph[(s - 63) >> 5] = ow_ph;
                                 cout_mh[(s - 63) >> 5] = ow_mh;
                             }
@@ -336,12 +341,18 @@ void k_bitparallel_long(KernelArgs args) {
                         wave_lds_fence();   // the ring's new ids are read from the next round on
                     }
                 }
-                if (record && (n & 31u) && lane == 63) {   // the last, partial word: bits sit at the top
-                    cout_ph[n >> 5] = ow_ph >> (32 - (n & 31u));
-                    cout_mh[n >> 5] = ow_mh >> (32 - (n & 31u));
+                if (kRecord && (n & 31u) && lane == 63) {   // the last, partial word: its columns sit at the bottom, the oldest goes to the top
+                    cout_ph[n >> 5] = ow_ph << (32 - (n & 31u));
+                    cout_mh[n >> 5] = ow_mh << (32 - (n & 31u));
                 }
                 const uint32_t mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
                 part += __popc(pv & mask) - __popc(mv & mask);
+            };
+            auto columns = [&](auto dense_tag, uint32_t (&tnxt)[kBytes ? 4 : 16], int (&tshift)[kBytes ? 4 : 1], uint32_t tsym_next) {
+                if (pass == 0 && record) columns_as(dense_tag, std::false_type{}, std::true_type{}, tnxt, tshift, tsym_next);
+                else if (pass == 0) columns_as(dense_tag, std::false_type{}, std::false_type{}, tnxt, tshift, tsym_next);   // (never: one pass is k_bitparallel's)
+                else if (record) columns_as(dense_tag, std::true_type{}, std::true_type{}, tnxt, tshift, tsym_next);
+                else columns_as(dense_tag, std::true_type{}, std::false_type{}, tnxt, tshift, tsym_next);
             };
 
             uint32_t tnxt[kBytes ? 4 : 16];

@@ -165,7 +165,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum_u32(uint32_t v) {
 // Must be used identically by the plan key (prepass.hip) and the kernel (bitparallel.hip).
 __host__ __device__ __forceinline__ bool bp_pattern_is_a(uint32_t la, uint32_t lb) {
     const uint32_t ga = (la + 31) >> 5, gb = (lb + 31) >> 5;
-    if (ga > 64 || gb > 64) return ga <= gb;   // at most one of them fits the 64-block systolic array
+    if (ga > 64 || gb > 64) {
+        // Beyond the 64-block systolic array a pattern runs as passes of 64 blocks, each a walk over the whole text, one pair per wave:
+        // wave-steps = passes x text (+ the fill). With the same number of passes either way the LONGER string is the cheaper pattern
+        // (2600 x 3500 symbols: two passes over 2600 columns instead of over 3500, and 110 of 128 lane-slots busy instead of 82) -- until
+        // round 5 the string of fewer blocks was taken, which is right only when it saves a pass or fits the array.
+        auto wave_steps = [](uint32_t g, uint32_t text) -> uint64_t {
+            if (g > 64) return (uint64_t)((g + 63) >> 6) * text + g;
+            return g ? ((uint64_t)text + g - 1) / (64 / g) : 0;   // floor(64 / g) pairs share a wave of k_bitparallel
+        };
+        return wave_steps(ga, lb) <= wave_steps(gb, la);
+    }
     const uint64_t ca = (uint64_t)ga * (lb + ga - 1), cb = (uint64_t)gb * (la + gb - 1);
     return ca <= cb;
 }

@@ -46,8 +46,9 @@ __device__ __forceinline__ uint32_t plan_key(uint32_t la, uint32_t lb, uint32_t 
             uint32_t bucket = txt_len >> shift;
             return (kClassBp0 + g - 1) * kBuckets + (bucket > 63 ? 63 : bucket);
         }
-        // more than 64 blocks: several passes of 64 blocks over the text (k_bitparallel_long)
-        uint32_t bucket = txt_len >> 8;
+        // more than 64 blocks: several passes of 64 blocks over the text (k_bitparallel_long), which draws its pairs from the END of the
+        // class: the order is by what a pair costs its wave -- passes x text steps --, heaviest last
+        uint32_t bucket = (((g + 63) >> 6) * txt_len) >> 9;
         return kClassBpLong * kBuckets + (bucket > 63 ? 63 : bucket);
     }
     uint32_t cols = symmetric ? m : lb, rows = symmetric ? n : la;

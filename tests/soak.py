@@ -24,13 +24,17 @@ REGIMES = [(0, 8), (0, 40), (20, 140), (100, 700), (500, 2100), (1900, 2300), (2
 ALPHABETS = {"acgt": [ord(c) for c in "ACGT"], "lower": list(range(97, 123)), "byte": list(range(256)),
              "binary": [48, 49], "ascii": list(range(32, 127))}
 SCRIPTS = [0x41, 0x62, 0xE9, 0x416, 0x434, 0x4E2D, 0x6587, 0x1F600, 0x20AC, 0x7F, 0x80, 0x7FF, 0x800, 0xFFFF, 0x10000]
+# code points by how many distinct ones a pattern sees (bp_dense.hpp: per-pair dictionaries of 251 slots): a handful; around what a dictionary
+# takes -- a sketch or a probe budget decides, pattern by pattern --; far beyond it (the group tables)
+CODE_POINT_POOLS = [SCRIPTS, SCRIPTS + list(range(0x430, 0x450)) + list(range(0x20, 0x7F)) + list(range(0x3041, 0x3097)),
+                    SCRIPTS + list(range(0x4E00, 0x4E00 + 900)) + list(range(0x1F300, 0x1F340))]
 
 
 def random_batch(rng, utf8):
     regime = REGIMES[int(rng.integers(0, len(REGIMES)))]
     mixed = rng.random() < 0.3
     budget = 1.5e9
-    alphabet = np.array(SCRIPTS if utf8 else ALPHABETS[str(rng.choice(list(ALPHABETS)))], np.uint32)
+    alphabet = np.array(CODE_POINT_POOLS[int(rng.integers(0, 3))] if utf8 else ALPHABETS[str(rng.choice(list(ALPHABETS)))], np.uint32)
     items_a, items_b, cells = [], [], 0
     while cells < budget and len(items_a) < 20000:
         lo, hi = REGIMES[int(rng.integers(0, len(REGIMES)))] if mixed else regime

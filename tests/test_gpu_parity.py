@@ -2716,6 +2716,7 @@ def test_code_point_items_on_a_dense_alphabet(sw, orc, request):
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (bad[:5], got[bad[:5]], want[bad[:5]], [kinds[order[i]] for i in bad[:5]])
         assert N.lib.swh_test_dense_items(counts) == 0
+        print("dense / declined items, dense / group-table passes:", list(counts))
         assert counts[0] > 30 and counts[1] > 10, list(counts)          # both kinds of item ran: the dense ones and the ones sent to the group tables
         assert counts[2] >= 16 and counts[3] >= 6, list(counts)         # ... and both kinds of pass of the long kernel
     for bound in (0, 31, 200, 5000):                                    # (bounds beyond the band kernels' clamp what the blocks return)

@@ -69,20 +69,36 @@ struct GroupTables3 {
         else s = c >> (3 * G - 8);
         return (uint32_t)__builtin_amdgcn_bitop3_b32((int)s, (int)mask, (int)tbase, 0xEA);
     }
-    __device__ __forceinline__ uint32_t lookup(uint32_t c) const {
-        uint32_t e = *(const lds_u32 *)(uintptr_t)addr<0>(c) & *(const lds_u32 *)(uintptr_t)(addr<1>(c) + 2048) &
-                     *(const lds_u32 *)(uintptr_t)(addr<2>(c) + 4096);
-        e &= *(const lds_u32 *)(uintptr_t)(addr<3>(c) + 6144) & *(const lds_u32 *)(uintptr_t)(addr<4>(c) + 8192);
-        return e & *(const lds_u32 *)(uintptr_t)(addr<5>(c) + 10240) & *(const lds_u32 *)(uintptr_t)(addr<6>(c) + 12288);
+    __device__ __forceinline__ uint32_t lookup(uint32_t c) const { return lookup_n<7>(c); }
+    __device__ __forceinline__ void insert(uint32_t c, uint32_t bit) const { insert_n<7>(c, bit); }
+    // The first NG groups only -- for an item none of whose PATTERN symbols has a bit at or above 3 NG (bp_item: Latin, Cyrillic, Greek,
+    // Arabic, Devanagari ... need four groups, the BMP six). A TEXT symbol with such a bit matches nothing: the last group's index is
+    // clamped to 8, which is entry 0 of the group behind it -- a group this item never enters anything into, so its entries are zero.
+    template <int NG, int G> __device__ __forceinline__ uint32_t entry_n(uint32_t c) const {
+        if constexpr (G + 1 == NG && NG < 7) {
+            uint32_t idx = c >> (3 * G);
+            idx = idx < 8u ? idx : 8u;
+            return *(const lds_u32 *)(uintptr_t)(tbase + (idx << 8) + 2048u * G);
+        } else {
+            return *(const lds_u32 *)(uintptr_t)(addr<G>(c) + 2048u * G);
+        }
     }
-    __device__ __forceinline__ void insert(uint32_t c, uint32_t bit) const {
+    template <int NG> __device__ __forceinline__ uint32_t lookup_n(uint32_t c) const {
+        uint32_t e = entry_n<NG, 0>(c) & entry_n<NG, 1>(c);
+        e &= entry_n<NG, 2>(c) & entry_n<NG, 3>(c);
+        if constexpr (NG > 4) e &= entry_n<NG, 4>(c);
+        if constexpr (NG > 5) e &= entry_n<NG, 5>(c);
+        if constexpr (NG > 6) e &= entry_n<NG, 6>(c);
+        return e;
+    }
+    template <int NG> __device__ __forceinline__ void insert_n(uint32_t c, uint32_t bit) const {
         __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)addr<0>(c), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<1>(c) + 2048), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<2>(c) + 4096), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<3>(c) + 6144), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<4>(c) + 8192), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<5>(c) + 10240), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<6>(c) + 12288), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (NG > 4) __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<4>(c) + 8192), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (NG > 5) __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<5>(c) + 10240), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (NG > 6) __hip_atomic_fetch_or((lds_u32 *)(uintptr_t)(addr<6>(c) + 12288), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
 
@@ -164,6 +180,7 @@ __device__ __forceinline__ void bp_item(const KernelArgs &args, BpWave<Sym> &wv,
         }
     };
     fetch_text(0 - (int)blk);
+    [[maybe_unused]] uint32_t groups = 7;   // (code points) 3-bit groups of the tables this item uses
 
     // ---- build the match tables of my block -------------------------------------------------
     if constexpr (kBytes) {
@@ -203,9 +220,23 @@ __device__ __forceinline__ void bp_item(const KernelArgs &args, BpWave<Sym> &wv,
 #pragma unroll
             for (int r = 0; r < 4; ++r) psym[q + r] = four[r];
         }
+        // how many 3-bit groups this ITEM needs: none of its pattern symbols has a bit at or above 3 x groups (wave-uniform)
+        uint32_t seen = 0;
 #pragma unroll
-        for (int q = 0; q < 32; ++q)
-            if ((uint32_t)q < brows) grp.insert(psym[q], 1u << q);
+        for (int q = 0; q < 32; ++q) seen |= (uint32_t)q < brows ? psym[q] : 0u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) seen |= (uint32_t)__shfl_xor((int)seen, off);
+        groups = seen < (1u << 12) ? 4u : (seen < (1u << 15) ? 5u : (seen < (1u << 18) ? 6u : 7u));
+        auto enter = [&](auto ng_tag) {
+            constexpr int NG = decltype(ng_tag)::value;
+#pragma unroll
+            for (int q = 0; q < 32; ++q)
+                if ((uint32_t)q < brows) grp.template insert_n<NG>(psym[q], 1u << q);
+        };
+        if (groups == 4) enter(std::integral_constant<int, 4>{});
+        else if (groups == 5) enter(std::integral_constant<int, 5>{});
+        else if (groups == 6) enter(std::integral_constant<int, 6>{});
+        else enter(std::integral_constant<int, 7>{});
     }
     acc[lane] = 0;
     wave_lds_fence();  // acc slots are accumulated into by other lanes below
@@ -241,6 +272,8 @@ __device__ __forceinline__ void bp_item(const KernelArgs &args, BpWave<Sym> &wv,
             mv = ph_s & xv;
         }
     };
+    auto columns = [&](auto ng_tag) {
+    [[maybe_unused]] constexpr int NG = decltype(ng_tag)::value;
     for (uint32_t s0 = 0; s0 < steps; s0 += 16) {
         uint32_t tcur[kTextRegs];
         if constexpr (kBytes) {
@@ -271,12 +304,18 @@ __device__ __forceinline__ void bp_item(const KernelArgs &args, BpWave<Sym> &wv,
                 eqs[3] = nib.template lookup<3>(tcur[q]);
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) eqs[u] = grp.lookup(tcur[q * 4 + u]);
+                for (int u = 0; u < 4; ++u) eqs[u] = grp.template lookup_n<NG>(tcur[q * 4 + u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) column(eqs[u], gs + u);
         }
     }
+    };
+    if constexpr (kBytes) columns(std::integral_constant<int, 7>{});
+    else if (groups == 4) columns(std::integral_constant<int, 4>{});
+    else if (groups == 5) columns(std::integral_constant<int, 5>{});
+    else if (groups == 6) columns(std::integral_constant<int, 6>{});
+    else columns(std::integral_constant<int, 7>{});
 
     // ---- distance = n + sum over blocks popcount(pv) - popcount(mv) -------------------------
     const uint32_t mask = brows >= 32 ? 0xFFFFFFFFu : ((1u << brows) - 1u);
@@ -289,9 +328,18 @@ __device__ __forceinline__ void bp_item(const KernelArgs &args, BpWave<Sym> &wv,
         if (staged && bounded < 0xFFFFu) staged[p - staged_base] = (uint16_t)bounded;   // (0xFFFF: "no distance here")
         else store_result(args.job, p, (int64_t)bounded);
     }
-    // ---- clear my table column ---------------------------------------------------------------
+    // ---- clear my table column (code points: the groups this item entered symbols into) -----
+    if constexpr (kBytes) {
 #pragma unroll
-    for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
+        for (int k = 0; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) table[k * 64 + lane] = 0;
+        if (groups > 4) {
+#pragma unroll
+            for (int k = 32; k < BpTraits<Sym>::kEntries; ++k) table[k * 64 + lane] = 0;
+        }
+    }
     wave_lds_fence();
 }
 

@@ -6,6 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import stringwars_amd as sw, oracle
 rng = np.random.default_rng(5)
 scripts = [0x41, 0x62, 0xE9, 0x416, 0x434, 0x4E2D, 0x6587, 0x1F600, 0x20AC, 0x7FF, 0x800]
+if "--low" in sys.argv:     # Latin and Cyrillic only: every symbol below U+0800 (the tables' first four 3-bit groups)
+    scripts = [0x41, 0x62, 0x65, 0x74, 0xE9, 0xFC, 0x416, 0x434, 0x43E, 0x442, 0x451]
+if "--bmp" in sys.argv:     # no astral symbols: six groups
+    scripts = [0x41, 0x62, 0xE9, 0x416, 0x434, 0x4E2D, 0x6587, 0x20AC, 0x7FF, 0x800, 0x3042]
 def word(n): return "".join(chr(scripts[i]) for i in rng.integers(0, len(scripts), n))
 A, B = [], []
 for _ in range(60000):
@@ -34,4 +38,4 @@ while time.perf_counter() < until:
 best = 1e9
 for _ in range(7):
     eng.pairs(pa, pb, scope); t = scope.last_timing(); best = min(best, t["compute_ms"])
-print("pairs", len(A), "kernel ms", round(best, 4), t["dominant_name"], "TCUPS", round(t["cells"] / best / 1e9, 1))
+print("scripts", "low" if "--low" in sys.argv else ("bmp" if "--bmp" in sys.argv else "all"), "pairs", len(A), "kernel ms", round(best, 4), t["dominant_name"], "TCUPS", round(t["cells"] / best / 1e9, 1))

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""bench.py -- GCUPS of batched Levenshtein on MI355X (BASELINE.json metric), one JSON line from rank 0.
+"""bench.py -- GCUPS of batched Levenshtein on MI355X (BASELINE.json metric): rank 0's stdout ENDS with one short JSON line (the headline,
+held to 6 KB at N = 1 and 8 KB beyond: `fit_line`), preceded by one short `{"leg": ...}` line per other config; the full per-config entries,
+CPU rows and rank identities go to --details-out (bench_configs.json) and to stderr.
 
 A "step" is ONE SYNCHRONOUS CALL of the hot path over one batch held resident in HBM -- results visible on return,
 the reference's own metric (`compute_into` inside `measure_throughput`, bench.rs:478-486, utils.rs:721-799) -- with tapes
@@ -21,12 +23,14 @@ algorithm skips. Fields of the line:
   value_steady       the same calls over at least `--steady-seconds` (default 1 s) of wall time
   value_pipelined    K steps enqueued asynchronously on two internal lanes (not the reference's metric; what a caller
                      that does not need each result before the next call gets)
-  roofline           dominant kernel of the synchronous call: executed lane-ops (PMC constants, profiles/r5) over the kernel
+  roofline           dominant kernel of the synchronous call: executed lane-ops (PMC constants, profiles/r6) over the kernel
                      time measured live with hipEvents inside the library, on the kernel's own stream
   configs            (N = 1) every other BASELINE config at full size, same measurement per entry: C1, C3 prepared / raw,
-                     C4 linear / affine / full byte alphabet, C5 at 20 M pairs per GPU -- each with its synchronous-call
-                     GCUPS, kernel time, roofline object and a parity check against the oracle
+                     C4 linear / affine / full byte alphabet, C5 at 20 M pairs per GPU, Smith-Waterman on C4's sequences, the
+                     2048 x 2048 cross-product call -- in the line: {name: value, ms, kernel, kernel_ms, frac, parity}; in
+                     --details-out: each with its roofline object, traffic and parity sample
   cpu_baseline(s)    the oracle's CPU rows on this box's host cores, bounded samples (rank 0, N = 1)
+  details            where the full entries were written
 
 Order of a run: data, tapes, `--prewarm-seconds` of untimed steps (an idle MI355X needs a few hundred milliseconds of work
 to reach its clocks), W warm-up steps, the K timed steps, a profiled repeat, the steady-state loop, the pipelined steps,
@@ -69,7 +73,7 @@ PEAK_HBM_GBS = 8000.0
 NOMINAL_OPS_PER_CELL = {"lev": 5, "lev_utf8": 5, "nw_linear": 6, "nw_affine": 11}
 # Executed VALU instructions and HBM traffic per call come from rocprofv3 PMC passes over `bench.py --only-config ...`
 # (tools/refresh_profiles.sh -> tools/pmc_constants.py); they cannot be read from inside the process.
-PMC_CONSTANTS = os.path.join(ROOT, "profiles", "r5", "pmc_constants.json")
+PMC_CONSTANTS = os.path.join(ROOT, "profiles", "r6", "pmc_constants.json")
 PMC_CONSTANTS_NAME = os.path.relpath(PMC_CONSTANTS, ROOT)
 
 CONFIGS = {
@@ -107,11 +111,23 @@ LEGS = {
                       text="C4: NW, 256x256 i8 matrix (20 amino acids + other), 10 K pairs ~4 KB, linear gaps -4"),
     "c4_affine": dict(workload="protein4k", pairs=10_000, kind="nw", gaps=(-11, -1), prepared=True, variant="affine", check=128,
                       text="C4 with affine gaps (-11, -1)"),
-    "c4_bytes": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=128,
-                     text="C4 over the full byte alphabet (all 256 classes of the matrix in use), 2 K pairs ~4 KB, linear gaps -4"),
-    "c4_letters52": dict(workload="bytes4k", pairs=2_000, kind="nw", gaps=(-4, -4), prepared=True, variant="letters52", check=128, letters=52,
+    "c4_bytes": dict(workload="bytes4k", pairs=10_000, kind="nw", gaps=(-4, -4), prepared=True, variant="linear", check=128,
+                     text="C4 over the full byte alphabet (all 256 classes of the matrix in use), 10 K pairs ~4 KB, linear gaps -4 (BASELINE configs[3] as worded)"),
+    "c4_letters52": dict(workload="bytes4k", pairs=10_000, kind="nw", gaps=(-4, -4), prepared=True, variant="letters52", check=128, letters=52,
                          text="C4 over a 52-letter alphabet (a-z, A-Z: what a rust-bio style scoring closure over mixed-case text distinguishes, "
-                              "bench.rs:746-752; 53 symbol classes), 2 K pairs ~4 KB, linear gaps -4: the column-profile kernel on the wide class table"),
+                              "bench.rs:746-752; 53 symbol classes), 10 K pairs ~4 KB, linear gaps -4: the column-profile kernel on the wide class table"),
+    # SmithWatermanScores (bench.rs:882-963) on C4's sequences, and the reference's own call shape -- compute_into(queries, candidates, &mut matrix),
+    # bench.rs:478-486, :599-603 -- at the side its H100 tables use (similarities/README.md:22: 16384 per core -> side 2048 on 256 CUs)
+    "sw_linear": dict(workload="protein4k", pairs=10_000, kind="nw", local=True, gaps=(-4, -4), prepared=True, variant="sw_linear", check=32,
+                      text="Smith-Waterman local score on C4's sequences: 256x256 i8 matrix, 10 K pairs ~4 KB, linear gaps -4"),
+    "sw_affine": dict(workload="protein4k", pairs=10_000, kind="nw", local=True, gaps=(-11, -1), prepared=True, variant="sw_affine", check=32,
+                      text="Smith-Waterman local score on C4's sequences with affine gaps (-11, -1)"),
+    "cross_lev": dict(workload="acgt100", side=2048, pairs=2048 * 2048, kind="lev", cross=True, prepared=True, variant="cross", check=4096,
+                      text="cross-product: 2048 queries x 2048 candidates of 100 ACGT bytes (the reference's compute_into shape, bench.rs:478-486), "
+                           "unit-cost Levenshtein, u64 matrix on the device"),
+    "cross_nw": dict(workload="acgt100", side=2048, pairs=2048 * 2048, kind="nw", cross=True, gaps=(-2, -2), unary=(2, -1), prepared=True,
+                     variant="cross_linear", check=4096,
+                     text="cross-product: 2048 x 2048 ACGT-100 strings, NeedlemanWunschScores with unary_class_costs(2, -1), linear gaps -2 (bench.rs:658-662, :814-821)"),
     "c5": dict(workload="short_words", pairs=20_000_000, kind="lev", prepared=True, check=200_000,
                text="C5: one GPU's share of the 100 M short-word pairs (20 M pairs <= 16 B, mean ~6), unbounded Levenshtein"),
     # beyond BASELINE's five: what round 4 added kernels for
@@ -121,7 +137,8 @@ LEGS = {
                      text="NW on word-sized strings (the reference's default `words` token mode, bench.rs:271): 4 M pairs <= 16 B, "
                           "unary_class_costs(2, -1) as a 32-class table, linear gaps -2 -- one pair per lane (alignshort.hip)"),
 }
-DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words"]
+DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words",
+                "sw_linear", "sw_affine", "cross_lev", "cross_nw"]
 
 
 def parse_args():
@@ -161,6 +178,8 @@ def parse_args():
     p.add_argument("--die-rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: this rank exits with code 3 ...
     p.add_argument("--die-at", default="start", choices=["start", "after-init", "measure"], help=argparse.SUPPRESS)   # ... at this point
     p.add_argument("--c5-pairs", type=int, default=0, help="at N > 1: total pairs of the C5 strong-scaling entry (default 100 M; testing)")
+    p.add_argument("--details-out", default=os.path.join(ROOT, "bench_configs.json"),
+                   help="where rank 0 writes the FULL per-config entries, CPU rows and rank list (the stdout line carries their summary only)")
     return p.parse_args()
 
 
@@ -342,7 +361,19 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
     leg = LEGS[name]
     pairs = pairs_override or leg["pairs"]
     started = time.perf_counter()
-    a, b = sw.generate_pairs(leg["workload"], pairs, seed=seed)
+    cross = bool(leg.get("cross"))
+    if cross:
+        # queries [0, side) x candidates [side, 2*side) of one token tape (bench.rs:113-148): fixed-length ACGT strings, the
+        # reference's DNA datasets in synthetic form (similarities/README.md:30-40)
+        side = max(2, int(round(pairs ** 0.5))) if pairs_override else leg["side"]
+        pairs = side * side
+        length = int(leg["workload"][4:])
+        rng = np.random.default_rng(seed)
+        offsets = (np.arange(2 * side + 1, dtype=np.uint64) * length)
+        tape = sw.Strs(data=np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2 * side * length)], offsets=offsets)
+        a, b = sw.Strs(data=tape.data[:side * length], offsets=offsets[:side + 1].copy()), sw.Strs(data=tape.data[side * length:], offsets=offsets[:side + 1].copy())
+    else:
+        a, b = sw.generate_pairs(leg["workload"], pairs, seed=seed)
     letters = None
     if leg.get("letters"):   # the byte workload folded onto an alphabet of that many letters (a-z, A-Z, 0-9 ...): same lengths, same edits
         letters = (bytes(range(97, 123)) + bytes(range(65, 91)) + bytes(range(48, 58)))[:leg["letters"]]
@@ -357,21 +388,25 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
     da = sw.DeviceTape(tensors[0].data_ptr(), tensors[1].data_ptr(), a.count, a.offsets.dtype, keepalive=tensors[:2])
     db = sw.DeviceTape(tensors[2].data_ptr(), tensors[3].data_ptr(), b.count, b.offsets.dtype, keepalive=tensors[2:])
     kind, utf8 = leg["kind"], leg["kind"] == "lev_utf8"
-    out = torch.zeros(pairs + 4, dtype=torch.int32, device=device)
+    out = torch.zeros(pairs + 4, dtype=torch.int64 if cross else torch.int32, device=device)
+    nw_engine = sw.SmithWatermanScores if leg.get("local") else sw.NeedlemanWunschScores
     if kind == "nw" and leg.get("unary"):
         byte_to_class, class_costs = sw.unary_class_costs(*leg["unary"])       # bench.rs:98-108: class = byte % 32
         matrix = class_costs[byte_to_class][:, byte_to_class].astype(np.int8)  # the same scoring as a 256 x 256 table (what the oracle takes)
-        engine = sw.NeedlemanWunschScores(byte_to_class, class_costs, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)
+        engine = nw_engine(byte_to_class, class_costs, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)
         model = "nw_linear" if leg["gaps"][0] == leg["gaps"][1] else "nw_affine"
     elif kind == "nw":
         alphabet = letters if letters else (None if leg["workload"] == "bytes4k" else sw.synth.AMINO_ACIDS)
         matrix = sw.substitution_matrix(seed, alphabet)
-        engine = sw.NeedlemanWunschScores(substitution_matrix=matrix, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)
+        engine = nw_engine(substitution_matrix=matrix, open=leg["gaps"][0], extend=leg["gaps"][1], capabilities=scope)
         model = "nw_linear" if leg["gaps"][0] == leg["gaps"][1] else "nw_affine"
     else:
         engine = (sw.LevenshteinDistancesUTF8 if utf8 else sw.LevenshteinDistances)(capabilities=scope, algorithm=algorithm)
         model = kind
-    if leg["prepared"]:
+    if cross:
+        pa, pb = sw.PreparedTape(scope, da, utf8=utf8), sw.PreparedTape(scope, db, utf8=utf8)
+        call = lambda: engine(pa, pb, scope, out=out.data_ptr())     # compute_into(queries, candidates, &mut matrix): 64-bit entries, row-major
+    elif leg["prepared"]:
         pa, pb = sw.PreparedTape(scope, da, utf8=utf8), sw.PreparedTape(scope, db, utf8=utf8)
         call = engine.bind_pairs(pa, pb, scope, out, bound=leg.get("bound")) if kind != "nw" else engine.bind_pairs(pa, pb, scope, out)
     elif kind == "nw":
@@ -426,8 +461,8 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
         lengths_a, lengths_b = codepoint_lengths(a), codepoint_lengths(b)
     else:
         lengths_a, lengths_b = a.lengths.astype(np.int64), b.lengths.astype(np.int64)
-    cells = int((lengths_a * lengths_b).sum())
-    algorithmic_bytes = int(a.data.nbytes + b.data.nbytes + 2 * pairs * a.offsets.dtype.itemsize + 4 * pairs)
+    cells = int(lengths_a.sum()) * int(lengths_b.sum()) if cross else int((lengths_a * lengths_b).sum())
+    algorithmic_bytes = int(a.data.nbytes + b.data.nbytes + 2 * len(lengths_a) * a.offsets.dtype.itemsize + (8 if cross else 4) * pairs)
     entry = {"config": name, "workload": leg["text"], "pairs": pairs, "cells": cells, "dtype": "i32" if kind == "nw" else "u32",
              "tapes": "prepared" if leg["prepared"] else "raw device tapes", "offsets": str(a.offsets.dtype)}
     if timed_calls:
@@ -448,17 +483,123 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
         import oracle  # the checker; the timed calls above never touch it
         count = min(pairs, leg["check"])
         got = out[:pairs].cpu().numpy()
-        if kind == "nw":
+        if cross:
+            # the first and the last rows of the matrix (and as many in between as `check` allows), entry by entry
+            rows = sorted(set(np.linspace(0, len(lengths_a) - 1, max(2, count // len(lengths_b))).astype(int).tolist()))
+            grid = got.reshape(len(lengths_a), len(lengths_b))
+            ok = True
+            for r in rows:
+                if kind == "nw":
+                    want = [oracle.nw_score(a[r], b[c], matrix, leg["gaps"][0], leg["gaps"][1], local=bool(leg.get("local"))) for c in range(len(lengths_b))]
+                else:
+                    want = [oracle.levenshtein(a[r], b[c], algo="hyyro") for c in range(len(lengths_b))]
+                ok = ok and bool((grid[r].astype(np.int64) == np.array(want, dtype=np.int64)).all())
+            count = len(rows) * len(lengths_b)
+        elif kind == "nw" and leg.get("local"):
+            want = np.array([oracle.nw_score(a[i], b[i], matrix, leg["gaps"][0], leg["gaps"][1], local=True) for i in range(count)], dtype=np.int64)
+            ok = bool((got[:count].astype(np.int64) == want).all())
+        elif kind == "nw":
             want = oracle.nw_pairs(a, b, matrix, leg["gaps"][0], leg["gaps"][1], count=count)
             ok = bool((got[:count].astype(np.int64) == want.astype(np.int64)).all())
         else:
             want = oracle.levenshtein_pairs(a, b, utf8=utf8, algo="hyyro" if not utf8 else "wf", bound=leg.get("bound"), count=count)
             ok = bool((got[:count].astype(np.uint32) == want.astype(np.uint32)).all())
         entry["parity_vs_oracle"] = ok
-        entry["parity_sample"] = f"first {count} pairs of the call's results against oracle/"
+        entry["parity_sample"] = (f"{count} entries (whole rows) of the call's matrix against oracle/" if cross else
+                                  f"first {count} pairs of the call's results against oracle/")
     entry["generate_s"] = round(generate_s, 2)
     del call, engine
     return entry
+
+
+# ---- what goes where ---------------------------------------------------------------------------------------------------------------
+# stdout ends with ONE short headline line (the reference's reporter prints one short line per variant, utils.rs:652-692): the
+# driver parses that line, so it is held to LINE_BUDGET bytes. Before it, one short summary line per config (`{"leg": ...}`); the
+# full entries -- prose, traffic detail, PMC provenance, CPU samples, every rank's identity -- go to --details-out (JSON) and, one
+# line each, to stderr.
+LINE_BUDGET = {1: 6144}
+LINE_BUDGET_MANY = 8192
+
+
+def line_budget(world):
+    return LINE_BUDGET.get(world, LINE_BUDGET_MANY)
+
+
+ROOFLINE_KEYS = ("bound", "kernel", "kernel_ms", "unit", "peak", "achieved", "frac", "traffic", "lane_ops_per_cell", "nominal_ops_per_cell_equiv",
+                 "hbm", "pmc_stale", "launches_timed", "all_kernels_ms", "kernel_ms_scaled_to_step", "families_summed")
+
+
+def compact_roofline(roof):
+    """The roofline object of the headline line: every number, none of the prose (that stays in --details-out)."""
+    if not roof:
+        return roof
+    out = {k: roof[k] for k in ROOFLINE_KEYS if k in roof}
+    if roof.get("traffic_detail"):
+        out["traffic_vs_algorithmic"] = roof["traffic_detail"]["vs_algorithmic"]
+    return out
+
+
+def compact_leg(entry):
+    """One config's summary for the headline's `configs` map and its own short stdout line."""
+    if "error" in entry:
+        return {"error": str(entry["error"])[:160]}
+    roof = entry.get("roofline") or {}
+    out = {"value": entry.get("value"), "ms": entry.get("ms_per_call", entry.get("ms_per_step")), "pairs": entry.get("pairs", entry.get("pairs_total")),
+           "kernel": roof.get("kernel", entry.get("dominant_kernel")), "kernel_ms": roof.get("kernel_ms", entry.get("kernel_ms_rank0_per_step")),
+           "frac": roof.get("frac"), "parity": entry.get("parity_vs_oracle")}
+    if "gather_ok" in entry:
+        out["gather_ok"] = entry["gather_ok"]
+        out["n_gpus"] = entry.get("n_gpus")
+        if entry.get("gather"):
+            out["gather_exposed_ms"] = entry["gather"].get("exposed_ms_per_step")
+        if isinstance(entry.get("gather_u8"), dict):
+            out["gather_u8_value"] = entry["gather_u8"].get("value", entry["gather_u8"].get("error"))
+    return out
+
+
+def compact_single_process(child):
+    if child is None:
+        return None
+    if "error" in child:
+        return {"error": str(child["error"])[:200]}
+    return {"mode": child.get("mode"), "value": child.get("value"), "ms_per_step": child.get("ms_per_step"), "n_gpus": child.get("n_gpus"),
+            "device_count": (child.get("config") or {}).get("device_count"), "parity_vs_oracle": child.get("parity_vs_oracle"), "gather_ok": child.get("gather_ok")}
+
+
+def write_details(path, details):
+    """The full entries: a JSON file beside the script (or wherever --details-out points) and one line each on stderr."""
+    for key, value in details.items():
+        rows = value if isinstance(value, list) else [value]
+        for row in rows:
+            print(json.dumps({"detail": key, **row} if isinstance(row, dict) else {"detail": key, "value": row}), file=sys.stderr, flush=True)
+    if not path:
+        return None
+    try:
+        with open(path, "w") as handle:
+            json.dump(details, handle, indent=1)
+        return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+    except OSError as error:
+        return f"not written ({error})"
+
+
+def fit_line(line, world):
+    """Serialises the headline line and holds it to its byte budget: what does not fit is dropped from the least important end
+    (the per-config map loses its kernel names and times first), never the contract's keys."""
+    budget = line_budget(world)
+    text = json.dumps(line)
+    for shed in ("kernel", "kernel_ms", "ms", "pairs"):
+        if len(text) <= budget:
+            break
+        for summary in (line.get("configs") or {}).values():
+            summary.pop(shed, None)
+        text = json.dumps(line)
+    if len(text) > budget:
+        for key in ("cpu_baselines", "gather", "single_process", "configs"):
+            if len(text) <= budget:
+                break
+            line[key] = "see " + str(line.get("details"))
+            text = json.dumps(line)
+    return text
 
 
 def free_port():
@@ -508,7 +649,7 @@ def self_launch(args):
         for row in child.stdout:
             sys.stdout.write(row)
             sys.stdout.flush()
-            if row.startswith("{") and ('"metric"' in row or '"error"' in row):
+            if row.startswith('{"metric"'):
                 seen["line"] = True
             seen["tail"] = (seen["tail"] + [row.rstrip()])[-5:]
     reader = threading.Thread(target=pump, daemon=True)
@@ -895,7 +1036,8 @@ def main():
         raise
     except BaseException as error:   # a rank that cannot go on says so in a JSON line (rank 0's is THE line; the launcher adds one if none came)
         rank = int(os.environ.get("RANK", "0"))
-        print(error_line(args, f"rank {rank}: {type(error).__name__}: {error}", rank=rank), flush=True)
+        # ONE line on stdout: rank 0's (the launcher adds one if rank 0 never spoke); the other ranks say theirs on stderr
+        print(error_line(args, f"rank {rank}: {type(error).__name__}: {error}", rank=rank), file=sys.stdout if rank == 0 else sys.stderr, flush=True)
         import traceback
         traceback.print_exc()
         os._exit(1)        # not sys.exit: a process group whose peer is gone can hang in its destructors
@@ -922,7 +1064,8 @@ def run(args):
         import signal
 
         def terminated(signum, frame):
-            print(error_line(args, f"rank {rank}: terminated by signal {signum} (another rank failed, or the launcher gave up)", rank=rank), flush=True)
+            print(error_line(args, f"rank {rank}: terminated by signal {signum} (another rank failed -- its own message is on stderr --, or the launcher gave up)",
+                             rank=rank), file=sys.stdout if rank == 0 else sys.stderr, flush=True)
             os._exit(1)
         signal.signal(signal.SIGTERM, terminated)
 
@@ -1017,17 +1160,17 @@ def run(args):
         unprofiled_ms_per_step = head["elapsed"] / args.steps * 1e3
         # (only then: where the profiled repeat's kernel time fits inside the timed steps it is reported as measured -- the figure the
         # committed `rocprofv3 --kernel-trace --stats` average must agree with)
-        scale = 1.0
+        # (advisor, round 5: the headline kernel time is the MEASURED one; the figure brought to the timed steps' scale rides beside it)
+        scaled_ms = None
         if kernel_ms > unprofiled_ms_per_step and profiled_ms_per_step > 0:
-            scale = min(1.0, unprofiled_ms_per_step / profiled_ms_per_step)
-        kernel_ms_profiled = kernel_ms
-        kernel_ms *= scale
+            scaled_ms = kernel_ms * min(1.0, unprofiled_ms_per_step / profiled_ms_per_step)
+        extra = {"all_kernels_ms": round(totals["total_ms"] / calls_timed, 4), "launches_timed": totals["calls"],
+                 "profiled_repeat_ms_per_step": round(profiled_ms_per_step, 4),
+                 "measured": "hipEvents inside the library over a repeat of the K timed synchronous steps (average per call), on the kernel's own stream"}
+        if scaled_ms is not None:
+            extra["kernel_ms_scaled_to_step"] = round(scaled_ms, 4)
         roofline = roofline_of(sync_timing["dominant_name"], kernel_ms, int(cells / n_pieces), int(sync_timing["bytes"]), head["workload"],
-                               pairs // n_pieces, constants,
-                               extra={"all_kernels_ms": round(totals["total_ms"] / calls_timed * scale, 4), "launches_timed": totals["calls"],
-                                      "kernel_ms_profiled_repeat": round(kernel_ms_profiled, 4), "profiled_repeat_ms_per_step": round(profiled_ms_per_step, 4),
-                                      "measured": "hipEvents inside the library over a repeat of the K timed synchronous steps (average per call), scaled by "
-                                                  "ms_per_step / profiled_repeat_ms_per_step where the repeat with event pairs ran slower than the timed steps"})
+                               pairs // n_pieces, constants, extra=extra)
         roofline["unit_note"] = "bound = integer VALU issue (not MFMA: min-plus has no dense contraction; not HBM: see `hbm`)"
         parity = None
         cpu_baseline, cpu_baselines = None, None
@@ -1080,6 +1223,20 @@ def run(args):
             cpu_baseline = {k: v for k, v in cpu_baselines[0].items() if k != "name"}
         elapsed, steady = head["elapsed"], head["steady"]
         ms_per_step = elapsed / args.steps * 1e3
+        # the full entries (--details-out, stderr) ...
+        details = {
+            "headline": {"config": args.config, "workload": cfg["text"].format(pairs=head["total_pairs"] if strong else pairs) + ", tapes prepared and resident in HBM",
+                         "value_is": "rate of the K timed steps; a step is one synchronous call (results visible on return; the reference's "
+                                     "compute_into metric, utils.rs:721-799); a call returns when every result has been written through and "
+                                     "acknowledged (the kernel's summary in host-mapped memory), "
+                                     + ("as built" if os.environ.get("STRINGWARS_AMD_EARLY_RETURN", "1") != "0" else "switched off: it waits for the stream")
+                                     + " (DESIGN.md 3)" + (" followed by the gather of the distances to rank 0, which overlaps the next step's call" if world > 1 else ""),
+                         "value_steady_is": f"the same steps over >= {args.steady_seconds} s: {steady}" if steady else None,
+                         "value_pipelined_is": "K steps enqueued asynchronously on two internal lanes" + (f", {round(head['pipelined_ms'], 4)} ms per step" if head["pipelined_ms"] else ""),
+                         "device_prewarm_s": args.prewarm_seconds, "roofline": roofline, "gather": head["gather"]},
+            "configs": leg_entries or [], "cpu_baselines": cpu_baselines or [], "ranks_seen": ranks_seen,
+        }
+        # ... and the headline line: the contract's keys, every number of the roofline object, one summary per config
         line = {
             "metric": "GCUPS (DP cell updates/s) batched Levenshtein", "value": round(head["total_cells"] * args.steps / elapsed / 1e9, 2),
             "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1087,18 +1244,16 @@ def run(args):
             "dtype": "u32", "data": "synthetic",
             "value_steady": steady["value"] if steady else None, "value_pipelined": head["pipelined_rate"],
             "config": {"workload": cfg["text"].format(pairs=head["total_pairs"] if strong else pairs) + ", tapes prepared and resident in HBM",
-                       "value_is": "rate of the K timed steps; a step is one synchronous call (results visible on return; the reference's "
-                                   "compute_into metric, utils.rs:721-799); a call returns when every result has been written through and "
-                                   "acknowledged (the kernel's summary in host-mapped memory), "
-                                   + ("as built" if os.environ.get("STRINGWARS_AMD_EARLY_RETURN", "1") != "0" else "switched off: it waits for the stream")
-                                   + " (DESIGN.md 3)" + (" followed by the gather of the distances to rank 0, which overlaps the next step's call" if world > 1 else ""),
-                       "value_steady_is": f"the same steps over >= {args.steady_seconds} s: {steady}" if steady else None,
-                       "value_pipelined_is": "K steps enqueued asynchronously on two internal lanes" + (f", {round(head['pipelined_ms'], 4)} ms per step" if head["pipelined_ms"] else ""),
+                       "step": "one synchronous call (results visible on return)" + (" + gather of the u32 distances to rank 0" if world > 1 else ""),
                        "pairs_per_gpu": pairs, "pairs_total": head["total_pairs"], "cells_per_gpu": cells, "algorithm": args.algorithm,
-                       "offsets": str(head["offsets_dtype"]), "pieces_per_step": n_pieces, "device_prewarm_s": args.prewarm_seconds,
-                       "collective": collective_text(strong, world), "seed": args.seed},
-            "roofline": roofline, "configs": leg_entries, "cpu_baseline": cpu_baseline, "cpu_baselines": cpu_baselines,
-            "parity_vs_oracle": parity, "gather_ok": head["gather_ok"], "gather": head["gather"], "ranks_seen": ranks_seen,
+                       "offsets": str(head["offsets_dtype"]), "pieces_per_step": n_pieces, "collective": collective_text(strong, world), "seed": args.seed},
+            "roofline": compact_roofline(roofline),
+            "cpu_baseline": {k: (v[:200] if isinstance(v, str) else v) for k, v in cpu_baseline.items()} if cpu_baseline else None,
+            "cpu_baselines": {row["name"]: {"value": row["value"], "cores": row["cores"]} for row in cpu_baselines} if cpu_baselines else None,
+            "configs": {entry["config"]: compact_leg(entry) for entry in leg_entries} if leg_entries is not None else None,
+            "parity_vs_oracle": parity, "gather_ok": head["gather_ok"],
+            "gather": {k: head["gather"][k] for k in ("exposed_ms_per_step", "alone_ms", "transport", "bytes_to_root_per_step", "compute_only_ms_per_step")} if head["gather"] else None,
+            "ranks_seen": {k: ranks_seen[k] for k in ("world_size", "backend", "rccl_version", "distinct_devices")} if ranks_seen else None,
         }
     if world > 1:
         dist.barrier()
@@ -1125,9 +1280,13 @@ def run(args):
                 child = {"error": f"exit code {done.returncode}", "stderr_tail": done.stderr[-600:]}
         except subprocess.TimeoutExpired:
             child = {"error": f"no line within {args.single_process_timeout} s"}
-        line["single_process"] = child
+        details["single_process"] = child
+        line["single_process"] = compact_single_process(child)
     if line is not None:
-        print(json.dumps(line), flush=True)
+        for entry in details["configs"]:                     # one short line per config, before the headline line
+            print(json.dumps({"leg": entry["config"], **compact_leg(entry)}), flush=True)
+        line["details"] = write_details(args.details_out, details)
+        print(fit_line(line, world), flush=True)
 
 
 if __name__ == "__main__":

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
             align_fetch<W / 4>(a_data, a0, a_total, aw);
             align_fetch<W / 4>(b_data, b0, b_total, bw);
             const bool fits = have && la <= (uint32_t)W && lb <= (uint32_t)W;
-            if (have && !fits) misfit = 1;
+            if (have && !fits) misfit |= 1;
             const bool runs = fits && la && lb;
             const uint32_t m = runs ? la : 0u, n = runs ? lb : 0u;
             const uint32_t m_max = wave_max_u32(m), n_max = wave_max_u32(n);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
             uint32_t bw[W / 4];
             align_fetch<W / 4>(b_data, b0, b_total, bw);
             const bool fits = have && lb <= (uint32_t)W;
-            if (have && !fits) misfit = 1;
+            if (have && !fits) misfit |= 1;
             const uint32_t n = fits ? lb : 0u;
             const uint32_t n_max = wave_max_u32(n);
             uint32_t bcls[W / 4], sel[(W / 4) * PQ];
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_short(AlignShortArgs
                 const uint32_t qlen = wl.qlen[q];
                 sum_m += qlen;
                 item_maxa = qlen > item_maxa ? qlen : item_maxa;
-                if (qlen > (uint32_t)W) { misfit = 1; continue; }
+                if (qlen > (uint32_t)W) { misfit |= 1; continue; }
                 // (rows two at a time -- align_rows_uniform -- pay for strings of ~100 symbols; on words of ~5 the pair's extra step
                 // and registers cost more than the second chain returns: 2048 x 2048 words 1.40 -> 1.00 TCUPS, measured)
                 uint32_t acls[W / 4];
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
         uint32_t lb = 0;
         if (have) align_extent(job.b.offsets, args.off64, cand, b0, lb);
         const bool fits = have && lb <= (uint32_t)W;
-        if (have && !fits) misfit = 1;
+        if (have && !fits) misfit |= 1;
         const uint32_t n = fits ? lb : 0u;
         const uint32_t n_max = wave_max_u32(n);
         // -- my candidate: bytes -> classes (packed four to a dword), and the set of classes it uses
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
             const uint32_t qlen = wl.qlen[q];
             sum_m += qlen;
             item_maxa = qlen > item_maxa ? qlen : item_maxa;
-            if (qlen > (uint32_t)W) { misfit = 1; continue; }
+            if (qlen > (uint32_t)W) { misfit |= 1; continue; }
             if (!compact) continue;
             int score = align_rows_uniform<W, 1, false, kLocal>(wl.qcls[q], qlen, sel, n, n_max, (const char *)&wl.ctab[0][0], 8u, open, ext);
             if (fits) {
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignS
         uint32_t lb = 0;
         if (have) align_extent(job.b.offsets, args.off64, cand, b0, lb);
         const bool fits = have && lb <= 0x00FFFFFFu;
-        if (have && !fits) misfit = 1;
+        if (have && !fits) misfit |= 1;
         const uint32_t n = fits ? lb : 0u;
         const uint32_t n_max = wave_max_u32(n);
         const uint32_t passes = (n_max + W - 1) / W;
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignS
             align_extent(job.a.offsets, args.off64, q_first + q, qa0, qlen);
             sum_m += qlen;
             item_maxa = qlen > item_maxa ? qlen : item_maxa;
-            if (qlen > kAlignLongRows || qlen + 4 > rows_cap) { misfit = 1; continue; }
+            if (qlen > kAlignLongRows || qlen + 4 > rows_cap) { misfit |= 1; continue; }
             if (!compact) continue;
             // -- the query into LDS as class bytes, 1 KB per round
             wave_lds_fence();

@@ -48,8 +48,8 @@ __device__ __forceinline__ uint32_t plan_key(uint32_t la, uint32_t lb, uint32_t 
         }
         // more than 64 blocks: several passes of 64 blocks over the text (k_bitparallel_long), which draws its pairs from the END of the
         // class: the order is by what a pair costs its wave -- passes x text steps --, heaviest last
-        uint32_t bucket = (((g + 63) >> 6) * txt_len) >> 9;
-        return kClassBpLong * kBuckets + (bucket > 63 ? 63 : bucket);
+        uint64_t bucket = ((uint64_t)((g + 63) >> 6) * txt_len) >> 9;   // (64 bits: passes x text length wraps a u32 from ~16 M x 16 M symbols)
+        return kClassBpLong * kBuckets + (bucket > 63 ? 63u : (uint32_t)bucket);
     }
     uint32_t cols = symmetric ? m : lb, rows = symmetric ? n : la;
     uint32_t cls, bucket;

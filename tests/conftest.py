@@ -30,6 +30,12 @@ def scope(sw):
     return sw.DeviceScope(gpu_device=0)
 
 
+def child_pythonpath() -> str:
+    """PYTHONPATH of a child process a test starts: the repo root IN FRONT of whatever this run inherited (never instead of it)."""
+    inherited = os.environ.get("PYTHONPATH", "")
+    return ROOT + (os.pathsep + inherited if inherited else "")
+
+
 def run_in_child(request, env=None, test_library=False, timeout=1800) -> bool:
     """For tests that need an environment switch the library reads once per process, or a test hook that only the TEST build of the
     library carries (libstringwars_amd_test.so, -DSWH_TEST_HOOKS): the test runs AGAIN in a child process with that environment
@@ -37,10 +43,14 @@ def run_in_child(request, env=None, test_library=False, timeout=1800) -> bool:
     import subprocess
     if os.environ.get("SWH_TEST_CHILD") == request.node.nodeid:
         return True
-    child_env = dict(os.environ, SWH_TEST_CHILD=request.node.nodeid, PYTHONPATH=ROOT, **(env or {}))
+    # ROOT goes IN FRONT of the inherited PYTHONPATH (site hooks and paths the parent run relies on -- the driver's observation hook
+    # among them -- stay in force in the child), and the child's test id is built from the test's file relative to ROOT, so it
+    # collects the same test whatever directory the parent was started from
+    child_env = dict(os.environ, SWH_TEST_CHILD=request.node.nodeid, PYTHONPATH=child_pythonpath(), **(env or {}))
     if test_library:
         child_env["STRINGWARS_AMD_LIBRARY"] = os.path.join(ROOT, "stringwars_amd", "libstringwars_amd_test.so")
-    done = subprocess.run([sys.executable, "-m", "pytest", request.node.nodeid, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+    test_id = os.path.relpath(str(request.node.fspath), ROOT) + "::" + request.node.nodeid.split("::", 1)[1]
+    done = subprocess.run([sys.executable, "-m", "pytest", test_id, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
                           cwd=ROOT, env=child_env, capture_output=True, text=True, timeout=timeout)
     assert done.returncode == 0 and " passed" in done.stdout, done.stdout[-4000:] + done.stderr[-2000:]
     return False

@@ -62,14 +62,17 @@ def test_bench_legs_cover_every_baseline_config():
     configs beside the headline C2, each at its full size -- and the two shapes round 4 added kernels for (C3's lines at k = 100,
     NW on word-sized strings)."""
     bench = load(os.path.join(ROOT, "bench.py"), "bench_module_legs")
-    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words"]
+    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words",
+                                  "sw_linear", "sw_affine", "cross_lev", "cross_nw"]
+    # Smith-Waterman on C4's sequences (bench.rs:882-963) and the reference's own call shape, compute_into(queries, candidates, &mut matrix) (bench.rs:478-486)
+    assert bench.LEGS["sw_linear"]["local"] and bench.LEGS["sw_affine"]["gaps"] == (-11, -1) and bench.LEGS["cross_lev"]["side"] == bench.LEGS["cross_nw"]["side"] == 2048
     # the reference's literal UTF-8 calls (bench.rs:538-546): raw tapes, no bound -- and raw tapes the scope's beliefs do not cover
     assert not bench.LEGS["utf8_unbounded_raw"]["prepared"] and "bound" not in bench.LEGS["utf8_unbounded_raw"] and bench.LEGS["c3_raw_cold"]["cold"] >= 2
     assert all(bench.LEGS[name]["check"] >= 100 for name in ("c4_linear", "c4_affine", "c4_bytes", "c4_letters52"))
     assert bench.LEGS["c4_letters52"]["letters"] == 52
     sizes = {name: (leg["workload"], leg["pairs"]) for name, leg in bench.LEGS.items()}
     assert sizes["c1"] == ("words16", 10_000) and sizes["c2"] == ("tokens64", 1_000_000) and sizes["c3"] == ("utf8_lines", 100_000)
-    assert sizes["c4_linear"] == sizes["c4_affine"] == ("protein4k", 10_000) and sizes["c4_bytes"] == ("bytes4k", 2_000)
+    assert sizes["c4_linear"] == sizes["c4_affine"] == ("protein4k", 10_000) and sizes["c4_bytes"] == sizes["c4_letters52"] == ("bytes4k", 10_000)   # configs[3] as worded: 10 K sequences
     assert sizes["c5"] == ("short_words", 20_000_000) and bench.LEGS["c3"]["bound"] == 32 and not bench.LEGS["c3_raw"]["prepared"]
     assert sizes["c3_k100"] == ("utf8_lines", 100_000) and bench.LEGS["c3_k100"]["bound"] == 100 and sizes["nw_words"] == ("words16", 4_000_000)
     assert bench.kernel_family("align_short_affine_w16") == "align_short" and bench.kernel_family("align_wide_local_w128") == "align_wide"
@@ -238,3 +241,33 @@ def test_trace_tools_read_rocprofv3_csvs(tmp_path):
     out = line.stdout.strip().splitlines()
     assert len(out) == 4, out
     assert "A hipLaunchKernel" in out[0] and "K swh::k_utf8_tile_decode" in out[1] and "K swh::k_banded" in out[2] and "A hipStreamSynchronize" in out[3]
+
+
+def test_headline_line_fits_its_budget():
+    """The driver parses the LAST stdout line: it is the headline only, held to 6 KB at N = 1 and 8 KB at N = 8 whatever the
+    per-config entries hold (round 5's 24 KB line could not be parsed). `fit_line` sheds the least important fields first and
+    never the contract's keys; the full entries go to --details-out."""
+    bench = load(os.path.join(ROOT, "bench.py"), "bench_module_line")
+    roof = {"bound": "valu", "kernel": "bitparallel_tiled", "kernel_ms": 0.1345, "unit": "Tint32op/s", "peak": 78.6, "achieved": 33.9, "frac": 0.4321,
+            "traffic": 600744140, "traffic_detail": {"vs_algorithmic": 4.29}, "pmc_source": "x" * 400, "measured": "y" * 400,
+            "hbm": {"achieved": 1041.2, "peak": 8000.0, "unit": "GB/s", "frac": 0.13, "algorithmic_bytes": 140028467}}
+    compact = bench.compact_roofline(roof)
+    assert compact["frac"] == 0.4321 and compact["traffic"] == 600744140 and compact["traffic_vs_algorithmic"] == 4.29 and "pmc_source" not in compact
+    legs = [{"config": name, "value": 1234.5, "ms_per_call": 1.5, "pairs": 10_000, "roofline": dict(roof), "parity_vs_oracle": True, "workload": "w" * 300}
+            for name in bench.DEFAULT_LEGS] + [{"config": "broken", "error": "RuntimeError: " + "z" * 900}]
+    for world in (1, 8):
+        line = {"metric": "GCUPS", "value": 31000.0, "unit": "GCUPS", "n_gpus": world, "steps": 20, "warmup": 5, "ms_per_step": 0.137, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": "C2 " + "c" * 150},
+                "roofline": compact, "cpu_baseline": {"value": 13.9, "unit": "GCUPS", "cores": 1, "kind": "port", "sample": "s" * 200},
+                "cpu_baselines": {f"cpu::row{i}": {"value": 1.0, "cores": 1} for i in range(5)},
+                "configs": {entry["config"]: bench.compact_leg(entry) for entry in legs}, "parity_vs_oracle": True, "gather_ok": None,
+                "ranks_seen": {"world_size": world, "backend": "nccl", "rccl_version": "2.26.6", "distinct_devices": world}, "details": "bench_configs.json"}
+        text = bench.fit_line(line, world)
+        assert len(text) <= bench.line_budget(world) and "\n" not in text
+        back = json.loads(text)
+        assert back["roofline"]["frac"] == 0.4321 and back["cpu_baseline"]["cores"] == 1 and back["configs"]["c5"]["parity"] is True
+        assert len(back["configs"]["broken"]["error"]) <= 160
+    # a pathological line (a config map that cannot fit) still fits: the map is replaced by a pointer to the details file
+    line["configs"] = {f"leg{i}": {"value": 1.0, "frac": 0.5, "parity": True, "note": "n" * 200} for i in range(60)}
+    text = bench.fit_line(line, 1)
+    assert len(text) <= bench.line_budget(1) and json.loads(text)["value"] == 31000.0

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TEST_LIBRARY_ENV, run_in_child
+from conftest import TEST_LIBRARY_ENV, child_pythonpath, run_in_child
 
 pytestmark = pytest.mark.gpu
 
@@ -682,7 +682,7 @@ def test_gotoh_narrow_strips_follow_the_scores(sw, orc, scope):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = []
     for narrow in ("1", "0"):
-        done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, STRINGWARS_AMD_NWP_NARROW=narrow, PYTHONPATH=root),
+        done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, STRINGWARS_AMD_NWP_NARROW=narrow, PYTHONPATH=child_pythonpath()),
                               capture_output=True, text=True, timeout=300)
         assert done.returncode == 0, done.stderr[-2000:]
         lines.append(done.stdout.strip().splitlines()[-1].split(" ", 1))
@@ -1725,7 +1725,7 @@ def test_utf8_look_back_epoch_wraps(orc):
         "print('epochs ok')\n")
     # (tapes of more than 4 MB together take the stream-per-tape path here; the default is 48 MB)
     env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_UTF8_EPOCH="65520", STRINGWARS_AMD_UTF8_MERGED_MB="4", STRINGWARS_AMD_UTF8_STAGING="tiles",
-               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+               PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0 and "epochs ok" in done.stdout, done.stderr[-2000:]
 
@@ -1787,7 +1787,7 @@ def test_doubling_schedule_for_bounds_beyond_one_band_word(orc):
         "for _ in range(3): assert (other.pairs(fa, fb, fresh) == want).all()\n"
         "sys.stderr.write('UNRELATED-END\\n'); sys.stderr.flush()\n"
         "print('doubling ok')\n")
-    env = dict(os.environ, STRINGWARS_AMD_STAMPS="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, STRINGWARS_AMD_STAMPS="1", PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
     assert done.returncode == 0 and "doubling ok" in done.stdout, done.stderr[-3000:]
     stages = done.stderr.split("STAGES-BEGIN")[1].split("STAGES-END")[0]
@@ -1844,7 +1844,7 @@ def test_utf8_lines_are_staged_string_by_string(orc):
         "for bound in (None, 32):\n"
         "    assert (engine.pairs(ea, eb, scope, bound=bound) == oracle.levenshtein_pairs(ea, eb, utf8=True, bound=bound)).all()\n"
         "print('strings ok')\n")
-    env = dict(os.environ, STRINGWARS_AMD_STAMPS="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, STRINGWARS_AMD_STAMPS="1", PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert done.returncode == 0 and "strings ok" in done.stdout, done.stderr[-3000:]
     assert "utf8_strings" in done.stderr and done.stderr.count("utf8_strings") >= 20, done.stderr[-2000:]
@@ -1862,7 +1862,7 @@ def test_utf8_string_by_string_staging_validates(orc):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, STRINGWARS_AMD_UTF8_STAGING="strings", PYTHONPATH=root)
+    env = dict(os.environ, STRINGWARS_AMD_UTF8_STAGING="strings", PYTHONPATH=child_pythonpath())
     picks = ("test_utf8_validation_matches_the_oracle or test_utf8_validation_fuzz or test_utf8_random_scripts or test_small_tapes_and_strings_at_tape_edges "
              "or test_believed_tape_sizes_are_checked_on_the_device or test_kat_levenshtein or test_golden_multilingual_words or test_config3_bounded_utf8 "
              "or test_general_cost_levenshtein_over_code_points or test_patterns_longer_than_64_blocks or test_banded_window_kernel")
@@ -1904,7 +1904,7 @@ def test_utf8_three_kernel_scan_path(orc, mode):
         "want = oracle.levenshtein_pairs(a, b, utf8=True, bound=40)\n"
         "assert (got == want).all()\n"
         "print('split-scan ok')\n")
-    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_UTF8_SCAN=mode, STRINGWARS_AMD_UTF8_STAGING="tiles", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_UTF8_SCAN=mode, STRINGWARS_AMD_UTF8_STAGING="tiles", PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0 and "split-scan ok" in done.stdout, done.stderr[-2000:]
 
@@ -1934,7 +1934,7 @@ def test_tiled_kernel_workgroup_shapes(orc, waves):
         "assert name == 'bitparallel_tiled', name\n"
         "assert (got == oracle.levenshtein_pairs(sa, sb, algo='hyyro')).all()\n"
         "print('tiled shapes ok')\n")
-    env = dict(os.environ, STRINGWARS_AMD_TILED_WAVES=waves, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, STRINGWARS_AMD_TILED_WAVES=waves, PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0 and "tiled shapes ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
 
@@ -2150,7 +2150,7 @@ def test_fused_planner_gives_up_instead_of_hanging():
         "assert (got[:20000] == want).all() and (got == again).all()\n"
         "assert second < 1.0, second\n"
         "print('gave-up ok', round(first, 2), round(second, 3))\n")
-    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_FUSED_OVERSUBSCRIBE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_FUSED_OVERSUBSCRIBE="1", PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert done.returncode == 0 and "gave-up ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
 
@@ -2196,37 +2196,59 @@ def test_comparison_knobs_keep_parity(shapes):
         "print('knobs ok')\n")
     env = dict(os.environ, **shapes, STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct", STRINGWARS_AMD_NW="classic",
                STRINGWARS_AMD_LONG_TICKET="0", STRINGWARS_AMD_BAND_ITEMS="fixed", STRINGWARS_AMD_BAND_CAP="64",
-               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+               PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert done.returncode == 0 and "knobs ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
 
 
-def test_bench_line_carries_every_config():
-    """`bench.py` as the driver runs it at N = 1 (scaled down): `value` is the synchronous-call rate, the steady and the pipelined
-    rates sit beside it, and `configs` holds C1, C3 (prepared and raw), C4 (linear, affine, full byte alphabet) and C5, each with its
-    rate, kernel time, roofline object and a parity check against the oracle; the CPU rows are there."""
+BENCH_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes",
+              "c4_letters52", "c5", "nw_words", "sw_linear", "sw_affine", "cross_lev", "cross_nw"]
+
+
+def bench_stdout(done):
+    """The JSON lines of a bench run's stdout: (every `{"leg": ...}` summary line, the LAST line = the headline)."""
+    rows = [json.loads(l) for l in done.stdout.splitlines() if l.startswith("{")]
+    return [r for r in rows[:-1] if "leg" in r], rows[-1], len(done.stdout.splitlines()[-1])
+
+
+def test_bench_line_is_short_and_the_details_carry_every_config(tmp_path):
+    """`bench.py` as the driver runs it at N = 1 (scaled down). The LAST stdout line is the headline only -- the contract's keys, the
+    full roofline numbers, `cpu_baseline`, one {value, frac, parity} summary per config -- and fits 6 KB (the driver could not parse
+    round 5's 24 KB line); one short `{"leg": ...}` line per config precedes it; the full entries (C1, C3 prepared and raw, C4 linear /
+    affine / full byte alphabet, C5, Smith-Waterman, the cross-product call: rate, kernel time, roofline object, parity sample) and the
+    CPU rows are in --details-out."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    details_path = str(tmp_path / "bench_configs.json")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--pairs", "50000", "--steps", "5", "--warmup", "1", "--prewarm-seconds", "0.05",
-           "--steady-seconds", "0.05", "--cpu-seconds", "0.2", "--leg-pairs", "600"]
+           "--steady-seconds", "0.05", "--cpu-seconds", "0.2", "--leg-pairs", "600", "--details-out", details_path]
     done = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-3000:])
-    line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    legs, line, line_bytes = bench_stdout(done)
+    assert line_bytes <= 6144 and len(done.stdout) <= 16384, (line_bytes, len(done.stdout))
     assert line["unit"] == "GCUPS" and line["n_gpus"] == 1 and line["steps"] == 5 and line["higher_is_better"] is True and line["scaling"] == "weak"
     assert line["value"] > 0 and line["value_steady"] > 0 and line["value_pipelined"] > 0 and line["parity_vs_oracle"] is True
     assert abs(line["value"] - line["config"]["cells_per_gpu"] * 5 / (line["ms_per_step"] * 5e-3) / 1e9) < 0.02 * line["value"]
-    assert line["roofline"]["bound"] == "valu" and line["roofline"]["kernel_ms"] > 0 and line["roofline"]["kernel"] == "bitparallel_tiled"
-    assert [e["config"] for e in line["configs"]] == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes",
-                                                        "c4_letters52", "c5", "nw_words"]
-    for entry in line["configs"]:
+    roof = line["roofline"]
+    assert roof["bound"] == "valu" and roof["kernel_ms"] > 0 and roof["kernel"] == "bitparallel_tiled" and roof["peak"] > 70 and roof["unit"] == "Tint32op/s"
+    assert {"achieved", "frac", "traffic"} <= set(roof)
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 0 and len(line["cpu_baselines"]) == 5
+    assert list(line["configs"]) == BENCH_LEGS and [r["leg"] for r in legs] == BENCH_LEGS
+    for name, summary in line["configs"].items():
+        assert "error" not in summary and summary["value"] > 0 and summary["parity"] is True and summary["kernel_ms"] > 0, (name, summary)
+    # the full entries
+    details = json.load(open(details_path))
+    assert [e["config"] for e in details["configs"]] == BENCH_LEGS and details["headline"]["roofline"]["measured"].startswith("hipEvents")
+    for entry in details["configs"]:
         assert "error" not in entry, entry
-        assert entry["value"] > 0 and entry["parity_vs_oracle"] is True and entry["roofline"]["kernel_ms"] > 0 and entry["pairs"] == 600, entry
+        assert entry["value"] > 0 and entry["parity_vs_oracle"] is True and entry["roofline"]["kernel_ms"] > 0, entry
+        assert entry["pairs"] == (576 if entry["config"].startswith("cross_") else 600), entry      # a 24 x 24 matrix for the cross-product calls
         assert "cells_mismatch" not in entry, entry
-    assert line["cpu_baseline"]["kind"] == "port" and len(line["cpu_baselines"]) == 5
-    c1_cpu = [row for row in line["cpu_baselines"] if row["name"] == "c1/cpu::hyyro<1cpu>"]
+    rows = details["cpu_baselines"]
+    c1_cpu = [row for row in rows if row["name"] == "c1/cpu::hyyro<1cpu>"]
     assert len(c1_cpu) == 1 and c1_cpu[0]["cores"] == 1 and c1_cpu[0]["value"] > 0           # BASELINE configs[0]: the per-pair CPU row on 10 K words
-    many = [row for row in line["cpu_baselines"] if row["cores"] > 1]
+    many = [row for row in rows if row["cores"] > 1]
     assert len(many) == 1 and many[0]["cores"] == os.cpu_count()                                 # every hardware thread of the box
 
 
@@ -2242,32 +2264,43 @@ def test_bench_two_ranks_share_the_gpu(config, pairs):
     port = 29600 + (os.getpid() % 300) + (0 if config == "c2" else 1)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--pairs", str(pairs),
-           "--steps", "3", "--warmup", "1", "--backend", "gloo", "--share-gpu"]
+           "--steps", "3", "--warmup", "1", "--backend", "gloo", "--share-gpu", "--details-out", ""]
     done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-3000:])
-    line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    _, line, line_bytes = bench_stdout(done)
+    assert line_bytes <= 8192, line_bytes
     assert line["n_gpus"] == 2 and line["gather_ok"] is True and line["parity_vs_oracle"] is True
     assert line["scaling"] == ("weak" if config == "c2" else "strong") and line["value"] > 0
 
 
-def test_bench_starts_two_ranks_by_itself():
+def test_bench_starts_two_ranks_by_itself(tmp_path):
     """`python bench.py --gpus 2` with NO torchrun prefix and no WORLD_SIZE (the shape of the driver's N = 1 command): the script
-    starts its ranks as a child process before touching the GPU and rank 0's line says `n_gpus: 2`. At N > 1 the line also carries
-    BASELINE configs[4] -- C5, strong scaling -- with its checked gather (u32 on the wire as the north star words it; the u8 variant beside it), the gather's price and
-    the ranks that took part, and the in-library sharded call (one scope over both member devices) as `single_process`."""
+    starts its ranks as a child process before touching the GPU and rank 0's line says `n_gpus: 2`. At N > 1 the headline line (<= 8 KB)
+    also summarises BASELINE configs[4] -- C5, strong scaling -- with its checked gather and the in-library sharded call (`single_process`);
+    --details-out carries the full entries: C5's shard ranges, the gather's price (u32 on the wire as the north star words it; the u8
+    variant beside it), the ranks that took part, the single-process child's own line."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    details_path = str(tmp_path / "bench_configs.json")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", "60000", "--c5-pairs", "700000", "--steps", "3", "--warmup", "1",
-           "--prewarm-seconds", "0.05", "--steady-seconds", "0.05", "--backend", "gloo", "--share-gpu"]
+           "--prewarm-seconds", "0.05", "--steady-seconds", "0.05", "--backend", "gloo", "--share-gpu", "--details-out", details_path]
     done = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-3000:])
-    line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])
+    legs, line, line_bytes = bench_stdout(done)
+    assert line_bytes <= 8192 and len(done.stdout) <= 16384, (line_bytes, len(done.stdout))
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["gather_ok"] is True and line["parity_vs_oracle"] is True and line["value"] > 0
-    assert line["ranks_seen"]["world_size"] == 2 and [r["rank"] for r in line["ranks_seen"]["ranks"]] == [0, 1]
+    assert line["ranks_seen"] == {"world_size": 2, "backend": "gloo", "rccl_version": None, "distinct_devices": line["ranks_seen"]["distinct_devices"]}
     assert line["gather"]["alone_ms"] > 0 and line["gather"]["bytes_to_root_per_step"] == 4 * 60000
-    (c5,) = line["configs"]
+    assert list(line["configs"]) == ["c5_strong"] and [r["leg"] for r in legs] == ["c5_strong"]
+    summary = line["configs"]["c5_strong"]
+    assert summary["value"] > 0 and summary["gather_ok"] is True and summary["parity"] is True and summary["n_gpus"] == 2 and summary["gather_u8_value"] > 0
+    assert line["single_process"]["mode"] == "single-process" and line["single_process"]["n_gpus"] == 2 and line["single_process"]["parity_vs_oracle"] is True
+    assert line["single_process"]["value"] > 0 and line["single_process"]["device_count"] == 2
+    details = json.load(open(details_path))
+    assert [r["rank"] for r in details["ranks_seen"]["ranks"]] == [0, 1]
+    (c5,) = details["configs"]
     assert c5["config"] == "c5_strong" and c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["pairs_total"] == 700000, c5
     assert c5["gather_ok"] is True and c5["parity_vs_oracle"] is True and c5["value"] > 0 and c5["ranks_seen"]["world_size"] == 2
     assert c5["shard_ranges"][0][0] == 0 and c5["shard_ranges"][0][1] == c5["shard_ranges"][1][0] and c5["shard_ranges"][1][1] == 700000
@@ -2276,7 +2309,7 @@ def test_bench_starts_two_ranks_by_itself():
     narrow = c5["gather_u8"]
     assert "error" not in narrow and narrow["gather_ok"] is True and narrow["same_results"] is True and narrow["value"] > 0, narrow
     assert narrow["gather"]["transport"].startswith("u8") and narrow["gather"]["bytes_to_root_per_step"] == 700000 - c5["shard_ranges"][0][1]
-    single = line["single_process"]
+    single = details["single_process"]
     assert "error" not in single, single
     assert single["mode"] == "single-process" and single["n_gpus"] == 2 and single["parity_vs_oracle"] is True and single["value"] > 0
     assert single["config"]["device_count"] == 2 and single["config"]["shard_cuts"][-1] == 2 * 60000
@@ -2292,14 +2325,14 @@ def test_bench_failures_at_two_ranks_end_with_a_line():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", "30000", "--steps", "2", "--warmup", "1", "--prewarm-seconds", "0.05",
-            "--steady-seconds", "0.05", "--backend", "gloo", "--share-gpu", "--no-configs", "--no-cpu-baseline"]
+            "--steady-seconds", "0.05", "--backend", "gloo", "--share-gpu", "--no-configs", "--no-cpu-baseline", "--details-out", ""]
     for at in ("after-init", "measure"):
         started = time.time()
         done = subprocess.run(base + ["--die-rank", "1", "--die-at", at, "--collective-timeout", "40", "--launch-timeout", "200"],
                               capture_output=True, text=True, timeout=600, cwd=root, env=env)
         assert done.returncode != 0 and time.time() - started < 400, (at, done.returncode)
         lines = [json.loads(l) for l in done.stdout.splitlines() if l.startswith("{")]
-        assert lines and "error" in lines[-1] and lines[-1]["value"] is None, (at, done.stdout[-800:], done.stderr[-800:])
+        assert len(lines) == 1 and "error" in lines[-1] and lines[-1]["value"] is None, (at, done.stdout[-800:], done.stderr[-800:])   # ONE line: rank 0's or the launcher's
     done = subprocess.run(base + ["--single-process-timeout", "0.01"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert done.returncode == 0, (done.stdout[-1000:], done.stderr[-2000:])
     line = json.loads([l for l in done.stdout.splitlines() if l.startswith("{")][-1])

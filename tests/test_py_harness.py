@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from conftest import child_pythonpath
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -65,7 +67,7 @@ def test_dataset_limit_sizes_and_truncation(tmp_path):
 
 
 def run_script(extra):
-    env = dict(os.environ, PYTHONPATH=ROOT)
+    env = dict(os.environ, PYTHONPATH=child_pythonpath())
     return subprocess.run([sys.executable, "-m", "stringwars_amd.bench_similarities", "--dataset", os.path.join(ROOT, "README.md"),
                            *extra], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
 
@@ -89,7 +91,7 @@ def test_script_measures_rows_on_gpu():
     for row in rows:
         assert re.match(r"^\S+<(k=32,)?1gpu>\s+\d+\.\d\d [kMG]?CUPS \| \d+\.\d\d [kMG]?B/s \| p50 .* p99 .*$", row), row
     env_bound = subprocess.run([sys.executable, "-m", "stringwars_amd.bench_similarities", "--dataset", os.path.join(ROOT, "README.md"),
-                                "--time-limit", "0.05", "-k", "k="], env=dict(os.environ, PYTHONPATH=ROOT, STRINGWARS_ERROR_BOUND="2"),
+                                "--time-limit", "0.05", "-k", "k="], env=dict(os.environ, PYTHONPATH=child_pythonpath(), STRINGWARS_ERROR_BOUND="2"),
                                capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert env_bound.returncode == 0 and len([l for l in env_bound.stdout.splitlines() if "<k=2,1gpu>" in l and "CUPS" in l]) == 2, env_bound.stdout + env_bound.stderr
     assert re.search(r"exceeded=[1-9]\d* of", env_bound.stderr), env_bound.stderr   # k = 2 is exceeded by README words

@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+from conftest import child_pythonpath
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -68,7 +70,7 @@ for bad in (b"\xc0\x80", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xe4\xb8", b"\x
     raise SystemExit("invalid UTF-8 accepted: %r" % bad)
 print("oracle clean")
 '''
-    env = dict(os.environ, LD_PRELOAD=sanitizer_runtime(), ORACLE_LIBRARY=library, PYTHONPATH=ROOT,
+    env = dict(os.environ, LD_PRELOAD=sanitizer_runtime(), ORACLE_LIBRARY=library, PYTHONPATH=child_pythonpath(),
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     result = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert "oracle clean" in clean(result)

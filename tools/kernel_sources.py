@@ -24,6 +24,8 @@ KERNELS = {
     "banded": ("swh::k_banded<", ("banded.hip", "common.hpp")),
     "wavefront": ("swh::k_wavefront<", ("wavefront.hip", "common.hpp")),
     "nwprofile": ("k_nwprofile<", ("nwprofile.hip", "common.hpp")),
+    "cross_short": ("swh::k_cross_short<", ("cross.hip", "bp_window.hpp", "common.hpp")),
+    "cross_short_u32": ("swh::k_cross_short_cp<", ("cross.hip", "bp_window.hpp", "common.hpp")),
     "align_short": ("swh::k_align_short<", ("alignshort.hip", "bp_window.hpp", "common.hpp")),
     "align_wide": ("swh::k_align_cross_wide<", ("alignshort.hip", "bp_window.hpp", "common.hpp")),
     "align_long": ("swh::k_align_cross_long<", ("alignshort.hip", "bp_window.hpp", "common.hpp")),

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--pairs", type=int, required=True)
     ap.add_argument("--calls", type=int, required=True, help="engine calls made by the profiled command")
     ap.add_argument("--variant", default="", help="distinguishes entries of one kernel and workload (linear / affine / k32 / raw ...)")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r5", "pmc_constants.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r6", "pmc_constants.json"))
     ap.add_argument("--source", default=None, help="what to record as the origin of the numbers")
     args = ap.parse_args()
     sums = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -54,7 +54,7 @@ struct __attribute__((aligned(4096))) ShortLds {
     };
     uint32_t hist[kShortKeys];                          // pairs per key, then exclusive starts
     uint8_t staged[kShortChunk];                        // distances of the chunk (<= 16)
-    uint32_t total, ticket;
+    uint32_t total, reserved;
     uint32_t mixed;                                     // some byte of the chunk differs from its wave's first byte in the upper three bits
     uint32_t refs[kShortWaves];                         // those first bytes' upper three bits, broadcast over a dword
 };
@@ -301,7 +301,6 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         const bool cand = candidate(cand_base, cand_len);
         const Off cand_bounds = bounds_request(cand, cand_base, cand_len);
         for (int i = threadIdx.x; i < kShortKeys; i += kShortThreads) lds.hist[i] = 0;
-        if (threadIdx.x == 0) lds.ticket = 0;
         // Do all bytes of the chunk share their upper three bits? (Checked on the 16-byte units as they arrive -- units past
         // the segments hold the tapes' next bytes: a false alarm there only costs the chunk its fast path.) The previous
         // chunk's flag was read before its last barrier; thread 0 of the first wave to get here resets it.
@@ -422,71 +421,88 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
         // the requests included -- in front of the first item; the whole round trip was exposed.
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         if (nxt.any) request(nxt, req_next);
-        // ---- E: work items of 64 sorted pairs, heaviest (last) first, dealt by an LDS ticket ----------------------------
+        // ---- E: work items of 64 sorted pairs, heaviest (last) first ---------------------------------------------------------
+        // An item's LDS round trips are taken off its dependency chain (round 6; before, a wave waited for eight of them per item
+        // -- ticket, descriptor, strings, one look-up per column -- at four waves per SIMD): items are dealt without a ticket, the
+        // NEXT item's descriptor is requested while an item's columns run and its strings while the item's result is
+        // staged and the table cleared; the match words of an item's first eight columns are requested together, before the
+        // first column is computed. DS instructions of a wave execute in order: the look-ups see the rows OR-ed in before
+        // them, the clear comes behind the last look-up.
         __builtin_amdgcn_s_setprio(0);
-        {
+        auto work_items = [&](auto one_tag) {
+            constexpr bool kOne = decltype(one_tag)::value;
             const uint32_t total = lds.total, items = (total + 63u) >> 6;
-            for (;;) {
-                uint32_t t = 0;
-                if (lane == 0) t = __hip_atomic_fetch_add(&lds.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                if (t >= items) break;
-                __builtin_amdgcn_s_setprio(1);   // an item's head is three LDS round trips in a row
+            // Items are dealt round by round, the waves taking turns in opposite directions (round r: wave w takes item r W + w when
+            // r is even, r W + W - 1 - w when odd; heaviest items first): every wave knows its next item without asking. (An LDS
+            // ticket costs a round trip at the head of every item -- hipcc waits for a one-lane atomic's result on the spot --, and
+            // ds_append, the uniform counter, hung the kernel on its second chunk: tools/c5_probe.py.)
+            const uint32_t my_wave = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+            auto ticket_of = [&](uint32_t round) -> uint32_t {
+                return round * (uint32_t)kShortWaves + ((round & 1u) ? (uint32_t)kShortWaves - 1u - my_wave : my_wave);
+            };
+            auto descriptor = [&](uint32_t t) -> uint2 {   // (lanes past the item's pairs read its first pair; their lengths are zeroed when the item starts)
                 const uint32_t item = items - 1 - t;
                 const uint32_t e = item * 64 + (uint32_t)lane;
-                const bool active = e < total;
-                uint2 d = lds.sorted[active ? e : item * 64];
-                if (!active) d = make_uint2(d.x, 0u);   // no rows, no columns
+                return lds.sorted[e < total ? e : item * 64];
+            };
+            struct Raw { uint32_t p[5], t[5]; };
+            // the strings as aligned dwords (realigned in registers when their item starts)
+            auto strings = [&](const uint2 &d) -> Raw {
+                Raw r;
                 const uint32_t pat = d.x & 0xFFFFu, txt = d.x >> 16;
-                const uint32_t m = d.y & 0xFFu, n = (d.y >> 8) & 0xFFu, q = d.y >> 16;
+                const uint32_t *pp = (const uint32_t *)((const uint8_t *)&lds + (pat & ~3u)), *tp = (const uint32_t *)((const uint8_t *)&lds + (txt & ~3u));
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { r.p[k] = pp[k]; r.t[k] = tp[k]; }
+                return r;
+            };
+            uint32_t round = 0, t = ticket_of(0);
+            uint2 d = make_uint2(0u, 0u);
+            Raw raw{};
+            if (t < items) { d = descriptor(t); raw = strings(d); }
+            while (t < items) {
+                __builtin_amdgcn_s_setprio(1);
+                const uint32_t item = items - 1 - t;
+                const bool active = item * 64 + (uint32_t)lane < total;
+                const uint32_t pat = d.x & 0xFFFFu, txt = d.x >> 16;
+                const uint32_t lens = active ? d.y : 0u;   // no rows, no columns
+                const uint32_t m = lens & 0xFFu, n = (lens >> 8) & 0xFFu, q = d.y >> 16;
                 const uint32_t last = total - item * 64 - 1 < 63u ? total - item * 64 - 1 : 63u;
                 const uint32_t n_max = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)last);   // sorted by text length first
                 const uint32_t m_max = wave_max_u32(m);
-                // the strings as aligned dwords, realigned in registers; bytes 8..15 only when some lane has that many
                 uint32_t pw[4], tw[4];
-                {
-                    const uint32_t *pp = (const uint32_t *)((const uint8_t *)&lds + (pat & ~3u)), *tp = (const uint32_t *)((const uint8_t *)&lds + (txt & ~3u));
-                    const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                    pw[0] = __builtin_amdgcn_alignbyte(p1, p0, pat); pw[1] = __builtin_amdgcn_alignbyte(p2, p1, pat);
-                    tw[0] = __builtin_amdgcn_alignbyte(t1, t0, txt); tw[1] = __builtin_amdgcn_alignbyte(t2, t1, txt);
-                    pw[2] = pw[3] = tw[2] = tw[3] = 0;
-                    if (m_max > 8) {
-                        const uint32_t p3 = pp[3], p4 = pp[4];
-                        pw[2] = __builtin_amdgcn_alignbyte(p3, p2, pat); pw[3] = __builtin_amdgcn_alignbyte(p4, p3, pat);
-                    }
-                    if (n_max > 8) {
-                        const uint32_t t3 = tp[3], t4 = tp[4];
-                        tw[2] = __builtin_amdgcn_alignbyte(t3, t2, txt); tw[3] = __builtin_amdgcn_alignbyte(t4, t3, txt);
-                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pw[k] = __builtin_amdgcn_alignbyte(raw.p[k + 1], raw.p[k], pat);
+                    tw[k] = __builtin_amdgcn_alignbyte(raw.t[k + 1], raw.t[k], txt);
                 }
                 const uint32_t rows = ((1u << m) - 1u) << half_shift;
-                if (one_table) {
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        if ((uint32_t)w * 4 + 0 >= m_max) break;
-                        nib.template insert_one<0>(pw[w], rows & (0x00010001u << (w * 4 + 0)));
-                        if ((uint32_t)w * 4 + 1 >= m_max) break;
-                        nib.template insert_one<1>(pw[w], rows & (0x00010001u << (w * 4 + 1)));
-                        if ((uint32_t)w * 4 + 2 >= m_max) break;
-                        nib.template insert_one<2>(pw[w], rows & (0x00010001u << (w * 4 + 2)));
-                        if ((uint32_t)w * 4 + 3 >= m_max) break;
-                        nib.template insert_one<3>(pw[w], rows & (0x00010001u << (w * 4 + 3)));
-                    }
-                } else {
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        // rows past a lane's pattern OR in a zero: no branch per lane, one scalar test per row
-                        if ((uint32_t)w * 4 + 0 >= m_max) break;
-                        nib.template insert<0>(pw[w], rows & (0x00010001u << (w * 4 + 0)));
-                        if ((uint32_t)w * 4 + 1 >= m_max) break;
-                        nib.template insert<1>(pw[w], rows & (0x00010001u << (w * 4 + 1)));
-                        if ((uint32_t)w * 4 + 2 >= m_max) break;
-                        nib.template insert<2>(pw[w], rows & (0x00010001u << (w * 4 + 2)));
-                        if ((uint32_t)w * 4 + 3 >= m_max) break;
-                        nib.template insert<3>(pw[w], rows & (0x00010001u << (w * 4 + 3)));
-                    }
-                }
+                // rows past a lane's pattern OR in a zero: no branch per lane, one scalar test per row
+#define SWH_SHORT_ROW(W, U) { if ((uint32_t)(W) * 4 + (U) >= m_max) break; \
+                              if constexpr (kOne) nib.template insert_one<U>(pw[W], rows & (0x00010001u << ((W) * 4 + (U)))); \
+                              else nib.template insert<U>(pw[W], rows & (0x00010001u << ((W) * 4 + (U)))); }
+                do {
+                    SWH_SHORT_ROW(0, 0) SWH_SHORT_ROW(0, 1) SWH_SHORT_ROW(0, 2) SWH_SHORT_ROW(0, 3)
+                    SWH_SHORT_ROW(1, 0) SWH_SHORT_ROW(1, 1) SWH_SHORT_ROW(1, 2) SWH_SHORT_ROW(1, 3)
+                    SWH_SHORT_ROW(2, 0) SWH_SHORT_ROW(2, 1) SWH_SHORT_ROW(2, 2) SWH_SHORT_ROW(2, 3)
+                    SWH_SHORT_ROW(3, 0) SWH_SHORT_ROW(3, 1) SWH_SHORT_ROW(3, 2) SWH_SHORT_ROW(3, 3)
+                } while (false);
+#undef SWH_SHORT_ROW
                 short_lds_order();
+                // the match words of columns 0..3 (4..7 when some text is that long), requested together: columns past a lane's text
+                // look up whatever bytes follow it -- any entry of the table will do, nobody uses the word. (Nibble tables: the two
+                // halves are ANDed when their column runs, not here, where it would wait for them.)
+                uint32_t eq[8], eh[8];
+#define SWH_SHORT_LOOKUP(C, W, U) { if constexpr (kOne) { eq[C] = nib.template lookup_one<U>(tw[W]); eh[C] = 0xFFFFFFFFu; } \
+                                    else { eq[C] = *(const lds_u32 *)(uintptr_t)nib.template lo_addr<U>(tw[W]); eh[C] = *(const lds_u32 *)(uintptr_t)(nib.template hi_addr<U>(tw[W]) + 2048); } }
+                SWH_SHORT_LOOKUP(0, 0, 0) SWH_SHORT_LOOKUP(1, 0, 1) SWH_SHORT_LOOKUP(2, 0, 2) SWH_SHORT_LOOKUP(3, 0, 3)
+                eq[4] = eq[5] = eq[6] = eq[7] = 0; eh[4] = eh[5] = eh[6] = eh[7] = 0;
+                if (n_max > 4) { SWH_SHORT_LOOKUP(4, 1, 0) SWH_SHORT_LOOKUP(5, 1, 1) SWH_SHORT_LOOKUP(6, 1, 2) SWH_SHORT_LOOKUP(7, 1, 3) }
+#undef SWH_SHORT_LOOKUP
+                // the next item's descriptor travels while the columns run
+                const uint32_t t_next = ticket_of(++round);
+                const bool more = t_next < items;
+                uint2 d_next = make_uint2(0u, 0u);
+                if (more) d_next = descriptor(t_next);
                 // the recurrence runs in the low 16 bits of every lane (the looked-up word is shifted down); what a lane
                 // < 32 sees above bit 15 are its partner's rows, and nothing ever moves down across bit 16
                 __builtin_amdgcn_s_setprio(0);
@@ -496,39 +512,48 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
                 // compare, an exec-mask save / restore and a branch per column: a third of a column's issue slots; lanes past the
                 // item's pairs compute something nobody reads); only the columns between the two lengths are predicated.
                 const uint32_t n_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
-                auto columns = [&](auto one_tag) {
-                    constexpr bool kOne = decltype(one_tag)::value;
-                    auto one_column = [&](auto w_tag, auto u_tag) {
-                        constexpr int w = decltype(w_tag)::value, u = decltype(u_tag)::value;
-                        const uint32_t x = tw[w];
-                        uint32_t both;
-                        if constexpr (kOne) both = nib.template lookup_one<u>(x);
-                        else both = nib.template lookup<u>(x);
-                        const uint32_t eq = both >> half_shift;
-                        const uint32_t xv = eq | mv;
-                        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
-                        uint32_t ph = mv | ~(xh | pv);
-                        const uint32_t mh = pv & xh;
-                        ph = (ph << 1) | 1u;
-                        pv = (mh + mh) | ~(xv | ph);   // (x + x: v_add_u32 issues in 2.5 cycles, a left shift in 4.4)
-                        mv = ph & xv;
-                    };
-                    auto step = [&](auto w_tag, auto u_tag) -> bool {   // false: past the longest text of the item
-                        constexpr uint32_t col = (uint32_t)(decltype(w_tag)::value * 4 + decltype(u_tag)::value);
-                        if (col >= n_max) return false;
-                        if (col < n_min) one_column(w_tag, u_tag);
-                        else if (col < n) one_column(w_tag, u_tag);
-                        return true;
-                    };
-#define SWH_SHORT_COLUMN(W, U) if (!step(std::integral_constant<int, W>{}, std::integral_constant<int, U>{})) return;
-                    SWH_SHORT_COLUMN(0, 0) SWH_SHORT_COLUMN(0, 1) SWH_SHORT_COLUMN(0, 2) SWH_SHORT_COLUMN(0, 3)
-                    SWH_SHORT_COLUMN(1, 0) SWH_SHORT_COLUMN(1, 1) SWH_SHORT_COLUMN(1, 2) SWH_SHORT_COLUMN(1, 3)
-                    SWH_SHORT_COLUMN(2, 0) SWH_SHORT_COLUMN(2, 1) SWH_SHORT_COLUMN(2, 2) SWH_SHORT_COLUMN(2, 3)
-                    SWH_SHORT_COLUMN(3, 0) SWH_SHORT_COLUMN(3, 1) SWH_SHORT_COLUMN(3, 2) SWH_SHORT_COLUMN(3, 3)
+                auto one_column = [&](uint32_t both) {
+                    const uint32_t eqw = both >> half_shift;
+                    const uint32_t xv = eqw | mv;
+                    const uint32_t xh = (((eqw & pv) + pv) ^ pv) | eqw;
+                    uint32_t ph = mv | ~(xh | pv);
+                    const uint32_t mh = pv & xh;
+                    ph = (ph << 1) | 1u;
+                    pv = (mh + mh) | ~(xv | ph);   // (x + x: v_add_u32 issues in 2.5 cycles, a left shift in 4.4)
+                    mv = ph & xv;
+                };
+                auto first_eight = [&]() {
+#define SWH_SHORT_COLUMN(C) { if ((uint32_t)(C) >= n_max) return; \
+                              const uint32_t both = kOne ? eq[C] : (eq[C] & eh[C]); \
+                              if ((uint32_t)(C) < n_min) one_column(both); else if ((uint32_t)(C) < n) one_column(both); }
+                    SWH_SHORT_COLUMN(0) SWH_SHORT_COLUMN(1) SWH_SHORT_COLUMN(2) SWH_SHORT_COLUMN(3)
+                    SWH_SHORT_COLUMN(4) SWH_SHORT_COLUMN(5) SWH_SHORT_COLUMN(6) SWH_SHORT_COLUMN(7)
 #undef SWH_SHORT_COLUMN
                 };
-                if (one_table) columns(std::true_type{});
-                else columns(std::false_type{});
+                first_eight();
+                if (n_max > 8) {   // (3 % of the synthetic words' residues): a look-up per column
+                    auto late = [&]() {
+                        auto step = [&](auto w_tag, auto u_tag) -> bool {   // false: past the longest text of the item
+                            constexpr int w = decltype(w_tag)::value, u = decltype(u_tag)::value;
+                            constexpr uint32_t col = (uint32_t)(w * 4 + u);
+                            if (col >= n_max) return false;
+                            uint32_t both;
+                            if constexpr (kOne) both = nib.template lookup_one<u>(tw[w]);
+                            else both = nib.template lookup<u>(tw[w]);
+                            if (col < n_min) one_column(both);
+                            else if (col < n) one_column(both);
+                            return true;
+                        };
+#define SWH_SHORT_COLUMN(W, U) if (!step(std::integral_constant<int, W>{}, std::integral_constant<int, U>{})) return;
+                        SWH_SHORT_COLUMN(2, 0) SWH_SHORT_COLUMN(2, 1) SWH_SHORT_COLUMN(2, 2) SWH_SHORT_COLUMN(2, 3)
+                        SWH_SHORT_COLUMN(3, 0) SWH_SHORT_COLUMN(3, 1) SWH_SHORT_COLUMN(3, 2) SWH_SHORT_COLUMN(3, 3)
+#undef SWH_SHORT_COLUMN
+                    };
+                    late();
+                }
+                // the next item's strings travel while this one's result is staged and the table cleared
+                Raw raw_next{};
+                if (more) raw_next = strings(d_next);
                 if (active) {
                     const uint32_t mask = (1u << m) - 1u;
                     const uint32_t dist = n + __popc(pv & mask) - __popc(mv & mask);
@@ -541,11 +566,14 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
                     for (int k = 0; k < 4; ++k) tb[k * 64 + lane] = make_uint4(0, 0, 0, 0);
                 }
                 short_lds_order();
+                t = t_next; d = d_next; raw = raw_next;
 #ifdef SWH_SHORT_PROFILE
                 ++items_done;
 #endif
             }
-        }
+        };
+        if (one_table) work_items(std::true_type{});
+        else work_items(std::false_type{});
         __builtin_amdgcn_s_setprio(3);   // the steps around E are chains of round trips and barriers: they go first, E fills the gaps
         SHORT_STAMP(4);   // E
         __syncthreads();

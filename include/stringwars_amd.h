@@ -88,6 +88,16 @@ swh_status_t swh_scope_synchronize(swh_scope_t scope, const char **error);
 swh_status_t swh_scope_set_pipelined(swh_scope_t scope, int enabled, const char **error);
 swh_status_t swh_scope_join(swh_scope_t scope, const char **error);
 
+/* What a scope REMEMBERS between calls. A scope learns from its calls -- the longest strings of the previous batch (raw tapes
+ * then run without a planning pre-pass), the byte totals and ASCII-ness of the raw UTF-8 tapes it last staged, whether the
+ * two-stage (band first) schedule paid off, which engine / tapes the small-alphabet alignment kernels could not take -- and
+ * every belief is CHECKED on the device: a wrong one costs the call a redo, never a result. The reference's engines keep no
+ * such state (`compute_into` is a pure function of its arguments, bench.rs:478-486); a caller who wants that -- or a timing
+ * that does not depend on what ran before -- calls `swh_scope_forget` first. `swh_scope_describe` writes the beliefs as one
+ * line of text (`key=value` pairs; truncated to `capacity`, always NUL-terminated) for logs and tests. */
+swh_status_t swh_scope_forget(swh_scope_t scope);
+swh_status_t swh_scope_describe(swh_scope_t scope, char *text, size_t capacity);
+
 /* Kernel timing (hipEvents on the scope's stream around every kernel of the last engine call).
  * Used by bench.py's roofline object; off by default. */
 typedef struct swh_timing_t {

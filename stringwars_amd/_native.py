@@ -114,6 +114,8 @@ SIGNATURES = {
     "swh_scope_synchronize": (C.c_int, [_P, _ERR]),
     "swh_scope_set_pipelined": (C.c_int, [_P, C.c_int, _ERR]),
     "swh_scope_join": (C.c_int, [_P, _ERR]),
+    "swh_scope_forget": (C.c_int, [_P]),
+    "swh_scope_describe": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "swh_scope_set_profiling": (C.c_int, [_P, C.c_int]),
     "swh_scope_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
     "swh_scope_timing_totals": (C.c_int, [_P, C.POINTER(TimingTotals)]),

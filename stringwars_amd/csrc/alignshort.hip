@@ -500,7 +500,9 @@ struct AlignWideLds {
 };
 
 template <int W, bool kLocal>
-__global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShortArgs args) {
+// (two waves per SIMD, i.e. at most 256 registers, stated: with `misfit |= 1` in place of `= 1` below -- round 6 -- hipcc gave the
+// W = 128 instantiation 257 registers, one wave per SIMD, and the ACGT-100 cross-product went from 4.0 to 6.4 ms: tools/cross_nw_probe.py)
+__global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_wide(AlignShortArgs args) {
     __shared__ __attribute__((aligned(16))) char ltable[kClassLdsBytes];
     __shared__ __attribute__((aligned(16))) AlignWideLds wave_lds[kAlignWaves];
     __shared__ SummaryLds summary_lds;
@@ -525,6 +527,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
     const size_t elem = job.out_elem64 ? 8 : 4;
     unsigned long long cells = 0, syms = 0;
     uint32_t maxa = 0, maxb = 0, shorts = 0, misfit = 0;
+    uint32_t rich = 0;   // the alphabet bit, sticky and joined to `misfit` behind the items (the `misfit = 1` assignments below would drop it)
     const uint64_t chunks = (nb + 63) / 64, qblocks = (na + kAlignQueries - 1) / kAlignQueries;
     const uint64_t items = chunks * qblocks;
     for (uint64_t item = wave_id; item < items; item += waves_total) {
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
         uint32_t lb = 0;
         if (have) align_extent(job.b.offsets, args.off64, cand, b0, lb);
         const bool fits = have && lb <= (uint32_t)W;
-        if (have && !fits) misfit |= 1;
+        if (have && !fits) misfit = 1;
         const uint32_t n = fits ? lb : 0u;
         const uint32_t n_max = wave_max_u32(n);
         // -- my candidate: bytes -> classes (packed four to a dword), and the set of classes it uses
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) used |= (uint32_t)__shfl_xor((int)used, off);
         const bool compact = __popc(used) <= 8;
-        if (!compact) misfit |= 2;   // (bit 1: the alphabet is too rich for the compacting kernels -- CallSummary::violation)
+        if (!compact) rich = 2;   // (bit 1: the alphabet is too rich for the compacting kernels -- CallSummary::violation)
         // -- the item's queries into LDS as class bytes: lane l stages bytes 16 (l % 8) .. + 15 of query l / 8, two rounds of eight queries
         wave_lds_fence();                                  // the previous item's readers are done with the staging area
 #pragma unroll
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
             const uint32_t qlen = wl.qlen[q];
             sum_m += qlen;
             item_maxa = qlen > item_maxa ? qlen : item_maxa;
-            if (qlen > (uint32_t)W) { misfit |= 1; continue; }
+            if (qlen > (uint32_t)W) { misfit = 1; continue; }
             if (!compact) continue;
             int score = align_rows_uniform<W, 1, false, kLocal>(wl.qcls[q], qlen, sel, n, n_max, (const char *)&wl.ctab[0][0], 8u, open, ext);
             if (fits) {
@@ -636,6 +639,7 @@ __global__ __launch_bounds__(kAlignWaves * 64) void k_align_cross_wide(AlignShor
             if (chunk == 0) syms += sum_m;
         }
     }
+    misfit |= rich;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         cells += __shfl_xor(cells, off);

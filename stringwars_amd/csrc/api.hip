@@ -618,12 +618,15 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             // up to 128 symbols for cross-products with linear gaps, as long as the candidates of a work item use at most eight symbol
             // classes (DNA; the kernel checks per item, a scope that met richer text stops trying -- `align_wide_off`)
             static const bool wide_on = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_WIDE"); return !e || atoi(e) != 0; }();   // comparison knob: 0 = the multi-pass kernel instead
-            const bool wide = wide_on && spec.cross && both <= 128 && engine->scoring.open == engine->scoring.extend && !scope->align_wide_off && can_verify;
+            // (what the latch is keyed by: prepared handles, else the tapes' data pointers -- sub-views of one tape share them)
+            const void *key_a = spec.pa ? (const void *)spec.pa : (const void *)spec.a.data, *key_b = spec.pb ? (const void *)spec.pb : (const void *)spec.b.data;
+            const bool wide_off = scope->align_wide_off.engine == engine->uid && scope->align_wide_off.a == key_a && scope->align_wide_off.b == key_b;
+            const bool wide = wide_on && spec.cross && both <= 128 && engine->scoring.open == engine->scoring.extend && !wide_off && can_verify;
             if (known && (guaranteed || can_verify) && (both <= 32 || wide)) {
                 route = kRouteAlignShort;
                 longest = both;
                 align_wide = both > 32;
-            } else if (known && can_verify && spec.cross && !scope->align_wide_off &&
+            } else if (known && can_verify && spec.cross && !wide_off &&
                        both <= std::min(align_long_limit(), align_long_pays(engine->kind == 2, engine->scoring.open != engine->scoring.extend)) &&
                        align_long_fits(scope, ((uint64_t)(spec.b.count + 63) / 64) * ((uint64_t)(spec.a.count + align_long_queries(scope, spec.a.count, spec.b.count) - 1) /
                                                                                       align_long_queries(scope, spec.a.count, spec.b.count)),
@@ -901,7 +904,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                     // than the believed lengths just drops the belief, and the next batch of the same shape is routed afresh
                     const bool compact_route = (route == kRouteAlignShort && align_wide) || route == kRouteAlignLong;
                     const bool compact_failed = compact_route && (scope->summary_host[0].violation & 2u) != 0;
-                    if (compact_failed) scope->align_wide_off = true;
+                    if (compact_failed) {
+                        scope->align_wide_off.engine = engine->uid;
+                        scope->align_wide_off.a = spec.pa ? (const void *)spec.pa : (const void *)spec.a.data;
+                        scope->align_wide_off.b = spec.pb ? (const void *)spec.pb : (const void *)spec.b.data;
+                    }
                     scope->summary_pending = false;
                     scope->stamps_pending = false;
                     CallSpec again = spec;
@@ -1052,6 +1059,11 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
                 KernelArgs kp = k;
                 kp.boundary = (int32_t *)scope->boundary + 2 * groups * stride * 2;
                 kp.boundary_stride = stride;
+                if (kp.local && engine->scoring.step_span) {
+                    // Scoring::step_span = largest |cost| - open - extend (alignment_init): a local score is at most the largest cost x the shorter string
+                    const uint64_t largest_cost = (uint64_t)((int64_t)engine->scoring.step_span + engine->scoring.open + engine->scoring.extend);
+                    kp.local_narrow = largest_cost * (uint64_t)std::min(plan.max_la, plan.max_lb) < 0xFFFFull ? 1u : 0u;
+                }
                 launch_nwprofile(scope, kp, profile_first, profile_count);
             }
             if (multi) {
@@ -1244,6 +1256,40 @@ swh_status_t swh_scope_join(swh_scope_t handle, const char **error) {
     if (!scope->pipelined || !scope->last_lane) return swh_success_k;   // calls already ran on the scope's own stream
     hipError_t err = hipStreamWaitEvent(scope->stream, scope->last_lane->lane_done, 0);
     if (err != hipSuccess) return fail_hip(error, HipFailure{err, "hipStreamWaitEvent"});
+    return swh_success_k;
+}
+swh_status_t swh_scope_forget(swh_scope_t handle) {
+    if (!handle) return swh_invalid_argument_k;
+    Scope *scope = (Scope *)handle;
+    Scope *all[3] = {scope, scope->lanes[0], scope->lanes[1]};
+    for (Scope *s : all) {
+        if (!s) continue;
+        s->hint_short = true;
+        s->hint_lengths = false;
+        s->hint_max_la = s->hint_max_lb = 0;
+        s->hint_mean_x16 = s->hint_mean_string_x16 = 0;
+        s->size_belief[0] = Scope::SizeBelief{};
+        s->size_belief[1] = Scope::SizeBelief{};
+        s->doubling_settled = -1.0f;
+        s->doubling_rest = 0;
+        s->utf8_strings_rest = 0;
+        s->align_wide_off = Scope::AlignWideOff{};
+        s->early_return_last_us = 0;
+    }
+    return swh_success_k;
+}
+swh_status_t swh_scope_describe(swh_scope_t handle, char *text, size_t capacity) {
+    if (!handle || !text || !capacity) return swh_invalid_argument_k;
+    const Scope *s = (const Scope *)handle;
+    snprintf(text, capacity,
+             "lengths_believed=%d longest_a=%u longest_b=%u mean_string_x16=%u short_pairs_expected=%d "
+             "utf8_tape0=%s%s utf8_tape1=%s%s doubling_settled=%.3f doubling_rest=%u utf8_strings_rest=%u "
+             "align_wide_off_engine=%llu fused_planner=%s",
+             s->hint_lengths ? 1 : 0, s->hint_max_la, s->hint_max_lb, s->hint_mean_string_x16, s->hint_short ? 1 : 0,
+             s->size_belief[0].valid ? "sized" : "unknown", s->size_belief[0].ascii ? "+ascii" : "",
+             s->size_belief[1].valid ? "sized" : "unknown", s->size_belief[1].ascii ? "+ascii" : "",
+             (double)s->doubling_settled, s->doubling_rest, s->utf8_strings_rest,
+             (unsigned long long)s->align_wide_off.engine, s->fused_disabled ? "off" : "on");
     return swh_success_k;
 }
 swh_status_t swh_scope_set_profiling(swh_scope_t handle, int enabled) {

@@ -426,8 +426,11 @@ struct Scope {
     float doubling_settled = -1.0f;   // share of the pairs the first stage of the scope's previous doubling call settled (< 0: none yet)
     uint32_t doubling_rest = 0;   // calls left before the two-stage (doubling) schedule of api.hip is tried again: its first stage settled too few pairs
     uint32_t utf8_strings_rest = 0;   // raw UTF-8 calls left before the string-by-string staging is tried again (it met a string too long for it)
-    bool align_wide_off = false;   // k_align_cross_wide / _long met candidates with more than eight symbol classes: not tried again on this scope
-                                   // (a string longer than the believed lengths only drops the belief: the next call measures afresh)
+    // k_align_cross_wide / _long met candidates with more than eight symbol classes: not tried again for THAT engine on THOSE tapes
+    // (round 6: the latch used to hold for the whole scope -- DNA after one call on text ran 1.6 x slower for ever; another engine, i.e.
+    // another folding of bytes into classes, or other tapes get their own try). A string longer than the believed lengths only drops
+    // the belief: the next call measures afresh.
+    struct AlignWideOff { uint64_t engine = 0; const void *a = nullptr, *b = nullptr; } align_wide_off;
     uint32_t hint_max_la = 0, hint_max_lb = 0;
     uint32_t hint_mean_x16 = 0;   // mean string length of the previous call, x16 (both tapes together)
     uint32_t hint_mean_string_x16 = 0;   // symbols per STRING of the previous call, x16 (a cross-product counts every string once)
@@ -528,6 +531,7 @@ struct KernelArgs {
     Scoring scoring;
     uint32_t off64, sym_bytes, symmetric, affine;
     uint32_t local;         // Smith-Waterman: local alignment (floors at 0, maximum over all cells)
+    uint32_t local_narrow;  // (local) no score of the batch can reach 2^16 (largest cost x the shorter side's longest string): k_nwprofile's plain maxima run as v_max_u16
     int32_t *boundary;      // scratch for multi-pass wavefront
     uint64_t boundary_stride;  // int32 elements per group slot
     uint32_t band_fixed_items;   // k_banded: items of exactly P pairs (comparison knob STRINGWARS_AMD_BAND_ITEMS=fixed)

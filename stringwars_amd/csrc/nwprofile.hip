@@ -91,9 +91,14 @@ __device__ __forceinline__ int umax16(int a, int b) {
 // kRead: the pass takes its left edge from the previous pass's right edge (not the first pass); kWrite: it parks its own
 // right edge for the next pass (not the last one).
 // kLocal: Smith-Waterman (`SmithWatermanScores`, bench.rs:882-963) -- every cell floored at zero, the result is the maximum over
-// all cells (`best`, carried from pass to pass by the caller). The strips then hold H + open (what the up / left terms need;
-// the class table holds sub - open), no baseline to be relative to; phantom columns score 0, i.e. a substitution of `open`
-// <= 0, so a phantom cell never exceeds the real cell it descends from and the running maximum needs no column test.
+// all cells (`best`, carried from pass to pass by the caller). Round 6: the floor comes from UNSIGNED SATURATING subtraction
+// (`v_sub_u32 ... clamp`, Farrar's trick on 32-bit lanes): the strips hold the true H >= 0 and, beside it, G = sat(H - |open|),
+// which is both the `up` term of the cell below and the `left` term of the cell to the right -- one instruction per cell where
+// max(., 0) and + open were two. A cell is then  t = Hdiag + sub ; H = max3(t, Gup, Gleft) ; G = sat(H - |open|)  -- max3 of a
+// signed t with two non-negative terms needs no floor of its own. Gotoh: E and F are floored at zero as well (they only ever
+// enter H through a maximum with 0): f = max(Gup, sat(F - |ext|)), e = max(Gleft, sat(e - |ext|)), H = max3(t, e, f).
+// The running maximum takes the diagonal candidates t only, two per v_max3 (the best cell of a local alignment ends a
+// substitution, never a gap). Phantom columns score 0: their t is the H of a real cell, nothing new.
 template <int WE, bool kAffine, bool kRead, bool kWrite, bool kLocal, bool kNarrow>
 __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uint32_t ring_at, const uint8_t *ctab, const uint8_t *cmap,
                                          const uint8_t *table_src, uint32_t cstride,
@@ -133,7 +138,9 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const uint32_t cl = ccls[4 * pl + i];
-                        const uint32_t byte = cl != 0xFFu ? (uint32_t)crow[cl & (cstride - 1u)] : 0u;   // phantom columns score 0: harmless, never read back
+                        // phantom columns score 0: harmless, never read back. Local alignment: the class table holds sub - open (what the lane
+                        // kernels of alignshort.hip want); the profile takes the bias back -- its cells work on true scores
+                        const uint32_t byte = cl != 0xFFu ? (kLocal ? (uint32_t)(uint8_t)((int)(int8_t)crow[cl & (cstride - 1u)] + open) : (uint32_t)crow[cl & (cstride - 1u)]) : 0u;
                         dw |= byte << (8 * i);
                     }
                     ((uint32_t *)(smem + c * row_bytes))[pl * 64 + lane] = dw;
@@ -162,23 +169,29 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     ring_store(64 + lane, row_offset(64 + lane));
     wave_lds_fence();
 
-    static_assert(!kNarrow || (kAffine && !kLocal), "narrow strips: global alignment with affine gaps");
+    static_assert(!kNarrow || kAffine, "narrow strips: affine gaps");
+    // kNarrow with kLocal: no shifting at all -- Smith-Waterman's H, E and F are non-negative and bounded by the best score, so when the
+    // launch knows that no score can reach 2^16 (largest cost x shorter string) the two plain maxima of a cell are v_max_u16 as they are
+    constexpr bool kShift = kNarrow && !kLocal;
     int H[WE];
     [[maybe_unused]] int F[kAffine ? WE : 1];
-    const int h0_true = kLocal ? open : (kAffine ? 2 * open_minus_ext : 0);   // row 0: global -- relative to the all-gaps baseline (wavefront.hip: kSkew / kSkewAffine); local -- 0 + open
-    [[maybe_unused]] int shift = kNarrow ? h0_true - kCenter : 0;           // (narrow strips) true value = stored value + shift
-    const int h0 = kNarrow ? kCenter : h0_true;
+    const int h0_true = kLocal ? 0 : (kAffine ? 2 * open_minus_ext : 0);   // row 0: global -- relative to the all-gaps baseline (wavefront.hip: kSkew / kSkewAffine); local -- 0
+    [[maybe_unused]] const uint32_t open_abs = (uint32_t)-open, ext_abs = (uint32_t)-ext;
+    [[maybe_unused]] int G[kLocal ? WE : 1];   // (local) sat(H - |open|) of the strip
+    [[maybe_unused]] int shift = kShift ? h0_true - kCenter : 0;           // (narrow strips) true value = stored value + shift
+    const int h0 = kShift ? kCenter : h0_true;
     // "minus infinity": narrow strips never add to one (F of row 0 may as well be H of row 0: max(H, F) is H either way; E of
     // column 0 is 0, below every stored value)
-    constexpr int kNoF = kNegInfP, kNoE = kNarrow ? 0 : kNegInfP;
+    constexpr int kNoF = kLocal ? 0 : kNegInfP, kNoE = (kShift || kLocal) ? 0 : kNegInfP;
 #pragma unroll
     for (int k = 0; k < WE; ++k) {
         H[k] = h0;
-        if constexpr (kAffine) F[k] = kNarrow ? h0 : kNoF;
+        if constexpr (kAffine) F[k] = kShift ? h0 : kNoF;
+        if constexpr (kLocal) G[k] = 0;
     }
     int out_h = h0;
-    [[maybe_unused]] int out_e = kNarrow ? h0 : kNoE;
-    int prev_h = kLocal ? open : (kAffine ? (mine ? h0 : open_minus_ext - (kNarrow ? shift : 0)) : 0);   // H[0][my first column - 1]
+    [[maybe_unused]] int out_e = kShift ? h0 : kNoE;
+    int prev_h = kLocal ? 0 : (kAffine ? (mine ? h0 : open_minus_ext - (kShift ? shift : 0)) : 0);   // H[0][my first column - 1]
     // left-edge inputs of lane 0: the DP boundary column (pass 0: a constant, never reloaded) or the previous pass's right edge
     int bnd_next[4] = {h0, h0, h0, h0}, ebnd_next[4] = {kNoE, kNoE, kNoE, kNoE};
     int bnd_cur[4], ebnd_cur[4];
@@ -199,15 +212,15 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     auto bnd_flush = [&](int first_row) {          // rows first_row .. first_row + 63 of my right edge go to global memory
         const int r = first_row + lane;
         if (r >= 1 && (uint32_t)r <= rows) {
-            bnd_h[r] = wring_h[r & (kBndWriteRows - 1)] + (kNarrow ? shift : 0);
-            if constexpr (kAffine) bnd_e[r] = wring_e[r & (kBndWriteRows - 1)] + (kNarrow ? shift : 0);
+            bnd_h[r] = wring_h[r & (kBndWriteRows - 1)] + (kShift ? shift : 0);
+            if constexpr (kAffine) bnd_e[r] = wring_e[r & (kBndWriteRows - 1)] + (kShift ? shift : 0);
         }
     };
     if (read_bnd) {
         bnd_request(1); bnd_deliver(1);
         bnd_request(65); bnd_deliver(65);
         wave_lds_fence();
-        if constexpr (kNarrow) {   // rows 1 .. 64 become stored values (rows 65 .. 128: at the end of the first block)
+        if constexpr (kShift) {   // rows 1 .. 64 become stored values (rows 65 .. 128: at the end of the first block)
             rring_h[lane] -= shift;
             rring_e[lane] -= shift;
             wave_lds_fence();
@@ -229,6 +242,8 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
     auto offset_of = [&](const uint2 &o, int u) -> uint32_t { return ((u < 2 ? o.x : o.y) >> (16 * (u & 1))) & 0xFFFFu; };
     // the scores of a step are requested TWO steps ahead (an LDS round trip under this load is longer than one step of a
     // narrow strip): four buffers, step u of a group uses buffer u, so every index is static
+    // (Measured in round 6 and not kept: one `ds_read_i8` per cell, so that the diagonal sum is a plain v_add_u32 (2.45 SIMD cycles)
+    // instead of v_add_u32_sdwa (4.4) -- four times the LDS instructions: C4 linear 11.7 -> 8.7 TCUPS, SW linear 8.2 -> 6.7.)
     uint32_t sc[4][kPlanes];
     auto read_scores = [&](int buffer, uint32_t off) {
         const uint32_t *row = (const uint32_t *)(smem + off);
@@ -265,27 +280,28 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
                 read_scores((u + 2) & 3, u < 2 ? offset_of(off_cur, u + 2) : offset_of(off_nxt, u - 2));
                 __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks the ds_reads next to their use
                 const int recv_h = dpp_wave_shr1(bnd_cur[u], out_h);
-                int recv_e = kNegInfP;
+                int recv_e = kNoE;
                 if constexpr (kAffine) recv_e = dpp_wave_shr1(ebnd_cur[u], out_e);
                 if (kAllActive || s - (uint32_t)lane < rows) {   // active: DP row r = s - lane + 1
                     int left = recv_h, e = recv_e;
+                    if constexpr (kLocal) left = (int)__builtin_elementwise_sub_sat((uint32_t)recv_h, open_abs);   // what my first cell takes from the left: G
                     int t_pending = 0;
                     // A cell is computed in two halves one column apart (wavefront.hip: in-place strips): `cell(k)` first adds the
                     // substitution score to the diagonal -- H[k - 1] of the previous row, still in its register -- and only then
                     // finishes cell k - 1, whose new value can so be written in place (tied asm operand).
                     auto finish = [&](int k, int t, int after) {
                         if constexpr (kLocal) {
-                            int x = H[k], y = left;   // up and left: the strips already hold H + open
                             if constexpr (kAffine) {
-                                const int f = max(H[k], F[k] + ext);
+                                const int fdec = (int)__builtin_elementwise_sub_sat((uint32_t)F[k], ext_abs), edec = (int)__builtin_elementwise_sub_sat((uint32_t)e, ext_abs);
+                                const int f = kNarrow ? umax16(G[k], fdec) : max(G[k], fdec);
                                 F[k] = f;
-                                e = max(left, e + ext);
-                                x = e; y = f;
+                                e = kNarrow ? umax16(left, edec) : max(left, edec);
+                                asm("v_max3_i32 %0, %1, %2, %3" : "+v"(H[k]) : "v"(t), "v"(e), "v"(f), "v"(after));
+                            } else {
+                                asm("v_max3_i32 %0, %1, %2, %3" : "+v"(H[k]) : "v"(t), "v"(G[k]), "v"(left), "v"(after));
                             }
-                            const int h3 = max(max(max(t, x), y), 0);
-                            best = max(best, h3);
-                            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open), "v"(after));
-                            left = H[k];
+                            G[k] = (int)__builtin_elementwise_sub_sat((uint32_t)H[k], open_abs);
+                            left = G[k];
                         } else if constexpr (!kAffine) {
                             asm("v_max3_i32 %0, %1, %0, %2" : "+v"(H[k]) : "v"(t), "v"(left), "v"(after));
                             left = H[k];
@@ -298,10 +314,15 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
                             left = H[k];
                         }
                     };
+                    [[maybe_unused]] int t_even = 0;
                     auto cell = [&](int k, int sc) {
                         const int t = (k == 0 ? prev_h : H[k > 0 ? k - 1 : 0]) + sc;
                         if (k > 0) finish(k - 1, t_pending, t);
                         t_pending = t;
+                        if constexpr (kLocal) {   // the running maximum: two diagonal candidates per v_max3
+                            if (k & 1) best = max(max(best, t_even), t);
+                            else t_even = t;
+                        }
                     };
                     if constexpr (kAffine && !kLocal) {
                         // Gotoh, global: four cells per asm statement, in a fixed order (SWH_NWP_CELL). What this buys is the wait
@@ -358,11 +379,11 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
                         }
                         finish(WE - 1, t_pending, t_pending);
                     }
-                    out_h = left;
+                    out_h = kLocal ? H[WE - 1] : left;   // (local: `left` is G, the neighbour takes the true H and derives its own)
                     if constexpr (kAffine) out_e = e;
                     if constexpr (write_bnd) {
                         if (lane == 63) {   // row s - 62
-                            wring_h[(s - 62) & (kBndWriteRows - 1)] = left;
+                            wring_h[(s - 62) & (kBndWriteRows - 1)] = out_h;
                             if constexpr (kAffine) wring_e[(s - 62) & (kBndWriteRows - 1)] = e;
                         }
                     }
@@ -374,7 +395,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
             if (read_bnd) bnd_deliver(s0 - 60 + 129);
             wave_lds_fence();
             if (write_bnd) bnd_flush((int)(s0 - 60) - 62);   // lane 63 did rows s0 - 60 - 62 .. s0 - 60 + 1 in this block
-            if constexpr (kNarrow) {
+            if constexpr (kShift) {
                 // the middle of the wave goes back to kCenter (after the flush: what the block parked was stored under the old shift)
                 const int delta = __builtin_amdgcn_readlane(H[WE / 2], 32) - kCenter;
                 shift += delta;
@@ -416,7 +437,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &args, char *smem, uin
 #pragma unroll
             for (int k = 0; k < WE; ++k)
                 if ((uint32_t)k == kk) result = H[k];
-            if constexpr (kNarrow) result += shift;
+            if constexpr (kShift) result += shift;
             result += (int)(rows + cols) * ext;
             if constexpr (kAffine) result -= open_minus_ext;   // the strip holds H^ + (open - ext)
             store_result(args.job, p, (int64_t)result);
@@ -564,6 +585,8 @@ void launch_nwprofile(Scope *scope, KernelArgs args, uint32_t first, uint32_t co
         else launch_strip<true, false>(scope, args, first, count, classes, blocks, strip, "nwprofile_affine_w16", "nwprofile_affine_w12", "nwprofile_affine_w8", "nwprofile_affine_w4");
     } else {
         if (!args.affine) launch_strip<false, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_w16", "nwprofile_local_w12", "nwprofile_local_w8", "nwprofile_local_w4");
+        else if (args.local_narrow)   // no score of the batch reaches 2^16: api.hip
+            launch_strip<true, true, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_affine_narrow_w16", "nwprofile_local_affine_narrow_w12", "nwprofile_local_affine_narrow_w8", "nwprofile_local_affine_narrow_w4");
         else launch_strip<true, true>(scope, args, first, count, classes, blocks, strip, "nwprofile_local_affine_w16", "nwprofile_local_affine_w12", "nwprofile_local_affine_w8", "nwprofile_local_affine_w4");
     }
     SWH_HIP_CHECK(hipGetLastError());

@@ -108,6 +108,16 @@ class DeviceScope:
         err = C.c_char_p()
         N.check(N.lib.swh_scope_join(self._handle, C.byref(err)), err)
 
+    def forget(self) -> None:
+        """Drops everything the scope believes about earlier calls (``swh_scope_forget``): the next call is routed as on a new scope."""
+        N.lib.swh_scope_forget(self._handle)
+
+    def describe(self) -> dict:
+        """The scope's beliefs (``swh_scope_describe``) as a dict of strings."""
+        text = C.create_string_buffer(512)
+        N.lib.swh_scope_describe(self._handle, text, len(text))
+        return dict(item.split("=", 1) for item in text.value.decode().split())
+
     def set_profiling(self, enabled: bool) -> None:
         N.lib.swh_scope_set_profiling(self._handle, int(bool(enabled)))
 

@@ -69,6 +69,8 @@ extern "C" {
     fn swh_scope_synchronize(scope: Handle, error: Err) -> c_int;
     fn swh_scope_set_pipelined(scope: Handle, enabled: c_int, error: Err) -> c_int;
     fn swh_scope_join(scope: Handle, error: Err) -> c_int;
+    fn swh_scope_forget(scope: Handle) -> c_int;
+    fn swh_scope_describe(scope: Handle, text: *mut c_char, capacity: usize) -> c_int;
     fn swh_scope_set_profiling(scope: Handle, enabled: c_int) -> c_int;
     fn swh_scope_last_timing(scope: Handle, timing: *mut Timing) -> c_int;
     fn swh_scope_timing_totals(scope: Handle, totals: *mut TimingTotals) -> c_int;
@@ -200,6 +202,14 @@ impl DeviceScope {
     pub fn join(&self) -> Result<(), Error> { let mut m = ptr::null(); check(unsafe { swh_scope_join(self.handle, &mut m) }, m) }
     pub fn synchronize(&self) -> Result<(), Error> { let mut m = ptr::null(); check(unsafe { swh_scope_synchronize(self.handle, &mut m) }, m) }
     pub fn set_profiling(&self, enabled: bool) { unsafe { swh_scope_set_profiling(self.handle, enabled as c_int) }; }
+    /// Drops what the scope believes about earlier calls: the next call is routed as on a new scope.
+    pub fn forget(&self) { unsafe { swh_scope_forget(self.handle) }; }
+    /// The scope's beliefs as one line of `key=value` pairs.
+    pub fn describe(&self) -> String {
+        let mut text = vec![0 as c_char; 512];
+        unsafe { swh_scope_describe(self.handle, text.as_mut_ptr(), text.len()) };
+        unsafe { std::ffi::CStr::from_ptr(text.as_ptr()) }.to_string_lossy().into_owned()
+    }
     pub fn timing_totals(&self) -> TimingTotals { let mut t = TimingTotals::default(); unsafe { swh_scope_timing_totals(self.handle, &mut t) }; t }
     pub fn shard_timing(&self) -> ShardTiming { let mut t = ShardTiming::default(); unsafe { swh_scope_shard_timing(self.handle, &mut t) }; t }
     /// Cells and dominant kernel of the last call (`swh_scope_last_timing`), for the harness' own CUPS cross-check.

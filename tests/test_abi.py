@@ -38,7 +38,7 @@ _C_TO_RUST = {
     "int *": "*mut c_int", "const int *": "*const c_int", "size_t *": "*mut usize", "ptrdiff_t *": "*mut isize",
     "uint32_t *": "*mut u32", "int32_t *": "*mut i32", "const int8_t *": "*const i8", "const uint8_t *": "*const u8",
     "void *": "*mut c_void", "const void *": "*const c_void", "void **": "*mut *mut c_void", "const char **": "*mut *const c_char",
-    "const char *": "*const c_char",
+    "const char *": "*const c_char", "char *": "*mut c_char",
     "const swh_tape_u32_t *": "*const TapeU32", "const swh_tape_u64_t *": "*const TapeU64", "const swh_prepared_view_t *": "*const PreparedView",
     "swh_prepared_info_t *": "*mut PreparedInfo", "swh_timing_t *": "*mut Timing", "swh_timing_totals_t *": "*mut TimingTotals",
     "swh_shard_timing_t *": "*mut ShardTiming",

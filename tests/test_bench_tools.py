@@ -271,3 +271,20 @@ def test_headline_line_fits_its_budget():
     line["configs"] = {f"leg{i}": {"value": 1.0, "frac": 0.5, "parity": True, "note": "n" * 200} for i in range(60)}
     text = bench.fit_line(line, 1)
     assert len(text) <= bench.line_budget(1) and json.loads(text)["value"] == 31000.0
+
+
+def test_no_kernel_lost_an_occupancy_class():
+    """Every kernel of the built objects keeps at least the waves per SIMD its registers allowed when profiles/r6/kernel_resources.json
+    was written (tools/kernel_occupancy.py --write; no GPU needed). Round 6 lost 1.6 x on a cross-product to one register -- 256 -> 257
+    VGPRs, two waves per SIMD -> one -- and only a benchmark table noticed; a deliberate change regenerates the table."""
+    tool = load(os.path.join(ROOT, "tools", "kernel_occupancy.py"), "kernel_occupancy_module")
+    assert tool.waves_per_simd(256) == 2 and tool.waves_per_simd(257) == 1 and tool.waves_per_simd(128) == 4 and tool.waves_per_simd(40) == 8
+    committed = json.load(open(tool.TABLE))["kernels"]
+    built = tool.build_table()
+    assert len(built) >= 300 and set(committed) <= set(built), sorted(set(committed) - set(built))[:5]
+    lost = {k: (committed[k]["waves_per_simd"], built[k]["waves_per_simd"], built[k]["vgpr_count"]) for k in committed
+            if built[k]["waves_per_simd"] < committed[k]["waves_per_simd"]}
+    assert not lost, lost
+    # the hot kernels, by name: the classes DESIGN.md quotes
+    by = lambda needle: [e for k, e in built.items() if needle in k]
+    assert all(e["waves_per_simd"] >= 4 for e in by("k_short_tiled<")) and all(e["waves_per_simd"] >= 2 for e in by("k_align_cross_wide<128"))

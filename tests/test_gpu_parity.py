@@ -2762,3 +2762,50 @@ def test_code_point_items_on_a_dense_alphabet(sw, orc, request):
         assert N.lib.swh_test_dense_items(counts) == 0 and counts[0] == 0 and counts[1] == 0 and counts[2] == 0 and counts[3] > 0, list(counts)
     finally:
         del os.environ["STRINGWARS_AMD_BP_DENSE"]
+
+
+def test_scope_beliefs_can_be_read_and_dropped(sw, orc):
+    """`swh_scope_describe` / `swh_scope_forget` (round 6): what a scope remembers between calls is visible and can be dropped -- the
+    reference's `compute_into` is a pure function of its arguments (bench.rs:478-486), a caller who wants that, or a timing that
+    does not depend on history, forgets first. And the small-alphabet latch holds per engine and tapes, not per scope: DNA scored
+    after text on the same scope still takes the compacting kernel."""
+    scope = sw.DeviceScope(gpu_device=0)
+    fresh = scope.describe()
+    assert fresh["lengths_believed"] == "0" and fresh["utf8_tape0"] == "unknown" and fresh["align_wide_off_engine"] == "0"
+    # raw UTF-8 tapes: the first call sizes them, the scope then believes the totals (and says so); forget() makes the next call cold again
+    ua, ub = sw.generate_pairs("utf8_lines", 300, seed=5)
+    want = orc.levenshtein_pairs(ua, ub, utf8=True, bound=32)
+    da, db = ua.to_device(scope), ub.to_device(scope)
+    engine = sw.LevenshteinDistancesUTF8(capabilities=scope)
+    assert (engine.pairs(da, db, scope, bound=32) == want).all()
+    warm = scope.describe()
+    assert warm["utf8_tape0"].startswith("sized") and warm["utf8_tape1"].startswith("sized")
+    scope.forget()
+    assert scope.describe() == fresh
+    assert (engine.pairs(da, db, scope, bound=32) == want).all() and scope.describe()["utf8_tape0"].startswith("sized")
+    # the compacting cross-product kernel: text with more than eight classes fails it (the call is redone, the result is right) ...
+    rng = np.random.default_rng(8)
+    classes, costs = sw.unary_class_costs(2, -1)
+    matrix = costs[classes][:, classes].astype(np.int8)
+    nw = sw.NeedlemanWunschScores(classes, costs, open=-2, extend=-2, capabilities=scope)
+    def tape(alphabet, count, length):
+        pool = np.frombuffer(alphabet, np.uint8)
+        return sw.Strs([pool[rng.integers(0, len(pool), length)].tobytes() for _ in range(count)])
+    text_q, text_c = tape(b"abcdefghijklmnopqrstuvwxyz", 40, 90), tape(b"abcdefghijklmnopqrstuvwxyz", 70, 100)
+    dna_q, dna_c = tape(b"ACGT", 40, 90), tape(b"ACGT", 70, 100)
+    def check(q, c, pq, pc):
+        got = nw(pq, pc, scope)
+        for i in (0, 17, 39):
+            assert [int(x) for x in got[i]] == [orc.nw_score(q[i], c[j], matrix, -2, -2) for j in range(len(c))]
+    ptq, ptc, pdq, pdc = (sw.PreparedTape(scope, t) for t in (text_q, text_c, dna_q, dna_c))
+    scope.set_profiling(True)
+    check(text_q, text_c, ptq, ptc)
+    latched = scope.describe()["align_wide_off_engine"]
+    assert latched != "0"
+    check(text_q, text_c, ptq, ptc)                      # the same engine on the same tapes: not tried again
+    assert not scope.last_timing()["dominant_name"].startswith("align_wide")
+    check(dna_q, dna_c, pdq, pdc)                        # ... other tapes get their own try
+    assert scope.last_timing()["dominant_name"].startswith("align_wide"), scope.last_timing()
+    scope.set_profiling(False)
+    scope.forget()
+    assert scope.describe()["align_wide_off_engine"] == "0"

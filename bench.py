@@ -91,18 +91,18 @@ LEGS = {
                text="C1: 10 K ASCII word pairs <= 16 B, unbounded Levenshtein (BASELINE configs[0] shape, on the GPU)"),
     "c2": dict(workload="tokens64", pairs=1_000_000, kind="lev", prepared=True, check=20_000,
                text="C2: 1 M ASCII token pairs ~64 B, unbounded Levenshtein (the headline config)"),
-    "c3": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=True, variant="k32", check=1_000,
+    "c3": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=True, variant="k32", check=5_000,
                text="C3: 100 K UTF-8 line pairs ~1 KB, bounded Levenshtein k = 32 over code points, tapes prepared (decoded once)"),
-    "c3_raw": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, variant="k32", check=1_000,
+    "c3_raw": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, variant="k32", check=5_000,
                    text="C3 on raw device tapes: UTF-8 validated and decoded inside every call"),
     # the reference's literal UTF-8 calls (similarities/bench.rs:538-546, :625-629: raw tapes handed over on every call, no bound)
-    "utf8_unbounded_raw": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", prepared=False, variant="unbounded", check=1_000,
+    "utf8_unbounded_raw": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", prepared=False, variant="unbounded", check=5_000,
                                text="C3's lines, UNBOUNDED Levenshtein over code points on raw device tapes: LevenshteinDistancesUtf8's literal call "
                                     "(bench.rs:538-546) -- validated and decoded inside every call"),
-    "c3_raw_cold": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, cold=3, variant="k32", check=1_000,
+    "c3_raw_cold": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, cold=3, variant="k32", check=5_000,
                         text="C3 on raw device tapes the scope has not seen in its previous call (three copies of the tapes in turn: the library's "
                              "beliefs about a tape's byte total and its ASCII-ness never apply)"),
-    "utf8_unrelated_raw": dict(workload="script_lines", pairs=50_000, kind="lev_utf8", prepared=False, variant="unbounded", check=500,
+    "utf8_unrelated_raw": dict(workload="script_lines", pairs=50_000, kind="lev_utf8", prepared=False, variant="unbounded", check=2_500,
                                text="UNRELATED article lines of 700-1300 code points, one script each (Latin / Cyrillic / Greek / Arabic / Devanagari), unbounded "
                                     "Levenshtein over code points on raw device tapes: what the reference's cross-product of XLSum lines pairs up for "
                                     "LevenshteinDistancesUtf8 (bench.rs:386-399, similarities/README.md:18, :39-40) -- nothing for a band to settle; the "
@@ -131,7 +131,7 @@ LEGS = {
     "c5": dict(workload="short_words", pairs=20_000_000, kind="lev", prepared=True, check=200_000,
                text="C5: one GPU's share of the 100 M short-word pairs (20 M pairs <= 16 B, mean ~6), unbounded Levenshtein"),
     # beyond BASELINE's five: what round 4 added kernels for
-    "c3_k100": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=100, prepared=True, variant="k100", check=1_000,
+    "c3_k100": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=100, prepared=True, variant="k100", check=5_000,
                     text="C3's lines at k = 100 (STRINGWARS_ERROR_BOUND is free-form, README.md:311): the banded kernel's two-word window"),
     "nw_words": dict(workload="words16", pairs=4_000_000, kind="nw", gaps=(-2, -2), unary=(2, -1), prepared=True, variant="unary_linear", check=20_000,
                      text="NW on word-sized strings (the reference's default `words` token mode, bench.rs:271): 4 M pairs <= 16 B, "

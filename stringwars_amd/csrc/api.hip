@@ -170,14 +170,14 @@ static void ensure(char *&buf, size_t &cap, size_t need) {
 
 // both tapes of a call up to this size (together) are staged by one launch pair; STRINGWARS_AMD_UTF8_MERGED_MB=n moves it
 static uint64_t utf8_merged_bytes() {
-    static const uint64_t bytes = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_MERGED_MB"); return e ? (uint64_t)atol(e) << 20 : ~0ull; }();
+    static const uint64_t bytes = [] { const char *e = test_hook("STRINGWARS_AMD_UTF8_MERGED_MB"); return e ? (uint64_t)atol(e) << 20 : ~0ull; }();
     return bytes;
 }
 // STRINGWARS_AMD_UTF8_STAGING: `strings` -- every raw UTF-8 call on the planned / tiled routes stages string by string (k_utf8_strings: the
 // tests send words and empty strings through it), `tiles` -- never (the flat one-pass kernel: the comparison), unset -- tapes whose
 // mean string has at least kUtf8StringsMeanBytes bytes.
 static int utf8_strings_mode() {
-    static const int mode = [] { const char *e = getenv("STRINGWARS_AMD_UTF8_STAGING"); return !e ? 0 : (!strcmp(e, "strings") ? 1 : (!strcmp(e, "tiles") ? 2 : 0)); }();
+    static const int mode = [] { const char *e = test_hook("STRINGWARS_AMD_UTF8_STAGING"); return !e ? 0 : (!strcmp(e, "strings") ? 1 : (!strcmp(e, "tiles") ? 2 : 0)); }();
     return mode;
 }
 // u32 words of scratch the flat UTF-8 decoder needs for a tape of `bytes` bytes (see launch_utf8_decode)
@@ -301,7 +301,7 @@ enum Route { kRoutePlanned, kRouteTiled, kRouteDirectShort, kRouteShortTiled, kR
 // Strings up to this many symbols (G <= 8 blocks) are scored by the tiled kernel when their lengths are known; beyond it
 // a tile holds too few pairs per block count and the global sort of the planned path packs the waves better.
 static uint32_t tiled_longest_limit() {
-    static const uint32_t limit = [] { const char *e = getenv("STRINGWARS_AMD_TILED_MAX"); return e ? (uint32_t)atoi(e) : 256u; }();
+    static const uint32_t limit = [] { const char *e = test_hook("STRINGWARS_AMD_TILED_MAX"); return e ? (uint32_t)atoi(e) : 256u; }();
     return limit;
 }
 // Word-sized batches: k_short_tiled (<= 16 bytes, batches large enough to give every workgroup a chunk worth sorting) /
@@ -310,21 +310,21 @@ static uint32_t tiled_longest_limit() {
 // (STRINGWARS_AMD_SHORT_MIN_PAIRS, read per call: the tests send small batches to the chunked kernel with it)
 static uint64_t short_tiled_min_pairs() {
 #ifdef SWH_TEST_HOOKS
-    const char *e = getenv("STRINGWARS_AMD_SHORT_MIN_PAIRS");   // (the test library reads it per call: the tests move it between calls)
+    const char *e = test_hook("STRINGWARS_AMD_SHORT_MIN_PAIRS");   // (the test library reads it per call: the tests move it between calls)
     return e ? (uint64_t)atoll(e) : (uint64_t)1 << 16;
 #else
-    static const uint64_t pairs = [] { const char *e = getenv("STRINGWARS_AMD_SHORT_MIN_PAIRS"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 16; }();
+    static const uint64_t pairs = [] { const char *e = test_hook("STRINGWARS_AMD_SHORT_MIN_PAIRS"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 16; }();
     return pairs;
 #endif
 }
 // Bounds up to here may take the banded kernel (STRINGWARS_AMD_BAND_MAX=63: the one-word windows only, the comparison knob).
 static uint32_t band_max_bound() {
-    static const uint32_t most = [] { const char *e = getenv("STRINGWARS_AMD_BAND_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : kBandMaxBound; return v > kBandMaxBound ? kBandMaxBound : v; }();
+    static const uint32_t most = [] { const char *e = test_hook("STRINGWARS_AMD_BAND_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : kBandMaxBound; return v > kBandMaxBound ? kBandMaxBound : v; }();
     return most;
 }
 // Longest string k_align_cross_long is chosen for: the longest query it takes (STRINGWARS_AMD_ALIGN_LONG_MAX=n lowers it) ...
 static uint32_t align_long_limit() {
-    static const uint32_t limit = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_LONG_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : 4096u; return v > 4096u ? 4096u : v; }();
+    static const uint32_t limit = [] { const char *e = test_hook("STRINGWARS_AMD_ALIGN_LONG_MAX"); const uint32_t v = e ? (uint32_t)atoi(e) : 4096u; return v > 4096u ? 4096u : v; }();
     return limit;
 }
 // ... and per form, the length up to which it measured faster than the column-profile kernel on DNA cross-products (TCUPS, long
@@ -383,7 +383,7 @@ static void wait_for_summary(Scope *scope, hipStream_t stream) {
 
 static int short_route_choice() {
     static const int choice = [] {
-        const char *e = getenv("STRINGWARS_AMD_SHORT");
+        const char *e = test_hook("STRINGWARS_AMD_SHORT");
         return !e ? 0 : (!strcmp(e, "direct") ? 1 : (!strcmp(e, "tiled") ? 2 : 0));
     }();
     return choice;
@@ -430,7 +430,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             same_tape = spec.b.data == spec.a.data && spec.b.offsets == spec.a.offsets && spec.b.count == spec.a.count;
         }
         const bool dev_out = is_device_pointer(spec.out);
-        static const bool believe = [] { const char *e = getenv("STRINGWARS_AMD_SIZE_BELIEF"); return !e || atoi(e) != 0; }();
+        static const bool believe = [] { const char *e = test_hook("STRINGWARS_AMD_SIZE_BELIEF"); return !e || atoi(e) != 0; }();
         auto same_as_believed = [](const HostTape &t, const Scope::SizeBelief &slot) {
             return slot.valid && slot.data == t.data && slot.offsets == t.offsets && slot.count == t.count && slot.off64 == t.off64;
         };
@@ -606,7 +606,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
 
         // Alignment scores on a class table when both tapes hold word-sized strings only (the reference's default `words` token mode,
         // bench.rs:271): one pair per lane, no pre-pass (alignshort.hip). STRINGWARS_AMD_ALIGN_SHORT=0 keeps them on the planned path.
-        static const bool align_short_on = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_SHORT"); return !e || atoi(e) != 0; }();
+        static const bool align_short_on = [] { const char *e = test_hook("STRINGWARS_AMD_ALIGN_SHORT"); return !e || atoi(e) != 0; }();
         bool align_wide = false;   // kRouteAlignShort on k_align_cross_wide (its alphabet condition is checked by the kernel)
         if (engine->kind != 0 && engine->scoring.class_table && !utf8 && !spec.force_planned && align_short_on) {
             bool known = false;
@@ -617,7 +617,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
             const uint32_t both = la_max > lb_max ? la_max : lb_max;
             // up to 128 symbols for cross-products with linear gaps, as long as the candidates of a work item use at most eight symbol
             // classes (DNA; the kernel checks per item, a scope that met richer text stops trying -- `align_wide_off`)
-            static const bool wide_on = [] { const char *e = getenv("STRINGWARS_AMD_ALIGN_WIDE"); return !e || atoi(e) != 0; }();   // comparison knob: 0 = the multi-pass kernel instead
+            static const bool wide_on = [] { const char *e = test_hook("STRINGWARS_AMD_ALIGN_WIDE"); return !e || atoi(e) != 0; }();   // comparison knob: 0 = the multi-pass kernel instead
             // (what the latch is keyed by: prepared handles, else the tapes' data pointers -- sub-views of one tape share them)
             const void *key_a = spec.pa ? (const void *)spec.pa : (const void *)spec.a.data, *key_b = spec.pb ? (const void *)spec.pb : (const void *)spec.b.data;
             const bool wide_off = scope->align_wide_off.engine == engine->uid && scope->align_wide_off.a == key_a && scope->align_wide_off.b == key_b;
@@ -935,8 +935,8 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         bool doubling = false;
         double doubling_need = 0;
         constexpr uint32_t kDoublingBound = 63;
-        static const bool doubling_on = [] { const char *e = getenv("STRINGWARS_AMD_DOUBLING"); return !e || atoi(e) != 0; }();
-        static const uint64_t doubling_min = [] { const char *e = getenv("STRINGWARS_AMD_DOUBLING_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)200000; }();   // tuning knob: pairs x blocks
+        static const bool doubling_on = [] { const char *e = test_hook("STRINGWARS_AMD_DOUBLING"); return !e || atoi(e) != 0; }();
+        static const uint64_t doubling_min = [] { const char *e = test_hook("STRINGWARS_AMD_DOUBLING_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)200000; }();   // tuning knob: pairs x blocks
         if (doubling_on && bitpar_ok && pre.unit_costs && engine->algorithm == swh_algorithm_auto_k && spec.bound > kDoublingBound &&
             (prepared || scope->hint_lengths)) {
             const uint32_t la_max = prepared ? (utf8 ? spec.pa->longest_symbols : spec.pa->longest_bytes) : scope->hint_max_la;
@@ -1024,7 +1024,7 @@ static swh_status_t run_call_on(Scope *scope, const Engine *engine, const CallSp
         // Global or local alignment on a class table (<= 32 symbol classes; 33 .. 128 on the wide table), pairs of more than 384 columns: the column-profile kernel
         // (nwprofile.hip) takes them -- perm is sorted by class, so they are one contiguous range -- and the wavefront
         // kernels below see a plan without them. STRINGWARS_AMD_NW=classic keeps everything on the wavefront kernels.
-        static const bool nw_classic = [] { const char *e = getenv("STRINGWARS_AMD_NW"); return e && strcmp(e, "classic") == 0; }();
+        static const bool nw_classic = [] { const char *e = test_hook("STRINGWARS_AMD_NW"); return e && strcmp(e, "classic") == 0; }();
         uint32_t profile_first = 0, profile_count = 0;
         Plan wf_plan = plan;
         if ((engine->kind == 1 || engine->kind == 2) && (engine->scoring.class_table || engine->scoring.wide_table) && sym_bytes == 1 && !nw_classic) {

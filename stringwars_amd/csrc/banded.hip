@@ -288,7 +288,7 @@ static void launch_banded_one(Scope *scope, const KernelArgs &args, uint64_t pai
     // pairs with the items sized by the kernel: capacity 20 / 24 / 32 / 40 / 64 (6 / 5 / 4 / 3 / 2 workgroups
     // per CU): 0.356 / 0.344 / 0.331 / 0.351 / 0.450 ms; at 150 K - 800 K pairs 32 beats 64 by 13-17 % as well.
     // STRINGWARS_AMD_BAND_CAP=64: the large items (comparison knob).
-    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_BAND_CAP"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char *e = test_hook("STRINGWARS_AMD_BAND_CAP"); return e ? atoi(e) : 0; }();
     // Two-word windows: items of 16 pairs keep the workgroup at 35 KB of LDS = four per CU (items of 32: 69 KB, two per CU, and
     // the serial recurrence at two waves per SIMD: C3's lines at k = 64 / 100 / 127 take 0.81 / 0.99 / 1.05 ms instead of 0.73 / 0.84 / 0.91).
     if constexpr (WBITS > 64) launch_banded_items<Sym, WBITS, 16>(scope, args, pairs);
@@ -300,7 +300,7 @@ void launch_banded(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     const uint32_t k = args.job.bound;
     KernelArgs a = args;
     a.boundary = nullptr;
-    static const bool fixed_items = [] { const char *e = getenv("STRINGWARS_AMD_BAND_ITEMS"); return e && e[0] == 'f'; }();   // "fixed": comparison knob
+    static const bool fixed_items = [] { const char *e = test_hook("STRINGWARS_AMD_BAND_ITEMS"); return e && e[0] == 'f'; }();   // "fixed": comparison knob
     a.band_fixed_items = fixed_items ? 1u : 0u;
 #define SWH_BAND(SYM)                                                     \
     if (k + 1 <= 8) launch_banded_one<SYM, 8>(scope, a, pairs);           \

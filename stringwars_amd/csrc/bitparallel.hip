@@ -460,7 +460,7 @@ void launch_bitparallel_long(Scope *scope, KernelArgs args, const Plan &plan_hos
     const uint32_t max_blocks = (uint32_t)scope->compute_units * (bytes ? 4 : 1);
     if (blocks > max_blocks) blocks = max_blocks;
     // args.boundary / boundary_stride: the carry words, sized by the caller (bp_long_carry_words, <= 4096 waves)
-    static const bool round_robin = [] { const char *e = getenv("STRINGWARS_AMD_LONG_TICKET"); return e && atoi(e) == 0; }();   // comparison knob
+    static const bool round_robin = [] { const char *e = test_hook("STRINGWARS_AMD_LONG_TICKET"); return e && atoi(e) == 0; }();   // comparison knob
     args.ticket = nullptr;
     if (!round_robin && count > blocks * (uint32_t)waves) {   // more pairs than waves: somebody gets a second one
         args.ticket = scope->plan_leftover + 6;
@@ -503,7 +503,7 @@ static void launch_bitparallel_sym(Scope *scope, const KernelArgs &args, uint64_
 }
 
 void launch_bitparallel(Scope *scope, const KernelArgs &args, uint64_t pairs) {
-    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_BP_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4 (both widths), 10 (code points)
+    static const int forced = [] { const char *e = test_hook("STRINGWARS_AMD_BP_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4 (both widths), 10 (code points)
     if (args.sym_bytes == 4) {
         if (forced == 4) launch_bitparallel_sym<uint32_t, BpTraits<uint32_t>::kWaves>(scope, args, pairs);
         else if (forced == 10) launch_bitparallel_sym<uint32_t, 10>(scope, args, pairs);

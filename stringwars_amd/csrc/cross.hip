@@ -21,6 +21,7 @@ namespace swh {
 constexpr uint32_t kCrossMax = 32;          // longest query / candidate in bytes
 constexpr int kCrossQueries = 16;           // queries per work item (2048 x 2048 words: 4096 items, one per wave slot)
 constexpr int kCrossWaves = 4;
+constexpr uint32_t kCrossCompareRows = 12;  // code points: queries up to here are matched by comparison (k_cross_short_cp), longer ones through the group tables
 
 struct CrossArgs {
     Job job;                 // cross = 1; out is the matrix
@@ -282,6 +283,61 @@ __global__ __launch_bounds__(kCrossWaves * 64) void k_cross_short_cp(CrossArgs a
         const uint32_t n_max = wave_max_u32(n_live);
         unsigned long long sum_m = 0;
         uint32_t item_maxa = 0;
+        // ---- word-sized queries (every query of the item at most kCrossCompareRows symbols: tokens of ~5 code points): NO match table.
+        // The query is the same for all 64 lanes, so its symbols are SCALARS: row i's symbol is compared with the candidates' columns
+        // (`v_cmp_eq_u32 vcc, s, v` + `v_addc_co_u32 eq, eq, eq, vcc`: eq = 2 eq + match, rows from the last to the first) -- two
+        // instructions per cell of the match matrix, no LDS: against the group tables' seven ds_or per row and, per column, seven
+        // look-ups, seven address computations and six ANDs, that is 2 m + 11 instructions per column (m = 5: 21) instead of 31 + 7 LDS.
+        uint32_t longest_query = 0;
+        for (uint32_t q = 0; q < q_count; ++q) { const uint32_t m = wl.qlen[q]; longest_query = m > longest_query ? m : longest_query; }
+        longest_query = (uint32_t)__builtin_amdgcn_readfirstlane((int)longest_query);
+        if (longest_query <= kCrossCompareRows) {
+            for (uint32_t q = 0; q < q_count; ++q) {
+                const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)wl.qlen[q]);
+                sum_m += m;
+                item_maxa = m > item_maxa ? m : item_maxa;
+                uint32_t eq[kCrossMax];
+#pragma unroll
+                for (int t = 0; t < (int)kCrossMax; ++t) eq[t] = 0;
+                for (int i = (int)m - 1; i >= 0; --i) {
+                    const uint32_t sym = (uint32_t)__builtin_amdgcn_readfirstlane((int)wl.qsyms[q][i]);
+#pragma unroll
+                    for (int t4 = 0; t4 < (int)kCrossMax; t4 += 4) {
+                        if ((uint32_t)t4 >= n_max) break;
+                        // eq = 2 eq + (column symbol == row symbol): the comparison's lane mask is the carry-in of the addition
+                        // (hipcc builds it from v_cmp + v_cndmask + v_lshl_or and a wait state)
+                        asm("v_cmp_eq_u32 vcc, %4, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                            "v_cmp_eq_u32 vcc, %4, %6\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\t"
+                            "v_cmp_eq_u32 vcc, %4, %7\n\tv_addc_co_u32 %2, vcc, %2, %2, vcc\n\t"
+                            "v_cmp_eq_u32 vcc, %4, %8\n\tv_addc_co_u32 %3, vcc, %3, %3, vcc"
+                            : "+v"(eq[t4]), "+v"(eq[t4 + 1]), "+v"(eq[t4 + 2]), "+v"(eq[t4 + 3])
+                            : "s"(sym), "v"(tw[t4]), "v"(tw[t4 + 1]), "v"(tw[t4 + 2]), "v"(tw[t4 + 3])
+                            : "vcc");
+                    }
+                }
+                uint32_t pv = 0xFFFFFFFFu, mv = 0;
+#pragma unroll
+                for (int t = 0; t < (int)kCrossMax; ++t) {
+                    if ((uint32_t)t >= n_max) break;
+                    if ((uint32_t)t < n_live) {
+                        const uint32_t e = eq[t];
+                        const uint32_t xv = e | mv;
+                        const uint32_t xh = (((e & pv) + pv) ^ pv) | e;
+                        uint32_t ph = mv | ~(xh | pv);
+                        const uint32_t mh = pv & xh;
+                        ph = (ph << 1) | 1u;
+                        pv = (mh + mh) | ~(xv | ph);
+                        mv = ph & xv;
+                    }
+                }
+                if (fits) {
+                    const uint32_t mask = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u);
+                    const uint32_t d = n + __popc(pv & mask) - __popc(mv & mask);
+                    char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;
+                    store_out(dst, job.out_elem64 != 0, (int64_t)d);
+                }
+            }
+        }
         auto build = [&](uint32_t q, uint32_t *table) -> uint32_t {
             const uint32_t m = q < q_count ? wl.qlen[q] : 0u;
             if ((uint32_t)lane < m && m <= kCrossMax) {
@@ -291,8 +347,9 @@ __global__ __launch_bounds__(kCrossWaves * 64) void k_cross_short_cp(CrossArgs a
             }
             return m;
         };
-        uint32_t m_next = build(0, wl.table[0]);
-        for (uint32_t q = 0; q < q_count; ++q) {
+        const uint32_t q_tabled = longest_query <= kCrossCompareRows ? 0u : q_count;   // (the longer queries' items: the group tables, as before)
+        uint32_t m_next = q_tabled ? build(0, wl.table[0]) : 0u;
+        for (uint32_t q = 0; q < q_tabled; ++q) {
             uint32_t *table = wl.table[q & 1];
             const uint32_t m = m_next;
             lds_program_order();
@@ -330,7 +387,7 @@ __global__ __launch_bounds__(kCrossWaves * 64) void k_cross_short_cp(CrossArgs a
             if (lane < 56) table[lane] = 0;
         }
         lds_program_order();
-        if (lane < 56) wl.table[q_count & 1][lane] = 0;
+        if (q_tabled && lane < 56) wl.table[q_count & 1][lane] = 0;
         lds_program_order();
         if (have) {
             cells += sum_m * (unsigned long long)n;

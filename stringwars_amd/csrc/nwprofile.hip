@@ -545,7 +545,7 @@ void launch_strip(Scope *scope, const KernelArgs &args, uint32_t first, uint32_t
 // Strip width by the classes in use: classes x 64 W bytes of profile per wave, eight or more waves per CU.
 uint32_t nwprofile_strip(uint32_t classes) {
     // comparison knob STRINGWARS_AMD_NWP_STRIP=8|12|16 (honoured when the profile still fits a workgroup's 64 KB)
-    static const uint32_t forced = [] { const char *e = getenv("STRINGWARS_AMD_NWP_STRIP"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const uint32_t forced = [] { const char *e = test_hook("STRINGWARS_AMD_NWP_STRIP"); return e ? (uint32_t)atoi(e) : 0u; }();
     if ((forced == 4 || forced == 8 || forced == 12 || forced == 16) && (size_t)classes * 64 * forced + kScratchBytes + 256 <= 65536 && classes * 64 * forced <= 65535) return forced;
     // beyond the 32 classes of the register model (Scoring::wide_table): the profile's rows are what LDS holds -- strips of eight columns
     // as long as five single-wave workgroups fit a CU (56 classes: 32 KB each), of four beyond (128 classes: 36 KB, four per CU).
@@ -557,7 +557,7 @@ uint32_t nwprofile_strip(uint32_t classes) {
 // Narrow strips (see kCenter): everything a wave holds at one time must fit 16 bits around its middle.
 // Comparison knob: STRINGWARS_AMD_NWP_NARROW=0 keeps the 32-bit maxima.
 static bool nwprofile_narrow(const Scoring &scoring, uint32_t strip) {
-    static const bool off = [] { const char *e = getenv("STRINGWARS_AMD_NWP_NARROW"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char *e = test_hook("STRINGWARS_AMD_NWP_NARROW"); return e && e[0] == '0'; }();
     return !off && scoring.step_span && (uint64_t)scoring.step_span * (64 * strip + 256) <= 30000;
 }
 

@@ -817,7 +817,7 @@ void launch_prepass(Scope *scope, const PrepassArgs &args_in) {
     if (blocks < 1) blocks = 1;
     int dblocks = 0;
     // the planning passes as one launch when the batch fits a grid that is resident as a whole
-    static const bool fused_off = [] { const char *e = getenv("STRINGWARS_AMD_PLAN"); return e && !strcmp(e, "split"); }();
+    static const bool fused_off = [] { const char *e = test_hook("STRINGWARS_AMD_PLAN"); return e && !strcmp(e, "split"); }();
     if (scope->fused_per_cu < 0) {   // how many 1024-thread planning workgroups one compute unit holds (asked once)
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_plan_fused<uint32_t>, kPlanThreads, 0) != hipSuccess) per_cu = 0;

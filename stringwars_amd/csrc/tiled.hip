@@ -420,7 +420,7 @@ TilePlan plan_tiles(uint64_t pairs, uint32_t slots, uint32_t longest_text, uint3
     constexpr uint32_t kTileMin = 256;
     const uint64_t rounds = (pairs + (uint64_t)slots * kTileMax - 1) / ((uint64_t)slots * kTileMax);
     uint64_t tile = (pairs + slots * rounds - 1) / (slots * rounds);
-    static const uint32_t forced = [] { const char *e = getenv("STRINGWARS_AMD_TILE"); return e ? (uint32_t)atoi(e) : 0u; }();   // tuning knob
+    static const uint32_t forced = [] { const char *e = test_hook("STRINGWARS_AMD_TILE"); return e ? (uint32_t)atoi(e) : 0u; }();   // tuning knob
     if (forced) tile = forced;
     if (tile < kTileMin) tile = kTileMin;
     if (tile > (uint64_t)kTileMax) tile = kTileMax;
@@ -443,13 +443,13 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
     t.k = args;
     t.k.boundary = nullptr;
     t.tile = tp.tile; t.tiles = tp.tiles; t.shift = tp.shift;
-    static const bool no_affix = [] { const char *e = getenv("STRINGWARS_AMD_AFFIX"); return e && atoi(e) == 0; }();   // comparison knob
+    static const bool no_affix = [] { const char *e = test_hook("STRINGWARS_AMD_AFFIX"); return e && atoi(e) == 0; }();   // comparison knob
     t.cut_affixes = sizeof(Sym) == 1 && !no_affix ? 1u : 0u;
     t.partials = scope->plan_partials;
     t.done_counter = scope->done_counter;
     t.summary = scope->summary_target();
     opt_in_dynamic_lds(scope, (const void *)k_bitparallel_tiled<Sym, kWaves>, lds);
-    static const bool debug = getenv("STRINGWARS_AMD_DEBUG") != nullptr;
+    static const bool debug = test_hook("STRINGWARS_AMD_DEBUG") != nullptr;
     if (debug) {
         int per_cu = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bitparallel_tiled<Sym, kWaves>, kWaves * 64, lds);
@@ -462,7 +462,7 @@ static void launch_tiled_sym(Scope *scope, const KernelArgs &args, uint64_t pair
 }
 
 void launch_bitparallel_tiled(Scope *scope, const KernelArgs &args, uint64_t pairs, uint32_t longest_text) {
-    static const int forced = [] { const char *e = getenv("STRINGWARS_AMD_TILED_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4; code points also 8
+    static const int forced = [] { const char *e = test_hook("STRINGWARS_AMD_TILED_WAVES"); return e ? atoi(e) : 0; }();   // comparison knob: 4; code points also 8
     if (args.sym_bytes == 4) {   // code points: 14.25 KB of tables per wave -- one workgroup of ten waves fills a CU next to the tile's lists
                                  // (latency-bound like the planned kernel: 8 -> 10 waves is 8 % on token-sized strings; STRINGWARS_AMD_TILED_WAVES=8 / =4:
                                  // eight waves; two-wave workgroups, five per CU)

@@ -486,7 +486,7 @@ static void launch_one(Scope *scope, const KernelArgs &args, uint32_t cls, uint3
 // Tuning knob (STRINGWARS_AMD_WF_CAP=<columns per lane>): strips wider than the cap run as several passes of 32
 // columns per lane instead of one pass of up to 96 -- fewer registers per wave, more waves per SIMD.
 int wavefront_strip_cap() {
-    static int cap = [] { const char *e = getenv("STRINGWARS_AMD_WF_CAP"); return e ? atoi(e) : 0; }();
+    static int cap = [] { const char *e = test_hook("STRINGWARS_AMD_WF_CAP"); return e ? atoi(e) : 0; }();
     return cap;
 }
 

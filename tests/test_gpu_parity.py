@@ -682,7 +682,7 @@ def test_gotoh_narrow_strips_follow_the_scores(sw, orc, scope):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = []
     for narrow in ("1", "0"):
-        done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, STRINGWARS_AMD_NWP_NARROW=narrow, PYTHONPATH=child_pythonpath()),
+        done = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_NWP_NARROW=narrow, PYTHONPATH=child_pythonpath()),
                               capture_output=True, text=True, timeout=300)
         assert done.returncode == 0, done.stderr[-2000:]
         lines.append(done.stdout.strip().splitlines()[-1].split(" ", 1))
@@ -1272,7 +1272,7 @@ def test_word_sized_batches_on_the_chunked_kernel(sw, orc, request):
     edges, both offset widths, strided outputs, bounds, sub-views that start in the middle of a tape, and a
     batch that stops being word-sized (the kernel reports it, the call is redone on another route)."""
     # batches below 64 K pairs take k_direct_short otherwise (the threshold is read once per process: a child process with it set)
-    if not run_in_child(request, env={"STRINGWARS_AMD_SHORT_MIN_PAIRS": "1"}):
+    if not run_in_child(request, env={"STRINGWARS_AMD_SHORT_MIN_PAIRS": "1"}, test_library=True):
         return
     scope = sw.DeviceScope(gpu_device=0)
     rng = np.random.default_rng(53)
@@ -1795,7 +1795,7 @@ def test_doubling_schedule_for_bounds_beyond_one_band_word(orc):
     unrelated = done.stderr.split("UNRELATED-BEGIN")[1].split("UNRELATED-END")[0]
     assert unrelated.count("stamp banded") == 1 and unrelated.count("stamp plan_") == 4, unrelated    # tried once, then sat out
     # the comparison knob: one stage
-    env["STRINGWARS_AMD_DOUBLING"] = "0"
+    env.update(TEST_LIBRARY_ENV, STRINGWARS_AMD_DOUBLING="0")      # (A / B switches are test hooks since round 6: the test library reads them)
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
     assert done.returncode != 0 or "doubling ok" in done.stdout
     stages = done.stderr.split("STAGES-BEGIN")[1].split("STAGES-END")[0]
@@ -1849,7 +1849,7 @@ def test_utf8_lines_are_staged_string_by_string(orc):
     assert done.returncode == 0 and "strings ok" in done.stdout, done.stderr[-3000:]
     assert "utf8_strings" in done.stderr and done.stderr.count("utf8_strings") >= 20, done.stderr[-2000:]
     # the comparison knob keeps the flat kernel
-    env["STRINGWARS_AMD_UTF8_STAGING"] = "tiles"
+    env.update(TEST_LIBRARY_ENV, STRINGWARS_AMD_UTF8_STAGING="tiles")
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert done.returncode == 0 and "strings ok" in done.stdout, done.stderr[-3000:]
     assert "utf8_strings" not in done.stderr and "utf8_tile_decode" in done.stderr
@@ -1862,7 +1862,7 @@ def test_utf8_string_by_string_staging_validates(orc):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, STRINGWARS_AMD_UTF8_STAGING="strings", PYTHONPATH=child_pythonpath())
+    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_UTF8_STAGING="strings", PYTHONPATH=child_pythonpath())
     picks = ("test_utf8_validation_matches_the_oracle or test_utf8_validation_fuzz or test_utf8_random_scripts or test_small_tapes_and_strings_at_tape_edges "
              "or test_believed_tape_sizes_are_checked_on_the_device or test_kat_levenshtein or test_golden_multilingual_words or test_config3_bounded_utf8 "
              "or test_general_cost_levenshtein_over_code_points or test_patterns_longer_than_64_blocks or test_banded_window_kernel")
@@ -1934,7 +1934,7 @@ def test_tiled_kernel_workgroup_shapes(orc, waves):
         "assert name == 'bitparallel_tiled', name\n"
         "assert (got == oracle.levenshtein_pairs(sa, sb, algo='hyyro')).all()\n"
         "print('tiled shapes ok')\n")
-    env = dict(os.environ, STRINGWARS_AMD_TILED_WAVES=waves, PYTHONPATH=child_pythonpath())
+    env = dict(os.environ, **TEST_LIBRARY_ENV, STRINGWARS_AMD_TILED_WAVES=waves, PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert done.returncode == 0 and "tiled shapes ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
 
@@ -2194,7 +2194,7 @@ def test_comparison_knobs_keep_parity(shapes):
         "    scope.set_profiling(False)\n"
         "    assert (got == oracle.nw_pairs(pa, pb, matrix, *gaps)).all(), gaps\n"
         "print('knobs ok')\n")
-    env = dict(os.environ, **shapes, STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct", STRINGWARS_AMD_NW="classic",
+    env = dict(os.environ, **TEST_LIBRARY_ENV, **shapes, STRINGWARS_AMD_AFFIX="0", STRINGWARS_AMD_SHORT="direct", STRINGWARS_AMD_NW="classic",
                STRINGWARS_AMD_LONG_TICKET="0", STRINGWARS_AMD_BAND_ITEMS="fixed", STRINGWARS_AMD_BAND_CAP="64",
                PYTHONPATH=child_pythonpath())
     done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

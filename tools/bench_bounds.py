@@ -7,7 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BOUNDS = (32, 63, 64, 100, 127, 128, 255)
 if os.environ.get("BENCH_BOUNDS_CHILD") != "1":
     for knob in ("255", "63"):
-        env = dict(os.environ, BENCH_BOUNDS_CHILD="1", STRINGWARS_AMD_BAND_MAX=knob)
+        # (A / B switches are test hooks since round 6: the TEST library reads them, the shipped one does not)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, BENCH_BOUNDS_CHILD="1", STRINGWARS_AMD_BAND_MAX=knob, STRINGWARS_AMD_LIBRARY=os.path.join(root, "stringwars_amd", "libstringwars_amd_test.so"))
         subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, check=True)
     raise SystemExit(0)
 import numpy as np

@@ -8,6 +8,8 @@ Rows: code points on prepared tapes, the same on raw tapes, and the same tapes a
 stage would be tried once and then sit out (nothing to settle); the rows are the block kernels' own."""
 import argparse, json, os, sys, time
 os.environ.setdefault("STRINGWARS_AMD_DOUBLING", "0")
+# (A / B switches are test hooks since round 6: the TEST library reads them, the shipped one does not)
+os.environ.setdefault("STRINGWARS_AMD_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stringwars_amd", "libstringwars_amd_test.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import stringwars_amd as sw

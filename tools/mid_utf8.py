@@ -2,6 +2,7 @@
 stops paying against a launch pair and a stream per tape (STRINGWARS_AMD_UTF8_MERGED_MB)."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
+os.environ.setdefault("STRINGWARS_AMD_LIBRARY", os.path.join(os.getcwd(), "stringwars_amd", "libstringwars_amd_test.so"))   # (the switch is a test hook since round 6)
 import stringwars_amd as sw
 scope = sw.DeviceScope(gpu_device=0)
 for pairs in (2000, 8000, 16000, 32000):

@@ -6,6 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/tile_fetch
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export STRINGWARS_AMD_LIBRARY=$REPO/stringwars_amd/libstringwars_amd_test.so   # (A / B switches are test hooks since round 6)
 for tile in 0 256 512; do
     if [ "$tile" = 0 ]; then unset STRINGWARS_AMD_TILE; else export STRINGWARS_AMD_TILE=$tile; fi
     timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/t$tile" -o fetch -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --prewarm-seconds 0 > "$OUT/t$tile.log" 2>&1

@@ -102,6 +102,17 @@ __device__ __forceinline__ void align_selectors(const uint32_t (&cls)[W / 4], ui
     }
 }
 
+// SWH_LOCAL_LINEAR_CELL (round 6) -- Smith-Waterman with linear gaps, p = |open| = |extend|. With the true H >= 0 in the strip,
+//     H = max(0, Hdiag + s, Hup - p, Hleft - p) = sat( max3(Hdiag + (s + p), Hup, Hleft) - p )
+// (the maximum is >= Hup >= 0, so "max with 0 after subtracting p" is one unsigned saturating subtraction, `v_sub_u32 ... clamp`): the
+// class table already holds s - open = s + p, and a cell is `v_add_u32_sdwa ; v_max3_i32 ; v_sub_u32 clamp` -- three instructions where
+// max(., 0), the running maximum and + open made it five. The running maximum is taken over the max3 values, two per v_max3, and
+// loses its p once, at the end. (Gotoh keeps H + open in its strips: sharing sat(H - |open|) between the cell below and the cell to
+// the right needs a second register row, which the 128-column kernels do not have.)
+__device__ __forceinline__ int align_local_linear_best(int best_of_max3, int open) {
+    return (int)__builtin_elementwise_sub_sat((uint32_t)best_of_max3, (uint32_t)-open);
+}
+
 // One group of four cells of one DP row, updated in place: `H` holds the row above on entry (the previous row's values) and this
 // row's on exit. `c4` = the four substitution scores (biased as the table is), `diag` / `left` / `e` travel along the row. The four
 // diagonal sums read the OLD row before any cell of the group is overwritten; the last instruction of a cell has H[k] as a tied
@@ -117,6 +128,8 @@ __device__ __forceinline__ void align_group(int (&H)[W], int (&F)[kAffine ? W : 
     t[2] = H[g4 + 1] + (int)(int8_t)(c4 >> 16);
     t[3] = H[g4 + 2] + (int)(int8_t)(c4 >> 24);
     diag = H[g4 + 3];
+    [[maybe_unused]] const int gap = -open;   // (local, linear) |open| = |extend|
+    [[maybe_unused]] int mx_even = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = g4 + u;
@@ -135,10 +148,10 @@ __device__ __forceinline__ void align_group(int (&H)[W], int (&F)[kAffine ? W : 
             const int h3 = max(max(max(t[u], e), f), 0);
             best = max(best, h3);
             asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open));
-        } else {                          // local, linear
-            const int h3 = max(max(max(t[u], H[k]), left), 0);
-            best = max(best, h3);
-            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open));
+        } else {                          // local, linear: the strip holds the TRUE H >= 0 (SWH_LOCAL_LINEAR_CELL)
+            const int mx = max(max(t[u], H[k]), left);
+            if (u & 1) best = max(max(best, mx_even), mx); else mx_even = mx;
+            asm("v_sub_u32_e64 %0, %1, %2 clamp" : "+v"(H[k]) : "v"(mx), "v"(gap));
         }
         left = H[k];
     }
@@ -164,7 +177,7 @@ __device__ __forceinline__ int align_rows(const uint32_t (&acls)[W / 4], uint32_
     const int open_minus_ext = open - ext;
     int H[W];
     [[maybe_unused]] int F[kAffine ? W : 1];
-    const int row0 = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);
+    const int row0 = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : 2 * open_minus_ext);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         H[k] = row0;
@@ -186,8 +199,8 @@ __device__ __forceinline__ int align_rows(const uint32_t (&acls)[W / 4], uint32_
         if constexpr (PQ > 2) hi_next = *(const uint4 *)(ltable + (rowq[0] & 0xffu) * 32 + 16);
         if (i < m) {
             // boundary column: H of (row i + 1, column 0) on the left, of (row i, column 0) on the diagonal
-            int left = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);
-            int diag = kLocal ? open : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext));
+            int left = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : 2 * open_minus_ext);
+            int diag = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext));
             [[maybe_unused]] int e = kAlignNegInf;
 #pragma unroll
             for (int g4 = 0; g4 < W; g4 += 4) {
@@ -204,6 +217,8 @@ __device__ __forceinline__ int align_rows(const uint32_t (&acls)[W / 4], uint32_
                     t[2] = H[g4 + 1] + (int)(int8_t)(c4 >> 16);
                     t[3] = H[g4 + 2] + (int)(int8_t)(c4 >> 24);
                     diag = H[g4 + 3];
+                    [[maybe_unused]] const int gap = -open;   // (local, linear) |open| = |extend|
+                    [[maybe_unused]] int mx_even = 0;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int k = g4 + u;
@@ -222,10 +237,10 @@ __device__ __forceinline__ int align_rows(const uint32_t (&acls)[W / 4], uint32_
                             const int h3 = max(max(max(t[u], e), f), 0);
                             best = max(best, h3);
                             asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open));
-                        } else {                          // local, linear
-                            const int h3 = max(max(max(t[u], H[k]), left), 0);
-                            best = max(best, h3);
-                            asm("v_add_u32 %0, %1, %2" : "+v"(H[k]) : "v"(h3), "v"(open));
+                        } else {                          // local, linear: the strip holds the TRUE H >= 0 (SWH_LOCAL_LINEAR_CELL)
+                            const int mx = max(max(t[u], H[k]), left);
+                            if (u & 1) best = max(max(best, mx_even), mx); else mx_even = mx;
+                            asm("v_sub_u32_e64 %0, %1, %2 clamp" : "+v"(H[k]) : "v"(mx), "v"(gap));
                         }
                         left = H[k];
                     }
@@ -233,7 +248,7 @@ __device__ __forceinline__ int align_rows(const uint32_t (&acls)[W / 4], uint32_
             }
         }
     }
-    if constexpr (kLocal) return best;
+    if constexpr (kLocal) return kAffine ? best : align_local_linear_best(best, open);
     int result = 0;
 #pragma unroll
     for (int k = 0; k < W; ++k)
@@ -257,7 +272,7 @@ __device__ __forceinline__ int align_rows_uniform(const uint8_t *rowcls, uint32_
     const int open_minus_ext = open - ext;
     int H[W];
     int F[kAffine ? W : 1];
-    const int row0 = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);
+    const int row0 = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : 2 * open_minus_ext);
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         H[k] = row0;
@@ -276,14 +291,14 @@ __device__ __forceinline__ int align_rows_uniform(const uint8_t *rowcls, uint32_
     uint4 a_lo{0, 0, 0, 0}, a_hi{0, 0, 0, 0}, b_lo{0, 0, 0, 0}, b_hi{0, 0, 0, 0};
     fetch(0, a_lo, a_hi);
     fetch(1, b_lo, b_hi);
-    const int edge = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);
+    const int edge = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : 2 * open_minus_ext);
     uint32_t i = 0;
     for (; i + 1 < m; i += 2) {
         const uint4 ra_lo = a_lo, ra_hi = a_hi, rb_lo = b_lo, rb_hi = b_hi;
         fetch(i + 2, a_lo, a_hi);      // the next pair's costs are requested before this pair's cells
         fetch(i + 3, b_lo, b_hi);
         int left_a = edge, left_b = edge, e_a = kAlignNegInf, e_b = kAlignNegInf;
-        int diag_a = kLocal ? open : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext)), diag_b = edge;
+        int diag_a = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext)), diag_b = edge;
 #pragma unroll
         for (int g4 = 0; g4 <= W; g4 += 4) {
             if (g4 < W && (uint32_t)g4 < n_max)
@@ -294,13 +309,13 @@ __device__ __forceinline__ int align_rows_uniform(const uint8_t *rowcls, uint32_
     }
     if (i < m) {   // an odd row count: the last row on its own
         int left = edge, e = kAlignNegInf;
-        int diag = kLocal ? open : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext));
+        int diag = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : (i == 0 ? open_minus_ext : 2 * open_minus_ext));
 #pragma unroll
         for (int g4 = 0; g4 < W; g4 += 4)
             if ((uint32_t)g4 < n_max)
                 align_group<W, kAffine, kLocal>(H, F, g4, align_costs4<PQ>(a_lo, a_hi, sel + (g4 >> 2) * PQ), diag, left, e, best, open, ext, open_minus_ext);
     }
-    if constexpr (kLocal) return best;
+    if constexpr (kLocal) return kAffine ? best : align_local_linear_best(best, open);
     int result = 0;
 #pragma unroll
     for (int k = 0; k < W; ++k)
@@ -689,8 +704,8 @@ __device__ __forceinline__ void align_pass(const uint8_t *rowcls, uint32_t m, co
     const int open_minus_ext = open - ext;
     int H[W];
     int F[kAffine ? W : 1];
-    const int edge = kLocal ? open : (kSkew ? 0 : 2 * open_minus_ext);   // row 0 right of the corner, and the DP's own left edge below it
-    const int corner = kLocal ? open : (kSkew ? 0 : (first ? open_minus_ext : 2 * open_minus_ext));
+    const int edge = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : 2 * open_minus_ext);   // row 0 right of the corner, and the DP's own left edge below it
+    const int corner = kLocal ? (kAffine ? open : 0) : (kSkew ? 0 : (first ? open_minus_ext : 2 * open_minus_ext));
 #pragma unroll
     for (int k = 0; k < W; ++k) {
         H[k] = edge;
@@ -891,7 +906,7 @@ __global__ __launch_bounds__(kAlignWaves * 64, 2) void k_align_cross_long(AlignS
             if (fits) {
                 int score;
                 if (!n || !qlen) score = align_trivial(qlen, lb, kLocal, open, ext);
-                else if constexpr (kLocal) score = best;
+                else if constexpr (kLocal) score = kAffine ? best : align_local_linear_best(best, open);
                 else if constexpr (kAffine) score = result + (int)(qlen + n) * ext - open_minus_ext;
                 else score = result + (int)(qlen + n) * ext;
                 char *dst = job.out + (q_first + q) * job.row_stride + cand * elem;

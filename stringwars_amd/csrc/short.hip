@@ -447,12 +447,14 @@ __device__ __forceinline__ void short_run(const ShortArgs &args, ShortLds &lds) 
             };
             struct Raw { uint32_t p[5], t[5]; };
             // the strings as aligned dwords (realigned in registers when their item starts)
-            auto strings = [&](const uint2 &d) -> Raw {
-                Raw r;
+            auto strings = [&](const uint2 &d) -> Raw {   // bytes 8 .. 15 only when some lane of the item has that many
+                Raw r{};
                 const uint32_t pat = d.x & 0xFFFFu, txt = d.x >> 16;
                 const uint32_t *pp = (const uint32_t *)((const uint8_t *)&lds + (pat & ~3u)), *tp = (const uint32_t *)((const uint8_t *)&lds + (txt & ~3u));
 #pragma unroll
-                for (int k = 0; k < 5; ++k) { r.p[k] = pp[k]; r.t[k] = tp[k]; }
+                for (int k = 0; k < 3; ++k) { r.p[k] = pp[k]; r.t[k] = tp[k]; }
+                if (__builtin_amdgcn_ballot_w64((d.y & 0xFFu) > 8u)) { r.p[3] = pp[3]; r.p[4] = pp[4]; }
+                if (__builtin_amdgcn_ballot_w64(((d.y >> 8) & 0xFFu) > 8u)) { r.t[3] = tp[3]; r.t[4] = tp[4]; }
                 return r;
             };
             uint32_t round = 0, t = ticket_of(0);

@@ -102,6 +102,9 @@ LEGS = {
     "c3_raw_cold": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, cold=3, variant="k32", check=5_000,
                         text="C3 on raw device tapes the scope has not seen in its previous call (three copies of the tapes in turn: the library's "
                              "beliefs about a tape's byte total and its ASCII-ness never apply)"),
+    "c3_raw_forget": dict(workload="utf8_lines", pairs=100_000, kind="lev_utf8", bound=32, prepared=False, forget=True, variant="k32", check=5_000,
+                          text="C3 on raw device tapes with swh_scope_forget() before every call: a history-free call, the reference's compute_into "
+                               "semantics (bench.rs:478-486) -- what the scope's beliefs are worth is the distance to c3_raw"),
     "utf8_unrelated_raw": dict(workload="script_lines", pairs=50_000, kind="lev_utf8", prepared=False, variant="unbounded", check=2_500,
                                text="UNRELATED article lines of 700-1300 code points, one script each (Latin / Cyrillic / Greek / Arabic / Devanagari), unbounded "
                                     "Levenshtein over code points on raw device tapes: what the reference's cross-product of XLSum lines pairs up for "
@@ -137,7 +140,7 @@ LEGS = {
                      text="NW on word-sized strings (the reference's default `words` token mode, bench.rs:271): 4 M pairs <= 16 B, "
                           "unary_class_costs(2, -1) as a 32-class table, linear gaps -2 -- one pair per lane (alignshort.hip)"),
 }
-DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words",
+DEFAULT_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "c3_raw_forget", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words",
                 "sw_linear", "sw_affine", "cross_lev", "cross_nw"]
 
 
@@ -424,6 +427,10 @@ def run_leg(name, sw, scope, torch, device, seed, constants, calls=0, pairs_over
             ta, tb = copies[turn[0] % len(copies)]
             turn[0] += 1
             return engine.pairs(ta, tb, scope, bound=leg.get("bound"), out=out)
+    elif leg.get("forget"):
+        def call():
+            scope.forget()
+            return engine.pairs(da, db, scope, bound=leg.get("bound"), out=out)
     else:
         call = lambda: engine.pairs(da, db, scope, bound=leg.get("bound"), out=out)
     made = 0

@@ -285,7 +285,7 @@ static void launch_banded_items(Scope *scope, const KernelArgs &args, uint64_t p
 template <typename Sym, int WBITS>
 static void launch_banded_one(Scope *scope, const KernelArgs &args, uint64_t pairs) {
     // Items of at most 32 pairs: 40 KB of LDS per workgroup, four workgroups = sixteen waves per CU. Measured on C3's 100 K
-    // pairs with the items sized by the kernel: capacity 20 / 24 / 32 / 40 / 64 (6 / 5 / 4 / 3 / 2 workgroups
+    // pairs with the items sized by the kernel (DESIGN_HISTORY.md, round-5 text 4.3): capacity 20 / 24 / 32 / 40 / 64 (6 / 5 / 4 / 3 / 2 workgroups
     // per CU): 0.356 / 0.344 / 0.331 / 0.351 / 0.450 ms; at 150 K - 800 K pairs 32 beats 64 by 13-17 % as well.
     // STRINGWARS_AMD_BAND_CAP=64: the large items (comparison knob).
     static const int forced = [] { const char *e = test_hook("STRINGWARS_AMD_BAND_CAP"); return e ? atoi(e) : 0; }();

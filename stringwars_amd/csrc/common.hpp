@@ -608,9 +608,9 @@ void launch_utf8_strings(Scope *scope, const Utf8StringsJob &a, const Utf8String
 void launch_utf8_decode_pair(Scope *scope, const Utf8Args &a, const Utf8Args *b, uint64_t first_word, bool opened);
 void utf8_status_open(Scope *scope, uint64_t words);
 
-// Environment switches come in two kinds. Comparison / tuning knobs are read ONCE per process by whoever uses them.
-// Test hooks -- fault injection, shapes no input reaches, the UTF-8 staging of rounds 1-2 kept as the tests' second implementation --
-// exist in the TEST library only (`make test-lib`: -DSWH_TEST_HOOKS -> libstringwars_amd_test.so, which the tests that need a hook
+// Environment switches. The shipped library reads four: TRACE, STAMPS, EARLY_RETURN, SHARD_CHECK. Everything else --
+// the A / B switches measurements were taken with, fault injection, shapes no input reaches, the UTF-8 staging of rounds 1-2 kept as
+// the tests' second implementation -- is a TEST HOOK and exists in the TEST library only (`make test-lib`: -DSWH_TEST_HOOKS -> libstringwars_amd_test.so, which the tests that need a hook
 // load in a child process); the shipped library does not look at them and does not carry the code behind them.
 inline const char *test_hook(const char *name) {
 #ifdef SWH_TEST_HOOKS

@@ -62,7 +62,7 @@ def test_bench_legs_cover_every_baseline_config():
     configs beside the headline C2, each at its full size -- and the two shapes round 4 added kernels for (C3's lines at k = 100,
     NW on word-sized strings)."""
     bench = load(os.path.join(ROOT, "bench.py"), "bench_module_legs")
-    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words",
+    assert bench.DEFAULT_LEGS == ["c1", "c3", "c3_raw", "c3_raw_cold", "c3_raw_forget", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes", "c4_letters52", "c5", "nw_words",
                                   "sw_linear", "sw_affine", "cross_lev", "cross_nw"]
     # Smith-Waterman on C4's sequences (bench.rs:882-963) and the reference's own call shape, compute_into(queries, candidates, &mut matrix) (bench.rs:478-486)
     assert bench.LEGS["sw_linear"]["local"] and bench.LEGS["sw_affine"]["gaps"] == (-11, -1) and bench.LEGS["cross_lev"]["side"] == bench.LEGS["cross_nw"]["side"] == 2048

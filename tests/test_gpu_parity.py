@@ -2201,7 +2201,7 @@ def test_comparison_knobs_keep_parity(shapes):
     assert done.returncode == 0 and "knobs ok" in done.stdout, (done.stdout[-500:], done.stderr[-2000:])
 
 
-BENCH_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes",
+BENCH_LEGS = ["c1", "c3", "c3_raw", "c3_raw_cold", "c3_raw_forget", "utf8_unbounded_raw", "utf8_unrelated_raw", "c3_k100", "c4_linear", "c4_affine", "c4_bytes",
               "c4_letters52", "c5", "nw_words", "sw_linear", "sw_affine", "cross_lev", "cross_nw"]
 
 

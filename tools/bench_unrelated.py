@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Measuring tool: UNRELATED lines through the UTF-8 engine, unbounded -- what the reference's cross-product of article lines is made
-of (similarities/README.md:39-40, :56: XLSum lines, one language per line), and what the two-stage schedule (DESIGN §4.3b) cannot settle.
+of (similarities/README.md:39-40, :56: XLSum lines, one language per line), and what the two-stage schedule (DESIGN.md §4.6) cannot settle.
 Lines of ~1000 code points, each in ONE script (its letters + ASCII punctuation / digits / spaces), pair i = (line i, line i + 1):
     python tools/bench_unrelated.py [--pairs 50000] [--scripts cyrillic,latin,...] [--cps 700,1300] [--mixed]
 --mixed: C3's synthetic lines instead (four scripts in every line, ~340 distinct symbols: beyond a 255-slot dictionary).

@@ -9,10 +9,10 @@ mkdir -p "$OUT"
 cd "$REPO"
 # entries of legs that are not re-profiled in this run stay as committed (a fresh box has no gpurun_out/)
 [ -f "$OUT/pmc_constants.json" ] || cp profiles/r6/pmc_constants.json "$OUT/pmc_constants.json" 2>/dev/null || cp profiles/r5/pmc_constants.json "$OUT/pmc_constants.json" 2>/dev/null
-LEGS=${*:-c2 c1 c3 c3_raw c3_raw_cold utf8_unbounded_raw utf8_unrelated_raw c3_k100 c4_linear c4_affine c4_bytes c4_letters52 c5 nw_words sw_linear sw_affine cross_lev cross_nw}
-declare -A WORKLOAD=([c1]=words16 [c2]=tokens64 [c3]=utf8_lines [c3_raw]=utf8_lines [c3_raw_cold]=utf8_lines [utf8_unbounded_raw]=utf8_lines [utf8_unrelated_raw]=script_lines [c3_k100]=utf8_lines [nw_words]=words16 [c4_linear]=protein4k [c4_affine]=protein4k [c4_bytes]=bytes4k [c4_letters52]=bytes4k [c5]=short_words [sw_linear]=protein4k [sw_affine]=protein4k [cross_lev]=acgt100 [cross_nw]=acgt100)
-declare -A PAIRS=([c1]=10000 [c2]=1000000 [c3]=100000 [c3_raw]=100000 [c3_raw_cold]=100000 [utf8_unbounded_raw]=100000 [utf8_unrelated_raw]=50000 [c3_k100]=100000 [nw_words]=4000000 [c4_linear]=10000 [c4_affine]=10000 [c4_bytes]=10000 [c4_letters52]=10000 [c5]=20000000 [sw_linear]=10000 [sw_affine]=10000 [cross_lev]=4194304 [cross_nw]=4194304)
-declare -A VARIANT=([c1]="" [c2]="" [c3]=k32 [c3_raw]=k32 [c3_raw_cold]=k32 [utf8_unbounded_raw]=unbounded [utf8_unrelated_raw]=unbounded [c3_k100]=k100 [nw_words]=unary_linear [c4_linear]=linear [c4_affine]=affine [c4_bytes]=linear [c4_letters52]=letters52 [c5]="" [sw_linear]=sw_linear [sw_affine]=sw_affine [cross_lev]=cross [cross_nw]=cross_linear)
+LEGS=${*:-c2 c1 c3 c3_raw c3_raw_cold c3_raw_forget utf8_unbounded_raw utf8_unrelated_raw c3_k100 c4_linear c4_affine c4_bytes c4_letters52 c5 nw_words sw_linear sw_affine cross_lev cross_nw}
+declare -A WORKLOAD=([c1]=words16 [c2]=tokens64 [c3]=utf8_lines [c3_raw]=utf8_lines [c3_raw_cold]=utf8_lines [c3_raw_forget]=utf8_lines [utf8_unbounded_raw]=utf8_lines [utf8_unrelated_raw]=script_lines [c3_k100]=utf8_lines [nw_words]=words16 [c4_linear]=protein4k [c4_affine]=protein4k [c4_bytes]=bytes4k [c4_letters52]=bytes4k [c5]=short_words [sw_linear]=protein4k [sw_affine]=protein4k [cross_lev]=acgt100 [cross_nw]=acgt100)
+declare -A PAIRS=([c1]=10000 [c2]=1000000 [c3]=100000 [c3_raw]=100000 [c3_raw_cold]=100000 [c3_raw_forget]=100000 [utf8_unbounded_raw]=100000 [utf8_unrelated_raw]=50000 [c3_k100]=100000 [nw_words]=4000000 [c4_linear]=10000 [c4_affine]=10000 [c4_bytes]=10000 [c4_letters52]=10000 [c5]=20000000 [sw_linear]=10000 [sw_affine]=10000 [cross_lev]=4194304 [cross_nw]=4194304)
+declare -A VARIANT=([c1]="" [c2]="" [c3]=k32 [c3_raw]=k32 [c3_raw_cold]=k32 [c3_raw_forget]=k32 [utf8_unbounded_raw]=unbounded [utf8_unrelated_raw]=unbounded [c3_k100]=k100 [nw_words]=unary_linear [c4_linear]=linear [c4_affine]=affine [c4_bytes]=linear [c4_letters52]=letters52 [c5]="" [sw_linear]=sw_linear [sw_affine]=sw_affine [cross_lev]=cross [cross_nw]=cross_linear)
 CALLS=3
 declare -A LEG_CALLS=([utf8_unbounded_raw]=9 [utf8_unrelated_raw]=9 [c3_k100]=9)   # two-stage calls: the first call of a scope runs in one stage (no lengths, no record yet) -- diluted
 # 1. PMC passes per config: exactly $CALLS engine calls each -> per-call totals in pmc_constants.json (stamped with a digest
@@ -27,7 +27,7 @@ for leg in $LEGS; do
     tag=$(echo $set | cut -d' ' -f1)
     timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$dir" -o "$tag" -- python3 "$REPO/bench.py" --only-config $leg --calls $CALLS --no-cpu-baseline > "$dir/$tag.log" 2>&1
   done
-  if [ "$leg" != c3_raw ] && [ "$leg" != c3_raw_cold ]; then   # (they share c3's dominant kernel and key: their passes are kept as JSON summaries only)
+  if [ "$leg" != c3_raw ] && [ "$leg" != c3_raw_cold ] && [ "$leg" != c3_raw_forget ]; then   # (they share c3's dominant kernel and key: their passes are kept as JSON summaries only)
     python3 "$REPO/tools/pmc_constants.py" "$dir" --workload ${WORKLOAD[$leg]} --pairs ${PAIRS[$leg]} --calls $CALLS --variant "${VARIANT[$leg]}" --out "$OUT/pmc_constants.json" \
       --source "rocprofv3 --pmc passes over 'bench.py --only-config $leg --calls $CALLS --no-cpu-baseline' (tools/refresh_profiles.sh)"
   fi

@@ -1,6 +1,6 @@
 #!/bin/bash
 # FETCH_SIZE and time per launch of k_bitparallel_tiled against the tile size (STRINGWARS_AMD_TILE): how much of C2's fetch
-# traffic is tiles pushing each other out of the XCD's L2 (DESIGN.md 5). Writes gpurun_out/tile_fetch/summary.txt.
+# traffic is tiles pushing each other out of the XCD's L2 (DESIGN.md §4.2). Writes gpurun_out/tile_fetch/summary.txt.
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/tile_fetch

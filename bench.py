@@ -203,6 +203,10 @@ def kernel_family(stamp):
     return stamp
 
 
+# kernel families whose launches one engine call can hold together (api.hip: the two-stage schedule; the planned alignment path)
+CO_RUNNING = ({"banded", "bitparallel", "bitparallel_u32", "bitparallel_long", "bitparallel_long_u32"}, {"nwprofile", "wavefront"})
+
+
 def roofline_of(kernel, kernel_ms, cells, algorithmic_bytes, workload, pairs, constants, extra=None, variant="", model="lev"):
     """Roofline object of one call's dominant kernel family. `achieved` is EXECUTED work: SQ_INSTS_VALU (wave instructions
     of every dispatch of the family in one call, PMC) x 64 lanes / the time those kernels cover, measured live with hipEvents
@@ -228,9 +232,12 @@ def roofline_of(kernel, kernel_ms, cells, algorithmic_bytes, workload, pairs, co
     if entry and seconds > 0:
         # a call may run DP kernels of several families (the two stages of a doubling call: the band, then bit-parallel blocks; an alignment
         # call's profile kernel and wavefront classes): `kernel_ms` is the time they cover together, so their instructions are summed
+        # (only families that can run in ONE call beside the dominant one -- the two stages of a doubling call, an alignment call's profile
+        # kernel and wavefront classes --, never whatever else happens to share the workload's name: advisor, round 5)
         suffix = key[len(kernel):]
+        beside = next((group for group in CO_RUNNING if kernel in group), {kernel})
         others = {k: v for k, v in constants.get("kernels", {}).items()
-                  if k != key and k.endswith(suffix) and k[:len(k) - len(suffix)] in KERNEL_SOURCES and not k.startswith(("utf8_", "plan_"))
+                  if k != key and k.endswith(suffix) and k[:len(k) - len(suffix)] in beside
                   and v.get("pairs_per_call", v.get("pairs_per_launch")) == per_call}
         lane_ops = (entry["valu_insts"] + sum(v["valu_insts"] for v in others.values())) * scale * 64
         if others:

@@ -2809,3 +2809,55 @@ def test_scope_beliefs_can_be_read_and_dropped(sw, orc):
     scope.set_profiling(False)
     scope.forget()
     assert scope.describe()["align_wide_off_engine"] == "0"
+
+
+@pytest.mark.parametrize("gaps", [(0, 0), (-1, -1), (-4096, -4096), (-3, -1), (-4096, 0), (-60, -60)])
+def test_smith_waterman_saturating_cells_at_their_edges(sw, orc, scope, gaps):
+    """Round 6's Smith-Waterman cells floor at zero by UNSIGNED SATURATING subtraction (`v_sub_u32 ... clamp`) and, for Gotoh, take their
+    plain maxima as `v_max_u16` when no score of the batch can reach 2^16 (largest cost x the shorter side's longest string). The edges:
+    free gaps, gaps far larger than any score, and scores on both sides of 2^16 -- identical strings of 2000 symbols under diagonals of 30
+    (60 000: the 16-bit maxima) and of 40 (80 000: the 32-bit ones) --, on the column-profile kernel (pairs of more than 384 columns) and on the
+    lane kernels (word-sized and 100-symbol strings), pairwise and as a cross-product."""
+    rng = np.random.default_rng(77 + abs(gaps[0]) + abs(gaps[1]))
+    for diagonal in (30, 40):
+        matrix = rng.integers(-12, 6, (256, 256)).astype(np.int8)
+        matrix = np.minimum(matrix, matrix.T)
+        classes = 12
+        fold = (np.arange(256) % classes).astype(np.uint8)                      # 12 symbol classes
+        table = matrix[:classes, :classes].copy()
+        np.fill_diagonal(table, diagonal)
+        full = table[fold][:, fold].astype(np.int8)
+        engine = sw.SmithWatermanScores(substitution_matrix=full, open=gaps[0], extend=gaps[1], capabilities=scope)
+        items_a, items_b = [], []
+        same = rng.integers(0, 256, 2000, dtype=np.uint8).tobytes()
+        items_a.append(same); items_b.append(same)                               # score = 2000 x diagonal
+        for n in (385, 700, 1300, 2100):
+            x = bytearray(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+            y = bytearray(x)
+            for at in rng.integers(0, n, n // 9):
+                y[int(at)] = int(rng.integers(0, 256))
+            del y[n // 3:n // 3 + 17]
+            items_a.append(bytes(x)); items_b.append(bytes(y))
+            items_a.append(bytes(y)); items_b.append(bytes(rng.integers(0, 256, n + 5, dtype=np.uint8).tobytes()))
+        a, b = sw.Strs(items_a), sw.Strs(items_b)
+        got = engine.pairs(a, b, scope)
+        want = [orc.nw_score(items_a[i], items_b[i], full, gaps[0], gaps[1], local=True) for i in range(len(items_a))]
+        assert [int(x) for x in got] == want, (gaps, diagonal)
+        assert int(got[0]) == 2000 * diagonal
+        assert (engine.pairs(sw.PreparedTape(scope, a), sw.PreparedTape(scope, b), scope) == got).all()
+    if gaps[0] == gaps[1] or gaps == (-3, -1):
+        # the lane kernels (alignshort.hip): word-sized pairs and a small-alphabet cross-product of 100-symbol strings
+        byte_to_class, class_costs = sw.unary_class_costs(2, -1)
+        table = class_costs[byte_to_class][:, byte_to_class].astype(np.int8)
+        engine = sw.SmithWatermanScores(byte_to_class, class_costs, open=gaps[0], extend=gaps[1], capabilities=scope)
+        words_a = [rng.integers(97, 101, int(rng.integers(0, 17)), dtype=np.uint8).tobytes() for _ in range(3000)]
+        words_b = [w if i % 3 == 0 else rng.integers(97, 101, int(rng.integers(0, 17)), dtype=np.uint8).tobytes() for i, w in enumerate(words_a)]
+        wa, wb = sw.Strs(words_a), sw.Strs(words_b)
+        got = engine.pairs(sw.PreparedTape(scope, wa), sw.PreparedTape(scope, wb), scope)
+        want = [orc.nw_score(words_a[i], words_b[i], table, gaps[0], gaps[1], local=True) for i in range(len(words_a))]
+        assert [int(x) for x in got] == want, gaps
+        dna = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(60, 129)))].tobytes() for _ in range(90)]
+        q, c = sw.Strs(dna[:20]), sw.Strs(dna[20:])
+        grid = engine(sw.PreparedTape(scope, q), sw.PreparedTape(scope, c), scope)
+        for i in (0, 7, 19):
+            assert [int(x) for x in grid[i]] == [orc.nw_score(dna[i], dna[20 + j], table, gaps[0], gaps[1], local=True) for j in range(70)], (gaps, i)
